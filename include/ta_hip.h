@@ -1,0 +1,130 @@
+/* ta_hip.h — C-ABI of the MI355X time-correlation library (libta_hip.so).
+ *
+ * This is the drop-in boundary for transport-analysis's time-correlation hot
+ * path.  The reference has no native seam of its own (it is pure Python); the
+ * entry points below are what a ctypes binding inside the reference's
+ * `_prepare` / `_single_frame` / `_conclude` hooks calls, and each one cites
+ * the reference code it replaces (paths relative to
+ * /root/reference/transport_analysis).  See INTEGRATION.md for the binding.
+ *
+ * Conventions
+ *   - every call returns int: 0 = TA_OK, negative = error (TA_E_*);
+ *     ta_last_error() returns a human-readable message for the last failure
+ *     on that context (or on the calling thread when ctx is NULL).
+ *   - slabs are the reference's layout: (n_frames, n_atoms, dim) row-major,
+ *     float64 (velocityautocorr.py:150-152, viscosity.py:128-134).
+ *   - outputs are caller-owned.  "lagsum" outputs are lag-indexed SUMS over the
+ *     atoms handled by this call, already divided by the frame-pair count
+ *     (n_frames - lag): lagsum[k] = sum_n by_particle[k, n].  The caller divides
+ *     by the total atom count after the (optional) cross-GPU reduce; this is the
+ *     only cross-atom operation of the path (velocityautocorr.py:214,237,
+ *     viscosity.py:233).
+ *   - by_particle outputs are (n_frames, ld_bp) row-major float64 with
+ *     ld_bp >= n_atoms (results.vacf_by_particle / results.visc_by_particle,
+ *     velocityautocorr.py:145-147, viscosity.py:117-119); pass NULL to skip.
+ *   - pointers named d_* are DEVICE pointers valid on the context's GPU;
+ *     pointers named h_* are host pointers.
+ *   - `stream` is a hipStream_t (void*); NULL = the context's own stream.
+ *     The *_dev entry points are asynchronous on that stream; host-facing
+ *     entry points block until results are in the host buffers.
+ *   - one context per analysis object; calls on one context are not re-entrant.
+ *   - there is NO CPU fallback: without a usable GPU ta_ctx_create fails.
+ */
+#ifndef TA_HIP_H
+#define TA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TA_OK 0
+#define TA_E_INVALID -1   /* bad argument (shape, NULL, unsupported dim) */
+#define TA_E_NOMEM -2     /* host or device allocation failed */
+#define TA_E_HIP -3       /* a HIP runtime call or kernel launch failed */
+#define TA_E_STATE -4     /* call order violated (e.g. compute before staging) */
+#define TA_E_UNSUPPORTED -5
+
+#define TA_F32 0
+#define TA_F64 1
+
+typedef struct ta_ctx ta_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+int ta_ctx_create(int device, ta_ctx **out);
+int ta_ctx_destroy(ta_ctx *ctx);
+const char *ta_last_error(const ta_ctx *ctx);
+/* number of visible HIP devices (0 when none / runtime unusable) */
+int ta_device_count(void);
+/* library ABI version, bumped on any signature change */
+int ta_abi_version(void);
+
+/* ---- staging: replaces the per-frame slab fills ------------------------
+ * VelocityAutocorr._prepare/_single_frame (velocityautocorr.py:142-153,178-194)
+ * ViscosityHelfand._prepare/_single_frame (viscosity.py:111-142,167-199)
+ *
+ * ta_stage_alloc allocates n_slabs pinned host slabs of (n_frames, n_atoms,
+ * dim) elements of `dtype` plus matching device slabs; h_slabs[i] receives the
+ * host pointers, which the Python side wraps as NumPy arrays and fills frame
+ * by frame.  ta_stage_commit copies frames [frame_lo, frame_hi) of every slab
+ * host->device asynchronously (f32 slabs are widened to f64 on the device).
+ * ta_stage_device returns the float64 device slab i (valid until the next
+ * ta_stage_alloc / ta_ctx_destroy).                                        */
+int ta_stage_alloc(ta_ctx *ctx, int64_t n_frames, int64_t n_atoms, int dim, int dtype,
+                   int n_slabs, void **h_slabs);
+int ta_stage_commit(ta_ctx *ctx, int64_t frame_lo, int64_t frame_hi);
+int ta_stage_device(ta_ctx *ctx, int slab, double **d_slab);
+int ta_stage_free(ta_ctx *ctx);
+
+/* ---- compute on staged slabs (host-facing, blocking) -------------------
+ * ta_vacf_fft     : VelocityAutocorr._conclude_fft    (velocityautocorr.py:208-215,
+ *                   incl. tidynamics.acf at :211-213)
+ * ta_vacf_direct  : VelocityAutocorr._conclude_simple (velocityautocorr.py:217-238)
+ * ta_helfand_msd  : ViscosityHelfand._conclude        (viscosity.py:201-233);
+ *                   slab 0 = velocities, slab 1 = positions; `scale` is
+ *                   1 / (2 * kB * mean(volumes) * temp_avg) (viscosity.py:229-231)
+ * h_timeseries: (n_frames,) = mean over atoms; h_by_particle: (n_frames, n_atoms)
+ * or NULL.                                                                   */
+int ta_vacf_fft(ta_ctx *ctx, double *h_timeseries, double *h_by_particle);
+int ta_vacf_direct(ta_ctx *ctx, double *h_timeseries, double *h_by_particle);
+int ta_helfand_msd(ta_ctx *ctx, const double *h_masses, double scale, double *h_timeseries,
+                   double *h_by_particle);
+
+/* ---- compute on caller-provided device memory (asynchronous) -----------
+ * Same arithmetic as above on a device-resident shard: d_vel / d_pos are
+ * (n_frames, n_atoms, dim) float64 with row stride ld_row elements between
+ * frames (ld_row >= n_atoms*dim; == for a dense slab, larger when the shard is a
+ * column block of a wider slab).  d_lagsum: (n_frames,) SUM over this shard's
+ * atoms.  d_by_particle: (n_frames, ld_bp) or NULL.  Used by the multi-GPU
+ * path (one shard per rank, then one RCCL reduce of d_lagsum) and by bench.py. */
+int ta_vacf_fft_dev(ta_ctx *ctx, const double *d_vel, int64_t n_frames, int64_t n_atoms,
+                    int dim, int64_t ld_row, double *d_lagsum, double *d_by_particle,
+                    int64_t ld_bp, void *stream);
+int ta_vacf_direct_dev(ta_ctx *ctx, const double *d_vel, int64_t n_frames, int64_t n_atoms,
+                       int dim, int64_t ld_row, double *d_lagsum, double *d_by_particle,
+                       int64_t ld_bp, void *stream);
+int ta_helfand_msd_dev(ta_ctx *ctx, const double *d_vel, const double *d_pos,
+                       const double *d_masses, int64_t n_frames, int64_t n_atoms, int dim,
+                       int64_t ld_row, double scale, double *d_lagsum,
+                       double *d_by_particle, int64_t ld_bp, void *stream);
+
+/* ---- instrumentation ----------------------------------------------------
+ * Device time of the last *_dev / host-facing compute call on this context,
+ * measured with hipEvents recorded on the stream the kernels were launched on.
+ * total_ms covers the whole launch sequence; main_kernel_ms only the dominant
+ * kernel (FFT accumulate pass / direct correlator).  Blocks until the events
+ * have completed.                                                            */
+int ta_last_timing(ta_ctx *ctx, float *total_ms, float *main_kernel_ms);
+/* FFT length bookkeeping for a given n_frames: *m_out = padded half-length M
+ * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1).        */
+int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_stages);
+/* tuning knob (bench/experiments): number of persistent workgroups for the FFT
+ * accumulate kernel; 0 = automatic. */
+int ta_set_option(ta_ctx *ctx, const char *key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TA_HIP_H */

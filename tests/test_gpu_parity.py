@@ -1,0 +1,223 @@
+"""GPU parity: HIP kernels (through the C-ABI) against the CPU oracle and the
+golden vectors produced by the reference.  Tolerance: scale-relative 1e-10
+(BASELINE.json north_star), stated per assertion."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, scale_rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+def g(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from transport_analysis_amd import _lib
+
+    assert _lib.device_count() >= 1, "no GPU visible: the HIP path cannot run"
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def run_vacf(ctx, v, fft, by_particle):
+    T, A, D = v.shape
+    (slab,) = ctx.stage_alloc(T, A, D, n_slabs=1)
+    slab[...] = v
+    ctx.stage_commit(0, T)
+    ts, bp = (ctx.vacf_fft if fft else ctx.vacf_direct)(by_particle=by_particle)
+    return ts, bp
+
+
+def run_helfand(ctx, v, x, m, scale, by_particle):
+    T, A, D = v.shape
+    sv, sx = ctx.stage_alloc(T, A, D, n_slabs=2)
+    sv[...] = v
+    sx[...] = x
+    ctx.stage_commit(0, T)
+    return ctx.helfand_msd(m, scale, by_particle=by_particle)
+
+
+def step(nstep, start=0, stop=None, step_=1, cols=(0, 1, 2)):
+    t = np.arange(nstep, dtype=np.float64)[start:stop:step_]
+    v = np.repeat(t[:, None, None], 3, axis=2)[:, :, list(cols)]
+    x = np.repeat((t * t / 2)[:, None, None], 3, axis=2)[:, :, list(cols)]
+    return v, x
+
+
+# ------------------------------------------------------------------ VACF
+@pytest.mark.parametrize("fft", [True, False])
+@pytest.mark.parametrize("tag", ["T7_A1_D1", "T64_A5_D2", "T200_A33_D3"])
+def test_vacf_golden_random(ctx, tag, fft):
+    v = g(f"rand_vel_{tag}.npy")
+    kind = "fft" if fft else "windowed"
+    want_bp, want_ts = g(f"ref_vacf_{kind}_bp_{tag}.npy"), g(f"ref_vacf_{kind}_ts_{tag}.npy")
+    ts, bp = run_vacf(ctx, v, fft, True)
+    assert bp.shape == want_bp.shape and ts.shape == want_ts.shape
+    assert scale_rel_err(bp, want_bp) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL
+    ts2, bp2 = run_vacf(ctx, v, fft, False)  # timeseries-only fast path
+    assert bp2 is None
+    assert scale_rel_err(ts2, want_ts) < TOL
+
+
+@pytest.mark.parametrize("fft", [True, False])
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_vacf_step_kat_full(ctx, d, fft):
+    # test_velocityautocorr.py:331-340 / :454-469 (N=5001); decimal=4 (windowed), 3 (FFT)
+    v, _ = step(5001, cols=range(d))
+    poly = g(f"kat_vacf_poly_N5001_D{d}.npy")
+    for by_particle in (False, True):
+        ts, _ = run_vacf(ctx, v, fft, by_particle)
+        np.testing.assert_almost_equal(ts, poly, decimal=3 if fft else 4)
+        assert scale_rel_err(ts, poly) < TOL
+
+
+@pytest.mark.parametrize("fft", [True, False])
+@pytest.mark.parametrize("d,cols", [(1, [1]), (2, [0, 2]), (3, [0, 1, 2])])
+def test_vacf_step_kat_sliced(ctx, d, cols, fft):
+    v, _ = step(5001, 10, 1000, 10, cols)
+    poly = g(f"kat_vacf_poly_10_1000_10_D{d}.npy")
+    ts, bp = run_vacf(ctx, v, fft, True)
+    np.testing.assert_almost_equal(ts, poly, decimal=3 if fft else 4)
+    assert scale_rel_err(ts, poly) < TOL
+    assert scale_rel_err(bp[:, 0], poly) < TOL
+
+
+def test_vacf_n10_notebook(ctx):
+    const = json.load(open(os.path.join(GOLDEN, "reference_constants.json")))
+    v, _ = step(10)
+    for fft in (True, False):
+        ts, _ = run_vacf(ctx, v, fft, False)
+        np.testing.assert_allclose(ts, const["notebook_poly_step_N10"], rtol=0, atol=1e-10)
+
+
+SHAPES = [(1, 1, 1), (2, 3, 3), (5, 2, 2), (16, 7, 3), (17, 4, 1), (33, 9, 2), (100, 40, 3),
+          (129, 3, 3), (257, 33, 3), (640, 11, 2), (641, 5, 3), (1000, 37, 3), (1025, 6, 1),
+          (2049, 3, 3), (2561, 4, 2), (4097, 2, 3), (5121, 2, 1), (10000, 3, 3), (10240, 2, 2)]
+
+
+@pytest.mark.parametrize("T,A,D", SHAPES)
+def test_vacf_fft_vs_oracle_shapes(ctx, T, A, D):
+    """Every FFT plan size incl. ragged/odd column counts, both output modes."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(T, A, D, seed=1000 + T)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
+    ts, bp = run_vacf(ctx, v, True, True)
+    assert scale_rel_err(bp, want_bp) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL
+    ts2, _ = run_vacf(ctx, v, True, False)
+    assert scale_rel_err(ts2, want_ts) < TOL
+
+
+@pytest.mark.parametrize("T,A,D", [(1, 2, 3), (3, 1, 1), (8, 5, 3), (9, 4, 2), (31, 6, 3),
+                                   (500, 9, 3), (1000, 33, 3), (4099, 3, 2)])
+def test_vacf_direct_vs_oracle_shapes(ctx, T, A, D):
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(T, A, D, seed=2000 + T)
+    want_bp, want_ts = orc.vacf_fft_batched(v)  # same quantity (reference asserts equality)
+    if T <= 1000:
+        want_bp, want_ts = orc.vacf_windowed(v)
+    ts, bp = run_vacf(ctx, v, False, True)
+    assert scale_rel_err(bp, want_bp) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL
+    ts2, _ = run_vacf(ctx, v, False, False)
+    assert scale_rel_err(ts2, want_ts) < TOL
+
+
+def test_vacf_config2_full_size(ctx):
+    """BASELINE config[1]: 1000 x 10000 x 3 float64, FFT path vs the oracle."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(1000, 10000, 3, seed=20250826)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
+    ts, _ = run_vacf(ctx, v, True, False)
+    assert scale_rel_err(ts, want_ts) < TOL
+    ts, bp = run_vacf(ctx, v, True, True)
+    assert scale_rel_err(ts, want_ts) < TOL
+    assert scale_rel_err(bp, want_bp) < TOL
+    tsd, _ = run_vacf(ctx, v, False, False)
+    assert scale_rel_err(tsd, want_ts) < TOL
+
+
+def test_vacf_linearity_and_lag0(ctx):
+    """Size-independent properties: lag 0 equals the mean squared speed; the lag
+    sums of two atom blocks add up to the lag sum of their union."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(3000, 64, 3, seed=5)
+    ts, _ = run_vacf(ctx, v, True, False)
+    np.testing.assert_allclose(ts[0], np.mean(np.sum(v * v, axis=2)), rtol=1e-12)
+    a, _ = run_vacf(ctx, v[:, :20], True, False)
+    b, _ = run_vacf(ctx, v[:, 20:], True, False)
+    assert scale_rel_err((20 * a + 44 * b) / 64, ts) < 1e-12
+
+
+# --------------------------------------------------------------- Helfand
+@pytest.mark.parametrize("tag", ["T9_A1_D1", "T50_A6_D2", "T120_A17_D3"])
+def test_helfand_golden_random(ctx, tag):
+    from transport_analysis_amd._base import BOLTZMANN
+
+    z = np.load(os.path.join(GOLDEN, f"rand_helfand_in_{tag}.npz"))
+    scale = 1.0 / (2 * BOLTZMANN * np.average(z["vol"]) * 313.0)
+    ts, bp = run_helfand(ctx, z["v"], z["x"], z["m"], scale, True)
+    want_bp, want_ts = g(f"ref_helfand_bp_{tag}.npy"), g(f"ref_helfand_ts_{tag}.npy")
+    assert ts[0] == 0.0 and np.all(bp[0] == 0.0)
+    assert scale_rel_err(bp, want_bp) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL
+    np.testing.assert_allclose(ts, want_ts, rtol=1e-7)  # the reference's own bar
+    ts2, bp2 = run_helfand(ctx, z["v"], z["x"], z["m"], scale, False)
+    assert bp2 is None and scale_rel_err(ts2, want_ts) < TOL
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_helfand_step_kat(ctx, d):
+    # test_viscosity.py:180-208 (assert_allclose rtol=1e-7), N=5001 and sliced
+    from transport_analysis_amd._base import BOLTZMANN
+
+    scale = 1.0 / (2 * BOLTZMANN * 8.0 * 300.0)
+    v, x = step(5001, cols=range(d))
+    ts, _ = run_helfand(ctx, v, x, np.array([16.0]), scale, False)
+    want = g(f"kat_helfand_poly_N5001_D{d}.npy")
+    np.testing.assert_allclose(ts, want, rtol=1e-7)
+    assert scale_rel_err(ts, want) < TOL
+    v, x = step(5001, 10, 1000, 10, range(d))
+    ts, _ = run_helfand(ctx, v, x, np.array([16.0]), scale, True)
+    np.testing.assert_allclose(ts, g(f"kat_helfand_poly_10_1000_10_D{d}.npy"), rtol=1e-7)
+
+
+@pytest.mark.parametrize("T,A,D", [(2, 3, 1), (8, 2, 3), (17, 5, 2), (300, 21, 3), (1001, 7, 3)])
+def test_helfand_vs_oracle_shapes(ctx, T, A, D):
+    from oracle import numpy_oracle as orc
+
+    v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=3000 + T)
+    want_bp, want_ts = orc.helfand(v, x, m, vol, 300.0)
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+    ts, bp = run_helfand(ctx, v, x, m, scale, True)
+    assert scale_rel_err(bp, want_bp) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL
+
+
+def test_f32_staging_is_lossless(ctx):
+    """MDAnalysis hands out float32; staging float32 and widening on the device
+    must give exactly what staging the upcast float64 gives."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(300, 17, 3, seed=9).astype(np.float32)
+    (slab,) = ctx.stage_alloc(300, 17, 3, n_slabs=1, dtype=np.float32)
+    slab[...] = v
+    ctx.stage_commit(0, 100)
+    ctx.stage_commit(100, 300)
+    ts32, _ = ctx.vacf_fft(by_particle=False)
+    ts64, _ = run_vacf(ctx, v.astype(np.float64), True, False)
+    np.testing.assert_array_equal(ts32, ts64)

@@ -1,0 +1,199 @@
+"""ctypes binding of libta_hip.so (the C-ABI declared in include/ta_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no GPU is
+usable, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libta_hip.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+TA_F32, TA_F64 = 0, 1
+
+#: every symbol include/ta_hip.h declares
+EXPORTS = (
+    "ta_abi_version", "ta_device_count", "ta_last_error", "ta_ctx_create", "ta_ctx_destroy",
+    "ta_stage_alloc", "ta_stage_commit", "ta_stage_device", "ta_stage_free",
+    "ta_vacf_fft", "ta_vacf_direct", "ta_helfand_msd",
+    "ta_vacf_fft_dev", "ta_vacf_direct_dev", "ta_helfand_msd_dev",
+    "ta_last_timing", "ta_fft_plan_info", "ta_set_option",
+)
+
+
+class TAError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libta_hip error {code}: {message}")
+        self.code = code
+
+
+def build(force=False):
+    """Compile libta_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", _CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", _CSRC])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError(
+            f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (hipcc --offload-arch=gfx950). transport_analysis_amd has no CPU fallback."
+        )
+    L = ctypes.CDLL(_SO)
+    vp, i64, ci, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
+    L.ta_abi_version.restype = ci
+    L.ta_device_count.restype = ci
+    L.ta_last_error.restype = ctypes.c_char_p
+    L.ta_last_error.argtypes = [vp]
+    L.ta_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]
+    L.ta_ctx_destroy.argtypes = [vp]
+    L.ta_stage_alloc.argtypes = [vp, i64, i64, ci, ci, ci, ctypes.POINTER(vp)]
+    L.ta_stage_commit.argtypes = [vp, i64, i64]
+    L.ta_stage_device.argtypes = [vp, ci, ctypes.POINTER(vp)]
+    L.ta_stage_free.argtypes = [vp]
+    L.ta_vacf_fft.argtypes = [vp, vp, vp]
+    L.ta_vacf_direct.argtypes = [vp, vp, vp]
+    L.ta_helfand_msd.argtypes = [vp, vp, dbl, vp, vp]
+    L.ta_vacf_fft_dev.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, i64, vp]
+    L.ta_vacf_direct_dev.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, i64, vp]
+    L.ta_helfand_msd_dev.argtypes = [vp, vp, vp, vp, i64, i64, ci, i64, dbl, vp, vp, i64, vp]
+    L.ta_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.ta_fft_plan_info.argtypes = [i64, ctypes.POINTER(i64), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    L.ta_set_option.argtypes = [vp, ctypes.c_char_p, i64]
+    for name in EXPORTS:
+        if name not in ("ta_last_error",):
+            getattr(L, name).restype = ci
+    _lib = L
+    return L
+
+
+def device_count():
+    return int(lib().ta_device_count())
+
+
+def fft_plan_info(n_frames):
+    m, nt, ns = ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
+    rc = lib().ta_fft_plan_info(int(n_frames), ctypes.byref(m), ctypes.byref(nt), ctypes.byref(ns))
+    if rc != 0:
+        return None
+    return {"M": m.value, "n_threads": nt.value, "n_stages": ns.value}
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else ctypes.c_void_p(None)
+
+
+class Context:
+    """One ta_ctx: owns a stream, plan tables, workspaces and the staged slabs."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p(None)
+        L = lib()
+        rc = L.ta_ctx_create(int(device), ctypes.byref(self._h))
+        if rc != 0:
+            raise TAError(rc, L.ta_last_error(None).decode())
+        self.device = int(device)
+        self._slabs = []
+
+    # -- plumbing -------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise TAError(rc, lib().ta_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._slabs = []
+            lib().ta_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        self._check(lib().ta_set_option(self._h, key.encode(), int(value)))
+
+    # -- staging --------------------------------------------------------
+    def stage_alloc(self, n_frames, n_atoms, dim, n_slabs=1, dtype=np.float64):
+        """Pinned host slabs (n_frames, n_atoms, dim) as NumPy views + device twins."""
+        code = TA_F64 if np.dtype(dtype) == np.float64 else TA_F32
+        ptrs = (ctypes.c_void_p * n_slabs)()
+        self._slabs = []
+        self._check(lib().ta_stage_alloc(self._h, n_frames, n_atoms, dim, code, n_slabs, ptrs))
+        ct = ctypes.c_double if code == TA_F64 else ctypes.c_float
+        n = int(n_frames) * int(n_atoms) * int(dim)
+        out = []
+        for p in ptrs:
+            buf = (ct * n).from_address(p)
+            out.append(np.frombuffer(buf, dtype=dtype).reshape(n_frames, n_atoms, dim))
+        self._slabs = out
+        self.shape = (int(n_frames), int(n_atoms), int(dim))
+        return out
+
+    def stage_commit(self, frame_lo, frame_hi):
+        self._check(lib().ta_stage_commit(self._h, int(frame_lo), int(frame_hi)))
+
+    def stage_device(self, slab):
+        p = ctypes.c_void_p()
+        self._check(lib().ta_stage_device(self._h, slab, ctypes.byref(p)))
+        return p.value
+
+    def stage_free(self):
+        self._slabs = []
+        self._check(lib().ta_stage_free(self._h))
+
+    # -- host-facing compute -------------------------------------------
+    def _host(self, fn, by_particle, *extra):
+        T, A, _ = self.shape
+        ts = np.empty(T, dtype=np.float64)
+        bp = np.empty((T, A), dtype=np.float64) if by_particle else None
+        self._check(fn(self._h, *extra, _ptr(ts), _ptr(bp)))
+        return ts, bp
+
+    def vacf_fft(self, by_particle=False):
+        return self._host(lib().ta_vacf_fft, by_particle)
+
+    def vacf_direct(self, by_particle=False):
+        return self._host(lib().ta_vacf_direct, by_particle)
+
+    def helfand_msd(self, masses, scale, by_particle=False):
+        m = np.ascontiguousarray(masses, dtype=np.float64)
+        return self._host(lib().ta_helfand_msd, by_particle, _ptr(m), ctypes.c_double(scale))
+
+    # -- device-pointer compute (asynchronous) --------------------------
+    def vacf_fft_dev(self, d_vel, n_frames, n_atoms, dim, ld_row, d_lagsum, d_bp=0, ld_bp=0, stream=0):
+        self._check(lib().ta_vacf_fft_dev(self._h, d_vel, n_frames, n_atoms, dim, ld_row, d_lagsum,
+                                          d_bp or None, ld_bp, stream or None))
+
+    def vacf_direct_dev(self, d_vel, n_frames, n_atoms, dim, ld_row, d_lagsum, d_bp=0, ld_bp=0, stream=0):
+        self._check(lib().ta_vacf_direct_dev(self._h, d_vel, n_frames, n_atoms, dim, ld_row, d_lagsum,
+                                             d_bp or None, ld_bp, stream or None))
+
+    def helfand_msd_dev(self, d_vel, d_pos, d_masses, n_frames, n_atoms, dim, ld_row, scale, d_lagsum,
+                        d_bp=0, ld_bp=0, stream=0):
+        self._check(lib().ta_helfand_msd_dev(self._h, d_vel, d_pos, d_masses, n_frames, n_atoms, dim,
+                                             ld_row, scale, d_lagsum, d_bp or None, ld_bp,
+                                             stream or None))
+
+    def last_timing(self):
+        t, m = ctypes.c_float(), ctypes.c_float()
+        self._check(lib().ta_last_timing(self._h, ctypes.byref(t), ctypes.byref(m)))
+        return t.value, m.value

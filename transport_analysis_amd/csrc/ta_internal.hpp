@@ -1,0 +1,54 @@
+// ta_internal.hpp — shared between the translation units of libta_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "fft_engine.hpp"
+
+namespace ta {
+
+struct FftArgs {
+    const double* vel;
+    long ld_row;
+    int T;
+    long n_cols;   // accum: columns of the shard (n_atoms * D)
+    long n_atoms;  // by_particle
+    int D;
+    const cd* tw2;        // W_{2M}^n, n < 2M
+    double* partial;      // accum: [2][nwg/2][M]
+    const double* spec;   // finalize: [2][M]
+    double* lagsum;       // finalize: [T]
+    double* by_particle;  // by_particle: (T, ld_bp)
+    long ld_bp;
+    double* ts_partial;   // by_particle: [nwg][T]
+};
+
+struct PlanEntry {
+    int M, NT, S;
+    size_t lds_bytes;
+    hipError_t (*accum)(bool vec, int nwg, hipStream_t st, const FftArgs& a);
+    hipError_t (*finalize)(hipStream_t st, const FftArgs& a);
+    hipError_t (*by_particle)(int nwg, hipStream_t st, const FftArgs& a);
+    int (*max_wg_per_cu)(int which);  // 0 accum(vec) 1 accum(novec) 2 by_particle
+};
+
+const std::vector<PlanEntry>& plans_pow2();
+const std::vector<PlanEntry>& plans_five();
+
+// direct.hip
+hipError_t launch_direct(int mode, const double* vel, const double* pos, const double* masses,
+                         long ld_row, int T, long n_atoms, int D, double scale,
+                         double* by_particle, long ld_bp, double* ts_partial, int nwg, int nt,
+                         size_t lds_bytes, hipStream_t st);
+int direct_chunk();                       // L
+size_t direct_lds_bytes(int T);
+int direct_max_wg_per_cu(int mode, int nt, size_t lds_bytes);
+
+hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,
+                               hipStream_t st);
+hipError_t launch_widen_f32(const float* in, double* out, long n, hipStream_t st);
+
+}  // namespace ta

@@ -1,0 +1,122 @@
+"""Einstein-Helfand viscosity function on MI355X — drop-in for
+``transport_analysis.viscosity.ViscosityHelfand``
+(/root/reference/transport_analysis/viscosity.py:26-272).  The windowed
+mean-squared-difference accumulator of ``_conclude`` (:201-233) runs in a
+hand-written HIP kernel; the fit (:235-245) stays on the host.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import _lib
+from ._base import BOLTZMANN, AnalysisBase, NoDataError, UpdatingAtomGroup, parse_dim_type
+
+_COMMIT_BYTES = 32 << 20
+
+
+class ViscosityHelfand(AnalysisBase):
+    r"""Viscosity function via the Einstein-Helfand method.
+
+    Parameters
+    ----------
+    atomgroup : AtomGroup
+    temp_avg : float — average temperature (K), default 300.
+    dim_type : {'xyz', 'xy', 'yz', 'xz', 'x', 'y', 'z'}
+    linear_fit_window : (int, int) or None — lag-index window for the slope fit.
+    by_particle : bool, keyword-only, default True — materialise
+        ``results.visc_by_particle``; ``False`` computes the timeseries only.
+    device : int, keyword-only — GPU index (default ``$TA_AMD_DEVICE`` or 0).
+
+    Attributes
+    ----------
+    results.timeseries : (n_frames,) — viscosity function averaged over particles
+        (lag 0 is exactly 0).
+    results.visc_by_particle : (n_frames, n_particles) or None
+    results.viscosity : slope of the linear fit (only with linear_fit_window).
+    """
+
+    def __init__(self, atomgroup, temp_avg=300.0, dim_type="xyz", linear_fit_window=None,
+                 **kwargs):
+        self._want_by_particle = bool(kwargs.pop("by_particle", True))
+        self._device = int(kwargs.pop("device", os.environ.get("TA_AMD_DEVICE", 0)))
+        super().__init__(atomgroup.universe.trajectory, **kwargs)
+
+        if isinstance(atomgroup, UpdatingAtomGroup):
+            raise TypeError("UpdatingAtomGroups are not valid for viscosity computation")
+
+        self.temp_avg = temp_avg
+        self.dim_type = dim_type.lower()
+        self.linear_fit_window = linear_fit_window
+        self._dim, self.dim_fac = parse_dim_type(self.dim_type)
+
+        self.atomgroup = atomgroup
+        self.n_particles = len(self.atomgroup)
+        self._ctx = None
+
+    _parse_dim_type = staticmethod(parse_dim_type)
+
+    def _prepare(self):
+        """Two pinned slabs (velocities, positions) + volumes + masses (:111-142)."""
+        if self._ctx is None:
+            self._ctx = _lib.Context(self._device)
+        self._velocities, self._positions = self._ctx.stage_alloc(
+            self.n_frames, self.n_particles, self.dim_fac, n_slabs=2)
+        self._volumes = np.zeros(self.n_frames)
+        self._masses = np.asarray(self.atomgroup.masses, dtype=np.float64)
+        self.boltzmann = BOLTZMANN
+        frame_bytes = max(1, 2 * self.n_particles * self.dim_fac * 8)
+        self._commit_every = max(1, _COMMIT_BYTES // frame_bytes)
+        self._committed = 0
+        self.results.visc_by_particle = None
+
+    def _single_frame(self):
+        """Stage volume, velocities and positions of one frame (:167-199)."""
+        ts = self._ts
+        if not (ts.has_velocities and ts.has_positions and ts.volume != 0):
+            raise NoDataError(
+                "Helfand viscosity computation requires "
+                "velocities, positions, and box volume in the trajectory"
+            )
+        i = self._frame_index
+        self._volumes[i] = ts.volume
+        self._velocities[i] = self.atomgroup.velocities[:, self._dim]
+        self._positions[i] = self.atomgroup.positions[:, self._dim]
+        if i + 1 - self._committed >= self._commit_every:
+            self._ctx.stage_commit(self._committed, i + 1)
+            self._committed = i + 1
+
+    def _conclude(self):
+        if self._committed < self.n_frames:
+            self._ctx.stage_commit(self._committed, self.n_frames)
+            self._committed = self.n_frames
+        self._vol_avg = np.average(self._volumes)
+        # everything is divided by 2 kB <V> T (:229-231)
+        scale = 1.0 / (2 * self.boltzmann * self._vol_avg * self.temp_avg)
+        ts, bp = self._ctx.helfand_msd(self._masses, scale, by_particle=self._want_by_particle)
+        self.results.visc_by_particle = bp
+        self.results.timeseries = ts
+
+        if self.linear_fit_window is not None:
+            # the reference fits against lagtimes = arange(1, n_frames): its x axis
+            # is one ahead of the timeseries index; the slope is unaffected (:235-245)
+            lagtimes = np.arange(1, self.n_frames)
+            lo, hi = self.linear_fit_window[0], self.linear_fit_window[1]
+            fit = np.polyfit(lagtimes[lo:hi], self.results.timeseries[lo:hi], 1)
+            self.results.viscosity = fit[0]
+
+    def plot_viscosity_function(self):
+        """Plot the viscosity function against lag index, marking the fit window (:247-272)."""
+        import matplotlib.pyplot as plt
+
+        plt.plot(np.arange(0, self.n_frames), self.results.timeseries, label="Viscosity Function")
+        if self.linear_fit_window is not None:
+            lo, hi = self.linear_fit_window[0], self.linear_fit_window[1]
+            plt.axvline(lo, color="red", linestyle="--", label="Fit Start")
+            plt.axvline(hi, color="blue", linestyle="--", label="Fit End")
+        plt.xlabel("Lag-time")
+        plt.ylabel("Viscosity Function")
+        plt.title("Viscosity Function vs Lag-time")
+        plt.legend()
+        plt.show()
