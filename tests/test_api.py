@@ -1,0 +1,225 @@
+"""API parity with the reference's own tests
+(/root/reference/transport_analysis/tests/test_velocityautocorr.py,
+test_viscosity.py), on in-memory trajectories.  Every test runs twice: on the CPU
+with an oracle-backed context (host logic only) and, marked gpu, on the real HIP
+path through the C-ABI."""
+import json
+import os
+
+import matplotlib
+
+matplotlib.use("Agg")
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_almost_equal, assert_approx_equal
+from scipy import integrate
+
+from conftest import GOLDEN
+from transport_analysis_amd import VelocityAutocorr as VACF
+from transport_analysis_amd import ViscosityHelfand as VH
+from transport_analysis_amd import _base, _lib
+from transport_analysis_amd._mini_mda import ArrayUniverse
+
+NSTEP = 5001
+DIMS = [("xyz", 3), ("xy", 2), ("xz", 2), ("yz", 2), ("x", 1), ("y", 1), ("z", 1)]
+CONST = json.load(open(os.path.join(GOLDEN, "reference_constants.json")))
+
+
+def g(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.fixture(params=["oracle-backed", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request, monkeypatch):
+    if request.param == "oracle-backed":
+        from fake_backend import OracleContext
+
+        monkeypatch.setattr(_lib, "Context", OracleContext)
+    else:
+        assert _lib.device_count() >= 1
+    return request.param
+
+
+@pytest.fixture(scope="module")
+def step_vtraj():
+    # test_velocityautocorr.py:46-57 / test_viscosity.py:56-86
+    t = np.arange(NSTEP, dtype=np.float64)
+    v = np.repeat(t[:, None, None], 3, axis=2)
+    x = np.repeat((t * t / 2)[:, None, None], 3, axis=2)
+    return ArrayUniverse(positions=x, velocities=v, masses=[16.0],
+                         dimensions=[2, 2, 2, 90, 90, 90])
+
+
+@pytest.fixture(scope="module")
+def water():
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((10, 30, 3)).astype(np.float32)
+    x = (10 + 0.01 * np.cumsum(v, axis=0)).astype(np.float32)
+    return ArrayUniverse(positions=x, velocities=v, masses=np.full(30, 15.999),
+                         dimensions=[20, 20, 20, 90, 90, 90], dt=0.5)
+
+
+# -------------------------------------------------------------- construction
+def test_ag_accepted(water):
+    VACF(water.atoms[:10], fft=False)
+    VH(water.atoms[:10])
+
+
+def test_no_velocities(backend):
+    u = ArrayUniverse(n_atoms=10, n_frames=5)
+    with pytest.raises(_base.NoDataError, match="VACF computation requires velocities"):
+        VACF(u.atoms, fft=False).run()
+    with pytest.raises(_base.NoDataError, match="Helfand viscosity computation requires"):
+        VH(u.atoms).run()
+
+
+def test_zero_volume_is_no_data(backend, water):
+    u = ArrayUniverse(positions=water.trajectory._pos, velocities=water.trajectory._vel)
+    with pytest.raises(_base.NoDataError, match="Helfand viscosity computation requires"):
+        VH(u.atoms).run()
+
+
+def test_updating_ag_rejected(water):
+    class Updating(_base.UpdatingAtomGroup):
+        universe = water
+
+        def __len__(self):
+            return 3
+
+    with pytest.raises(TypeError, match="UpdatingAtomGroups are not valid"):
+        VACF(Updating(), fft=False)
+    with pytest.raises(TypeError, match="UpdatingAtomGroups are not valid"):
+        VH(Updating())
+
+
+@pytest.mark.parametrize("dimtype", ["foo", "bar", "yx", "zyx"])
+def test_dimtype_error(water, dimtype):
+    with pytest.raises(ValueError, match=f"invalid dim_type: {dimtype}"):
+        VACF(water.atoms, dim_type=dimtype)
+    with pytest.raises(ValueError, match=f"invalid dim_type: {dimtype}"):
+        VH(water.atoms, dim_type=dimtype)
+
+
+def test_dimtype_is_lowercased(water):
+    assert VACF(water.atoms, dim_type="XZ")._dim == [0, 2]
+
+
+def test_must_run_first(step_vtraj):
+    v = VACF(step_vtraj.atoms, fft=False)
+    for call in (v.plot_vacf, v.self_diffusivity_gk, v.self_diffusivity_gk_odd,
+                 v.plot_running_integral):
+        with pytest.raises(RuntimeError, match="Analysis must be run"):
+            call()
+    assert "timeseries" not in v.results
+
+
+# -------------------------------------------------------------------- VACF
+def test_fft_vs_simple_and_attributes(backend, water):
+    ag = water.atoms[::3]
+    a = VACF(ag, fft=False).run()
+    b = VACF(ag, fft=True).run()
+    assert a.n_frames == 10 and a.n_particles == 10 and a.dim_fac == 3
+    assert a.results.vacf_by_particle.shape == (10, 10)
+    assert a.results.timeseries.dtype == np.float64
+    assert_allclose(a.times, 0.5 * np.arange(10))
+    assert_almost_equal(a.results.timeseries, b.results.timeseries, decimal=4)
+    assert_almost_equal(a.results.vacf_by_particle, b.results.vacf_by_particle, decimal=4)
+    assert_allclose(a.results.timeseries, a.results.vacf_by_particle.mean(axis=1), rtol=1e-12)
+    c = VACF(ag, fft=True, by_particle=False).run()
+    assert c.results.vacf_by_particle is None
+    assert_allclose(c.results.timeseries, b.results.timeseries, rtol=1e-10, atol=1e-12)
+
+
+def test_second_run_restages(backend, water):
+    v = VACF(water.atoms, fft=True)
+    first = v.run().results.timeseries.copy()
+    second = v.run(start=2).results.timeseries
+    assert len(first) == 10 and len(second) == 8
+    assert_allclose(v.run().results.timeseries, first, rtol=1e-12)
+
+
+@pytest.mark.parametrize("tdim,tdim_factor", DIMS)
+@pytest.mark.parametrize("fft", [False, True])
+def test_step_vtraj_all_dims(backend, step_vtraj, tdim, tdim_factor, fft):
+    v = VACF(step_vtraj.atoms, dim_type=tdim, fft=fft).run()
+    poly = g(f"kat_vacf_poly_N5001_D{tdim_factor}.npy")
+    assert_almost_equal(v.results.timeseries, poly, decimal=3 if fft else 4)
+    # Green-Kubo numbers quoted in the reference's tests (:378): 8 significant figures
+    assert_approx_equal(v.self_diffusivity_gk(), CONST["gk_trapezoid_step_N5001"], significant=8)
+    assert_approx_equal(v.self_diffusivity_gk_odd(), CONST["gk_simpson_step_N5001"], significant=8)
+    sl = slice(10, 1000, 10)
+    want = integrate.simpson(y=poly[sl], x=np.arange(NSTEP)[sl]) / tdim_factor
+    assert_approx_equal(v.self_diffusivity_gk(start=10, stop=1000, step=10), want, significant=6)
+    want = integrate.trapezoid(poly[sl], np.arange(NSTEP)[sl]) / tdim_factor
+    assert_approx_equal(v.self_diffusivity_gk_odd(start=10, stop=1000, step=10), want, significant=6)
+
+
+@pytest.mark.parametrize("tdim,tdim_factor", DIMS)
+@pytest.mark.parametrize("fft", [False, True])
+def test_start_stop_step_all_dims(backend, step_vtraj, tdim, tdim_factor, fft):
+    v = VACF(step_vtraj.atoms, dim_type=tdim, fft=fft).run(start=10, stop=1000, step=10)
+    assert v.n_frames == 99
+    assert_allclose(v.frames, np.arange(10, 1000, 10))
+    poly = g(f"kat_vacf_poly_10_1000_10_D{tdim_factor}.npy")
+    assert_almost_equal(v.results.timeseries, poly, decimal=3 if fft else 4)
+
+
+def test_plots(backend, water):
+    v = VACF(water.atoms, fft=False).run()
+    (line,) = v.plot_vacf()
+    x, y = line.get_xydata().T
+    assert_allclose(x, v.times)
+    assert_allclose(y, v.results.timeseries)
+    assert line.axes.get_xlabel() == "Time (ps)"
+    assert line.axes.get_ylabel() == "Velocity Autocorrelation Function (Å^2 / ps^2)"
+    (line,) = v.plot_vacf(start=1, stop=9, step=2, xlabel="a", ylabel="b")
+    x, y = line.get_xydata().T
+    assert_allclose(x, v.times[1:9:2])
+    assert_allclose(y, v.results.timeseries[1:9:2])
+    assert (line.axes.get_xlabel(), line.axes.get_ylabel()) == ("a", "b")
+    (line,) = v.plot_running_integral()
+    x, y = line.get_xydata().T
+    want = np.zeros(v.n_frames)
+    for i in range(1, v.n_frames):
+        want[i] = integrate.trapezoid(v.results.timeseries[: i + 1], v.times[: i + 1]) / v.dim_fac
+    assert_allclose(x, v.times)
+    assert_allclose(y, want)
+    assert line.axes.get_ylabel() == "Running Integral of the VACF (Å^2 / ps)"
+    (line,) = v.plot_running_integral(start=1, stop=9, step=2)
+    assert len(line.get_xydata()) == 4
+
+
+# ----------------------------------------------------------------- Helfand
+@pytest.mark.parametrize("tdim,tdim_factor", DIMS)
+def test_helfand_step_all_dims(backend, step_vtraj, tdim, tdim_factor):
+    # test_viscosity.py:180-208, assert_allclose default rtol=1e-7
+    vh = VH(step_vtraj.atoms, dim_type=tdim).run(start=10, stop=1000, step=10)
+    assert_allclose(vh.results.timeseries, g(f"kat_helfand_poly_10_1000_10_D{tdim_factor}.npy"))
+    assert vh.results.timeseries[0] == 0.0
+    assert vh.boltzmann == CONST["boltzmann_kJ_per_mol_K"]
+
+
+def test_helfand_full_kat(backend, step_vtraj):
+    vh = VH(step_vtraj.atoms, dim_type="x").run()
+    assert_allclose(vh.results.timeseries, g("kat_helfand_poly_N5001_D1.npy"))
+
+
+@pytest.mark.parametrize("tag", ["T50_A6_D2", "T120_A17_D3"])
+def test_helfand_fit_and_volume(backend, tag):
+    z = np.load(os.path.join(GOLDEN, f"rand_helfand_in_{tag}.npz"))
+    T, A, D = z["v"].shape
+    pad = lambda a: np.concatenate([a, np.zeros((T, A, 3 - D))], axis=2)  # noqa: E731
+    side = float(np.cbrt(np.average(z["vol"])))
+    u = ArrayUniverse(positions=pad(z["x"]), velocities=pad(z["v"]), masses=z["m"],
+                      dimensions=[side, side, side, 90, 90, 90])
+    # float32 trajectory data: compare against the oracle on the same rounded inputs
+    from oracle import numpy_oracle as orc
+
+    v32 = pad(z["v"]).astype(np.float32).astype(np.float64)[:, :, :D]
+    x32 = pad(z["x"]).astype(np.float32).astype(np.float64)[:, :, :D]
+    want_bp, want_ts = orc.helfand(v32, x32, z["m"], np.full(T, side**3), 313.0)
+    vh = VH(u.atoms, temp_avg=313.0, dim_type="xyz"[:D], linear_fit_window=(2, T - 2)).run()
+    assert_allclose(vh.results.timeseries, want_ts, rtol=1e-9)
+    assert_allclose(vh.results.visc_by_particle, want_bp, rtol=1e-9, atol=1e-12 * want_bp.max())
+    assert_allclose(vh.results.viscosity, orc.helfand_fit(want_ts, (2, T - 2)), rtol=1e-8)
+    vh.plot_viscosity_function()

@@ -48,6 +48,7 @@ struct ta_ctx {
     // options
     int64_t opt_fft_nwg = 0;
     int64_t opt_direct_nwg = 0;
+    int64_t opt_fft_debug = 0;
 };
 
 namespace {
@@ -221,6 +222,7 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return fail(ctx, TA_E_INVALID, "null argument");
     if (!strcmp(key, "fft_nwg")) ctx->opt_fft_nwg = value;
     else if (!strcmp(key, "direct_nwg")) ctx->opt_direct_nwg = value;
+    else if (!strcmp(key, "fft_debug")) ctx->opt_fft_debug = value;
     else return fail(ctx, TA_E_INVALID, std::string("unknown option ") + key);
     return TA_OK;
 }
@@ -333,6 +335,8 @@ int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int 
     FftArgs a{};
     a.vel = d_vel;
     a.ld_row = ld_row;
+    a.pair_stride = 2;
+    a.flags = (int)ctx->opt_fft_debug;
     a.T = (int)T;
     a.n_cols = A * D;
     a.n_atoms = A;

@@ -49,7 +49,7 @@ __device__ __forceinline__ cd load_z(const double* __restrict__ col, long ld_row
 template <class P, bool VEC, bool PASSB>
 __device__ __forceinline__ void fwd_first_stage(cd* __restrict__ lds, const cd* __restrict__ tw2,
                                                 const double* __restrict__ col, long ld_row,
-                                                int T, bool has2, int tid) {
+                                                int T, bool has2, int tid, int flags = 0) {
     using SI = StageInfo<P, 0>;
     cd v[SI::K][SI::R];
     // all of the thread's loads first: K*R independent requests in flight
@@ -60,8 +60,10 @@ __device__ __forceinline__ void fwd_first_stage(cd* __restrict__ lds, const cd* 
         for (int j = 0; j < SI::R; ++j) {
             const int t = u + j * SI::L;
             cd z = {0.0, 0.0};
-            if ((SI::TASKS % P::NT == 0 || u < SI::TASKS) && t < T)
-                z = load_z<VEC>(col, ld_row, t, has2);
+            if ((SI::TASKS % P::NT == 0 || u < SI::TASKS) && t < T) {
+                if (flags & 1) z = cd{(double)t, 1.0};  // timing diagnostics only
+                else z = load_z<VEC>(col, ld_row, t, has2);
+            }
             v[m][j] = z;
         }
     }
@@ -109,15 +111,16 @@ __device__ __forceinline__ void fwd_last_stage_acc(
 template <class P, bool VEC, bool PASSB>
 __device__ __forceinline__ void forward_pass_acc(
     cd* lds, const cd* tw2, const double* col, long ld_row, int T, bool has2,
-    double (&acc)[StageInfo<P, P::S - 1>::K][StageInfo<P, P::S - 1>::R], int tid) {
+    double (&acc)[StageInfo<P, P::S - 1>::K][StageInfo<P, P::S - 1>::R], int tid, int flags = 0) {
     // The per-thread twiddles are the same for every column pair; left alone, LICM
     // hoists ~50 complex values per thread out of the pair loop and spills them.
     // Laundering the (wave-uniform) table pointer keeps them as L1/L2-served loads.
     // Same for the per-lane gather addresses and table offsets (all functions of
     // tid and ld_row only): recomputing them per pass is cheaper than spilling.
     asm volatile("" : "+s"(tw2), "+s"(ld_row), "+v"(tid));
-    fwd_first_stage<P, VEC, PASSB>(lds, tw2, col, ld_row, T, has2, tid);
+    fwd_first_stage<P, VEC, PASSB>(lds, tw2, col, ld_row, T, has2, tid, flags);
     __syncthreads();
+    if (flags & 2) return;  // timing diagnostics only: load + first stage
     fwd_mid_stages<P, 1>(lds, tw2, tid);
     fwd_last_stage_acc<P>(lds, acc, tid);
     __syncthreads();
@@ -135,7 +138,8 @@ __device__ __forceinline__ void forward_pass_acc(
 template <class P, bool VEC, bool PASSB>
 __device__ __forceinline__ void accum_body(cd* lds, const double* __restrict__ vel, long ld_row,
                                            int T, long n_cols, const cd* __restrict__ tw2,
-                                           double* __restrict__ out, int slot, int n_slots) {
+                                           double* __restrict__ out, int slot, int n_slots,
+                                           long pair_stride, int flags) {
     using SL = StageInfo<P, P::S - 1>;
     const int tid = threadIdx.x;
     double acc[SL::K][SL::R];
@@ -145,9 +149,9 @@ __device__ __forceinline__ void accum_body(cd* lds, const double* __restrict__ v
         for (int q = 0; q < SL::R; ++q) acc[m][q] = 0.0;
     const long n_pairs = (n_cols + 1) / 2;
     for (long pair = slot; pair < n_pairs; pair += n_slots) {
-        const long col0 = 2 * pair;
-        const bool has2 = col0 + 1 < n_cols;
-        forward_pass_acc<P, VEC, PASSB>(lds, tw2, vel + col0, ld_row, T, has2, acc, tid);
+        const bool has2 = 2 * pair + 1 < n_cols;
+        forward_pass_acc<P, VEC, PASSB>(lds, tw2, vel + pair * pair_stride, ld_row, T, has2, acc,
+                                        tid, flags);
     }
 #pragma unroll
     for (int m = 0; m < SL::K; ++m) {
@@ -161,8 +165,8 @@ __device__ __forceinline__ void accum_body(cd* lds, const double* __restrict__ v
 
 template <class P, bool VEC>
 __global__ void __launch_bounds__(P::NT)
-    k_fft_accum(const double* __restrict__ vel, long ld_row, int T, long n_cols,
-                const cd* __restrict__ tw2, double* __restrict__ partial) {
+    k_fft_accum(const double* __restrict__ vel, long ld_row, long pair_stride, int T, long n_cols,
+                const cd* __restrict__ tw2, double* __restrict__ partial, int flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
     const int nwg = gridDim.x, wg = blockIdx.x;
@@ -179,9 +183,9 @@ __global__ void __launch_bounds__(P::NT)
     }
     double* out = partial + ((long)pass * n_slots + slot) * P::M;
     if (pass == 0)
-        accum_body<P, VEC, false>(lds, vel, ld_row, T, n_cols, tw2, out, slot, n_slots);
+        accum_body<P, VEC, false>(lds, vel, ld_row, T, n_cols, tw2, out, slot, n_slots, pair_stride, flags);
     else
-        accum_body<P, VEC, true>(lds, vel, ld_row, T, n_cols, tw2, out, slot, n_slots);
+        accum_body<P, VEC, true>(lds, vel, ld_row, T, n_cols, tw2, out, slot, n_slots, pair_stride, flags);
 }
 
 // Shared epilogue: LDS holds q = IDFT_M(P_A + i P_B) in natural order.

@@ -13,6 +13,8 @@ namespace ta {
 struct FftArgs {
     const double* vel;
     long ld_row;
+    long pair_stride;  // accum: elements between consecutive column pairs (2 for a slab)
+    int flags;         // accum: timing diagnostics (0 in production)
     int T;
     long n_cols;   // accum: columns of the shard (n_atoms * D)
     long n_atoms;  // by_particle

@@ -1,0 +1,47 @@
+"""Atom-sharded multi-GPU evaluation.
+
+Every per-atom series depends on that atom's data only; the single cross-atom
+operation of the path is the mean over atoms
+(/root/reference/transport_analysis/velocityautocorr.py:214,237;
+viscosity.py:233).  So each rank (one process per GPU) evaluates the
+lag-indexed SUM over its contiguous block of atoms and ONE all-reduce of that
+(n_frames,) float64 vector (RCCL over xGMI; 80 KB at 10 000 frames) followed by
+a division by the total atom count gives ``results.timeseries`` on every rank.
+``vacf_by_particle`` blocks stay on the rank that computed them.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def atom_shard(n_atoms, rank, world_size):
+    """Contiguous atom range [lo, hi) of `rank`: floor(n*r/W) .. floor(n*(r+1)/W)."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank out of range")
+    lo = (n_atoms * rank) // world_size
+    hi = (n_atoms * (rank + 1)) // world_size
+    return lo, hi
+
+
+def reduce_lagsum(lagsum, n_atoms_total, group=None):
+    """Sum the per-rank lag sums across ranks and divide by the total atom count.
+
+    `lagsum` is a torch tensor (device tensor with the nccl/RCCL backend, CPU
+    tensor with gloo); it is reduced in place and the mean is returned."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(lagsum, op=dist.ReduceOp.SUM, group=group)
+    return lagsum / float(n_atoms_total)
+
+
+def sharded_timeseries(compute_lagsum, n_atoms_total, rank, world_size, group=None):
+    """Evaluate one rank's shard and reduce.
+
+    compute_lagsum(lo, hi) -> torch tensor (n_frames,) holding
+    sum_{n in [lo,hi)} by_particle[:, n] for this rank's atoms (the product path
+    passes a closure over ``Context.vacf_fft_dev`` / ``vacf_direct_dev`` /
+    ``helfand_msd_dev``; an empty shard must return zeros)."""
+    lo, hi = atom_shard(n_atoms_total, rank, world_size)
+    part = compute_lagsum(lo, hi)
+    return reduce_lagsum(part, n_atoms_total, group)
