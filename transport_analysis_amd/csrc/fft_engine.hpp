@@ -268,4 +268,54 @@ __device__ __forceinline__ void fwd_mid_stages(cd* lds, const cd* tw2, int tid) 
     }
 }
 
+
+// In-LDS forward stage whose per-thread twiddle base b = u % L is the same for all
+// of the thread's butterflies (NT % L == 0): no table loads.  The twiddles
+// W^{q b} = seed^q are formed by repeated multiplication on the fly (two interleaved
+// chains, odd and even q, so consecutive products are independent; the error grows
+// by ~1 ulp per step, <= 8 steps per chain: far inside the 1e-10 budget).
+template <class P, int s, class Hook>
+__device__ __forceinline__ void fwd_stage_lds_seeded(cd* __restrict__ lds, cd seed, int tid,
+                                                     Hook&& after_task) {
+    using SI = StageInfo<P, s>;
+    static_assert(P::NT % SI::L == 0, "seeded stage needs NT % L == 0");
+    const cd seed2 = cmul(seed, seed);
+#pragma unroll
+    for (int m = 0; m < SI::K; ++m) {
+        const int u = tid + m * P::NT;
+        if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
+            const int blk = u / SI::L, b = u - blk * SI::L;
+            const int base = blk * SI::N + b;
+            cd v[SI::R];
+#pragma unroll
+            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(base + j * SI::L)];
+            Dft<SI::R>::run(v);
+            cd wo = seed, we = seed2;  // seed^q for the current odd / even q
+            v[1] = cmul(v[1], wo);
+            if constexpr (SI::R > 2) v[2] = cmul(v[2], we);
+#pragma unroll
+            for (int q = 3; q < SI::R; ++q) {
+                if (q & 1) {
+                    wo = cmul(wo, seed2);
+                    v[q] = cmul(v[q], wo);
+                } else {
+                    we = cmul(we, seed2);
+                    v[q] = cmul(v[q], we);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SI::R; ++q) lds[sw(base + q * SI::L)] = v[q];
+        }
+        // all lanes (also those without a butterfly in this round) run the hook
+        __builtin_amdgcn_sched_barrier(0);
+        after_task(m);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <class P, int s>
+constexpr bool stage_seedable() {
+    return StageInfo<P, s>::L > 1 && (P::NT % StageInfo<P, s>::L == 0);
+}
+
 }  // namespace ta

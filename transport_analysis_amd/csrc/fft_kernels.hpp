@@ -104,6 +104,9 @@ __device__ __forceinline__ void fwd_last_stage_acc(
 #pragma unroll
             for (int q = 0; q < SI::R; ++q) acc[m][q] += norm2(v[q]);
         }
+        // one butterfly at a time in registers (IR-level and machine-level fence)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -127,31 +130,266 @@ __device__ __forceinline__ void forward_pass_acc(
 }
 
 // ---- K1+K2: accumulate power spectra over column pairs ------------------------
-// Persistent workgroups.  A workgroup runs ONE pass type (A: even bins, B: odd
-// bins) over its share of the column pairs, so it carries a single accumulator
-// set; the A and the B workgroup of a pair are dealt to the same XCD (blockIdx % 8)
-// and walk the pairs in the same order, so the second reader of a line finds it in
-// that XCD's L2.  Workgroups of one XCD take consecutive pairs (adjacent columns).
-// partial: [2][n_slots][P::M] float64 in the transform's digit-reversed bin order,
-// n_slots = gridDim.x / 2.  Requires gridDim.x even (and a multiple of 16 for the
-// XCD-aware walk; otherwise the walk degrades to a plain interleave).
-template <class P, bool VEC, bool PASSB>
+// Persistent workgroups, one wave per SIMD-slot budget (NT = M/40 or M/32 threads,
+// up to 512 VGPRs).  A workgroup gathers a column pair ONCE into registers and runs
+// both passes from them (A: even bins, B: odd bins), so every input element is
+// requested from L2 once; workgroups of one XCD (blockIdx % 8) take consecutive
+// pairs, so the 8 pairs sharing a 128-byte line are read through the same L2.
+//
+// Software pipeline per pair:
+//   wait(v) -> first stage A (v kept) -> mid/last A -> first stage B (v consumed)
+//   -> issue gather of the NEXT pair into v -> mid/last B (covers the gather)
+// The mid stages take their twiddles from per-thread seeds in registers and the
+// last stage works on LDS only: no VMEM between the prefetch and its use, so no
+// s_waitcnt vmcnt drains it early.
+//
+// partial: [2][gridDim.x][P::M] float64 in the transform's digit-reversed bin order.
+// The gathered pair and the accumulators are "cold" for most of an iteration; at
+// one wave per SIMD a wave owns 512 registers, of which VALU instructions can only
+// address the first 256.  They are parked in the upper half (the AGPRs) explicitly:
+// the gather is issued as global_load_dwordx4 with an AGPR destination (inline asm,
+// so the compiler neither waits for it nor spills it), and TA_PIN_A forces a value
+// into the AGPR class at a program point so no long-lived VGPR copy survives.
+typedef double d2 __attribute__((ext_vector_type(2)));
+#define TA_PIN_A(x) asm volatile("" : "+a"(x))
+
+template <class P>
+using FirstRegs = d2[StageInfo<P, 0>::K][StageInfo<P, 0>::R];
+
+// Issue gather loads [lo, hi) (flat index m*R + j) of one column pair (no wait).
+// Rows past the end (t >= T, the zero padding) re-read row T-1 and are zeroed when
+// the registers are consumed, so the loads are branch-free.
+template <class P, bool VEC, int LO, int HI>
+__device__ __forceinline__ void gather_issue_range(FirstRegs<P>& v, const double* __restrict__ col,
+                                                   long ld_row, int T, bool has2, int tid) {
+    using SI = StageInfo<P, 0>;
+#pragma unroll
+    for (int f = LO; f < HI; ++f) {
+        if (f < SI::K * SI::R) {
+            const int m = f / SI::R, j = f % SI::R;
+            const int t = tid + m * P::NT + j * SI::L;
+            const int tc = t < T ? t : T - 1;
+            const double* p = col + (long)tc * ld_row;
+            if constexpr (VEC) {
+                v[m][j] = *reinterpret_cast<const d2*>(p);
+            } else {
+                d2 z;
+                z.x = p[0];
+                z.y = has2 ? p[1] : 0.0;
+                v[m][j] = z;
+            }
+        }
+    }
+}
+
+template <class P, bool VEC>
+__device__ __forceinline__ void gather_issue(FirstRegs<P>& v, const double* __restrict__ col,
+                                             long ld_row, int T, bool has2, int tid) {
+    using SI = StageInfo<P, 0>;
+    gather_issue_range<P, VEC, 0, SI::K * SI::R>(v, col, ld_row, T, has2, tid);
+}
+
+template <class P, bool VEC>
+__device__ __forceinline__ void gather_wait(FirstRegs<P>& v) {
+    using SI = StageInfo<P, 0>;
+    (void)v;
+}
+
+// First stage from the gathered registers.
+template <class P, bool PASSB, bool VEC>
+__device__ __forceinline__ void first_stage_from_regs(cd* __restrict__ lds,
+                                                      const cd* __restrict__ tw2,
+                                                      FirstRegs<P>& v, int T, int tid) {
+    using SI = StageInfo<P, 0>;
+#pragma unroll
+    for (int m = 0; m < SI::K; ++m) {
+        const int u = tid + m * P::NT;
+        if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
+            cd w[SI::R];
+#pragma unroll
+            for (int j = 0; j < SI::R; ++j) {
+                const bool live = u + j * SI::L < T;  // rows past the end are zero padding
+                w[j] = cd{live ? v[m][j].x : 0.0, live ? v[m][j].y : 0.0};
+            }
+            if constexpr (PASSB) {
+                // lane-uniform part of the twist: W_{2 R0}^j = tw2[j * L]
+#pragma unroll
+                for (int j = 1; j < SI::R; ++j) w[j] = cmul(w[j], tw2[j * SI::L]);
+            }
+            Dft<SI::R>::run(w);
+#pragma unroll
+            for (int q = PASSB ? 0 : 1; q < SI::R; ++q)
+                w[q] = cmul(w[q], tw2[u * (2 * q + (PASSB ? 1 : 0))]);
+#pragma unroll
+            for (int q = 0; q < SI::R; ++q) lds[sw(u + q * SI::L)] = w[q];
+        }
+        // one butterfly's twiddle loads at a time
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Last forward stage fused with |.|^2 accumulation; accumulators parked in AGPRs.
+template <class P, bool VEC, class Hook>
+__device__ __forceinline__ void last_stage_acc_parked(
+    const cd* __restrict__ lds,
+    double (&acc)[StageInfo<P, P::S - 1>::K][StageInfo<P, P::S - 1>::R], int tid, Hook&& after_task) {
+    using SI = StageInfo<P, P::S - 1>;
+#pragma unroll
+    for (int m = 0; m < SI::K; ++m) {
+        const int u = tid + m * P::NT;
+        if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
+            cd v[SI::R];
+#pragma unroll
+            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(u * SI::R + j)];
+            Dft<SI::R>::run(v);
+#pragma unroll
+            for (int q = 0; q < SI::R; ++q) {
+                acc[m][q] += norm2(v[q]);
+                if constexpr (VEC) TA_PIN_A(acc[m][q]);
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        after_task(m);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <class P, int s>
+__device__ __forceinline__ cd stage_seed(const cd* __restrict__ tw2, int tid) {
+    using SI = StageInfo<P, s>;
+    if constexpr (stage_seedable<P, s>()) return tw2[(tid % SI::L) * SI::TWSTEP];
+    else return cd{1.0, 0.0};
+}
+
+// Number of butterfly rounds a thread runs in the seeded mid stages s..S-2 and in the
+// last stage: the slots between which the next pair's gather loads are spread.
+template <class P, int s>
+constexpr int slots_from() {
+    if constexpr (s <= P::S - 2)
+        return (stage_seedable<P, s>() ? StageInfo<P, s>::K : 0) + slots_from<P, s + 1>();
+    else
+        return StageInfo<P, P::S - 1>::K;
+}
+
+// mid stages 1..S-2 (plans have S <= 5, so at most three of them).  `hook(slot)` is
+// called once per butterfly round with a compile-time slot number.
+template <class P, int s, int SLOT0, class Hook>
+__device__ __forceinline__ void mid_stages_seeded(cd* lds, const cd* tw2, const cd (&seed)[4],
+                                                  int tid, Hook&& hook) {
+    if constexpr (s <= P::S - 2) {
+        if constexpr (stage_seedable<P, s>()) {
+            fwd_stage_lds_seeded<P, s>(lds, seed[s], tid, [&](int m) { hook(SLOT0 + m); });
+            __syncthreads();
+            mid_stages_seeded<P, s + 1, SLOT0 + StageInfo<P, s>::K>(lds, tw2, seed, tid, hook);
+        } else {
+            fwd_stage_lds<P, s>(lds, tw2, tid);
+            __syncthreads();
+            mid_stages_seeded<P, s + 1, SLOT0>(lds, tw2, seed, tid, hook);
+        }
+    }
+}
+
+template <class P>
+constexpr bool plan_all_mid_seedable() {
+    bool ok = true;
+    if constexpr (P::S > 2) ok = ok && stage_seedable<P, 1>();
+    if constexpr (P::S > 3) ok = ok && stage_seedable<P, 2>();
+    if constexpr (P::S > 4) ok = ok && stage_seedable<P, 3>();
+    return ok;
+}
+
+// One pass type (A or B) over this workgroup's share of the column pairs.
+// STAMP (diagnostic builds only): lane 0 of wave 0 accumulates s_memtime deltas per
+// phase into stamps[0..7] = {wait+first stage, barrier, prefetch issue, mid stages,
+// last stage, end barrier, -, iterations}.
+#define TA_STAMP(idx)                                                              \
+    if constexpr (STAMP) {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();              \
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                      \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+        st_acc[idx] += now_ - st_prev;                                             \
+        st_prev = now_;                                                            \
+    }
+
+template <class P, bool VEC, bool PASSB, bool STAMP = false>
 __device__ __forceinline__ void accum_body(cd* lds, const double* __restrict__ vel, long ld_row,
-                                           int T, long n_cols, const cd* __restrict__ tw2,
-                                           double* __restrict__ out, int slot, int n_slots,
-                                           long pair_stride, int flags) {
+                                           long pair_stride, int T, long n_cols,
+                                           const cd* __restrict__ tw2, double* __restrict__ out,
+                                           int slot, int n_slots,
+                                           unsigned long long* __restrict__ stamps = nullptr) {
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_prev = 0;
+    if constexpr (STAMP) st_prev = __builtin_amdgcn_s_memtime();
     using SL = StageInfo<P, P::S - 1>;
-    const int tid = threadIdx.x;
+    static_assert(P::S <= 5, "seed array sized for S <= 5");
+    int tid = threadIdx.x;
     double acc[SL::K][SL::R];
 #pragma unroll
     for (int m = 0; m < SL::K; ++m)
 #pragma unroll
-        for (int q = 0; q < SL::R; ++q) acc[m][q] = 0.0;
+        for (int q = 0; q < SL::R; ++q) {
+            acc[m][q] = 0.0;
+            if constexpr (VEC) TA_PIN_A(acc[m][q]);
+        }
+    cd seed[4];
+    seed[0] = cd{1.0, 0.0};
+    seed[1] = stage_seed<P, (P::S > 2 ? 1 : 0)>(tw2, tid);
+    seed[2] = stage_seed<P, (P::S > 3 ? 2 : 0)>(tw2, tid);
+    seed[3] = stage_seed<P, (P::S > 4 ? 3 : 0)>(tw2, tid);
+
     const long n_pairs = (n_cols + 1) / 2;
-    for (long pair = slot; pair < n_pairs; pair += n_slots) {
-        const bool has2 = 2 * pair + 1 < n_cols;
-        forward_pass_acc<P, VEC, PASSB>(lds, tw2, vel + pair * pair_stride, ld_row, T, has2, acc,
-                                        tid, flags);
+    FirstRegs<P> v;
+    long pair = slot;
+    if (pair < n_pairs)
+        gather_issue<P, VEC>(v, vel + pair * pair_stride, ld_row, T, 2 * pair + 1 < n_cols, tid);
+    while (pair < n_pairs) {
+        // per-lane addresses and table offsets depend on tid/ld_row only: keep LICM from
+        // hoisting (and spilling) them out of the pair loop
+        asm volatile("" : "+s"(tw2), "+s"(ld_row), "+v"(tid));
+        gather_wait<P, VEC>(v);
+        first_stage_from_regs<P, PASSB, VEC>(lds, tw2, v, T, tid);
+        TA_STAMP(0)
+        __syncthreads();
+        TA_STAMP(1)
+        const long next = pair + n_slots;
+        const bool more = next < n_pairs;
+        const double* ncol = vel + (more ? next : pair) * pair_stride;
+        const bool nhas2 = 2 * (more ? next : pair) + 1 < n_cols;
+        // the next pair's gather, spread over the butterfly rounds of this pair: the
+        // divergent loads are L2-request-bound (~0.36 lane-requests/clk/CU), so issued in
+        // one burst they would stall the wave for as long as the whole transform takes
+        constexpr int NSLOT = slots_from<P, 1>();
+        constexpr int NLOAD = StageInfo<P, 0>::K * StageInfo<P, 0>::R;
+        constexpr int PER = (NLOAD + NSLOT - 1) / NSLOT;
+        auto hook = [&](int slot) {
+            if (more) {
+#define TA_PIECE(S)                                                                         \
+    if (slot == S)                                                                          \
+        gather_issue_range<P, VEC, (S)*PER, ((S) + 1) * PER>(v, ncol, ld_row, T, nhas2, tid);
+                TA_PIECE(0) TA_PIECE(1) TA_PIECE(2) TA_PIECE(3) TA_PIECE(4) TA_PIECE(5)
+                TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
+                TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)
+                TA_PIECE(18) TA_PIECE(19) TA_PIECE(20) TA_PIECE(21) TA_PIECE(22) TA_PIECE(23)
+#undef TA_PIECE
+            }
+        };
+        static_assert(NSLOT <= 24, "extend the TA_PIECE list");
+        TA_STAMP(2)
+        mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, hook);
+        TA_STAMP(3)
+        last_stage_acc_parked<P, VEC>(lds, acc, tid,
+                                      [&](int m) { hook(NSLOT - StageInfo<P, P::S - 1>::K + m); });
+        TA_STAMP(4)
+        __syncthreads();
+        TA_STAMP(5)
+        if constexpr (STAMP) st_acc[7] += 1;
+        pair = next;
+    }
+    if constexpr (STAMP) {
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 8; ++i) stamps[i] = st_acc[i];
     }
 #pragma unroll
     for (int m = 0; m < SL::K; ++m) {
@@ -163,17 +401,22 @@ __device__ __forceinline__ void accum_body(cd* lds, const double* __restrict__ v
     }
 }
 
-template <class P, bool VEC>
+// Persistent workgroups; gridDim.x even.  Workgroup -> (pass, slot): with a grid
+// that is a multiple of 16, blocks b and b+8 share an XCD, the A and the B workgroup
+// of a slot sit on the same XCD and an XCD's slots take consecutive pairs, so the 16
+// readers of a 128-byte line (8 pairs x 2 passes) go through one L2.
+// partial: [2][gridDim.x/2][P::M], digit-reversed bin order.
+template <class P, bool VEC, bool STAMP = false>
 __global__ void __launch_bounds__(P::NT)
     k_fft_accum(const double* __restrict__ vel, long ld_row, long pair_stride, int T, long n_cols,
-                const cd* __restrict__ tw2, double* __restrict__ partial, int flags) {
+                const cd* __restrict__ tw2, double* __restrict__ partial, int flags,
+                unsigned long long* __restrict__ stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
     const int nwg = gridDim.x, wg = blockIdx.x;
     const int n_slots = nwg / 2;
     int pass, slot;
     if (nwg % 16 == 0) {
-        // blocks b and b+8 share an XCD: (xcd, r) with r = b / 8; pass = r & 1.
         const int xcd = wg % 8, r = wg / 8, per_xcd = nwg / 16;
         pass = r & 1;
         slot = xcd * per_xcd + (r >> 1);
@@ -182,10 +425,13 @@ __global__ void __launch_bounds__(P::NT)
         slot = wg >> 1;
     }
     double* out = partial + ((long)pass * n_slots + slot) * P::M;
+    unsigned long long* st = STAMP ? stamps + 8 * (long)wg : nullptr;
     if (pass == 0)
-        accum_body<P, VEC, false>(lds, vel, ld_row, T, n_cols, tw2, out, slot, n_slots, pair_stride, flags);
+        accum_body<P, VEC, false, STAMP>(lds, vel, ld_row, pair_stride, T, n_cols, tw2, out, slot,
+                                         n_slots, st);
     else
-        accum_body<P, VEC, true>(lds, vel, ld_row, T, n_cols, tw2, out, slot, n_slots, pair_stride, flags);
+        accum_body<P, VEC, true, STAMP>(lds, vel, ld_row, pair_stride, T, n_cols, tw2, out, slot,
+                                        n_slots, st);
 }
 
 // Shared epilogue: LDS holds q = IDFT_M(P_A + i P_B) in natural order.

@@ -5,7 +5,10 @@
 
 namespace ta {
 
-// X(NT, radices...)   — the last radix has unit stride and feeds the accumulators
+// X(NT, radices...)   — the last radix has unit stride and feeds the accumulators.
+// NT = M/32 (2^a) or M/40 (5*2^a), at least 64: one wave per SIMD slot for the big
+// plans, so a thread can hold the gathered pair, both accumulator sets and one
+// butterfly's data without spilling (<= 512 VGPRs).
 #define TA_PLANS_POW2(X)        \
     X(64, 4, 4)                 \
     X(64, 8, 4)                 \
@@ -14,9 +17,9 @@ namespace ta {
     X(64, 16, 16)               \
     X(64, 8, 8, 8)              \
     X(64, 16, 8, 8)             \
-    X(128, 16, 16, 8)           \
-    X(256, 16, 16, 16)          \
-    X(512, 16, 8, 8, 8)
+    X(64, 16, 16, 8)            \
+    X(128, 16, 16, 16)          \
+    X(256, 16, 8, 8, 8)
 
 #define TA_PLANS_FIVE(X)        \
     X(64, 5, 4)                 \
@@ -25,9 +28,9 @@ namespace ta {
     X(64, 5, 8, 4)              \
     X(64, 5, 8, 8)              \
     X(64, 5, 16, 8)             \
-    X(128, 5, 16, 16)           \
-    X(128, 5, 8, 8, 8)          \
-    X(320, 5, 16, 8, 8)         \
-    X(640, 5, 16, 16, 8)
+    X(64, 5, 16, 16)            \
+    X(64, 5, 8, 8, 8)           \
+    X(128, 5, 16, 8, 8)         \
+    X(256, 5, 16, 16, 8)
 
 }  // namespace ta
