@@ -13,7 +13,7 @@ def run(T, A, D, nwg=0):
     ts, _ = ctx.vacf_fft(by_particle=False)
     _, want = orc.vacf_fft_batched(v)
     e = np.max(np.abs(ts - want)) / np.max(np.abs(want))
-    print(T, A, D, "nwg", nwg, "err", e, flush=True)
-for (T, A, D) in [(5, 2, 2), (17, 4, 1), (64, 5, 2), (33, 9, 2), (16, 4, 2), (64, 64, 2), (5, 20, 2), (200, 4, 2), (1000,4,2)]:
-    for nwg in (0, 2, 4, 16, 32):
-        run(T, A, D, nwg)
+    print(T, A, D, "M", _lib.fft_plan_info(T)["M"], "nwg", nwg, "err %.2e" % e, flush=True)
+for T in (600, 1100, 1500, 2049, 2561, 3000, 4097, 9000):
+    for (A, D) in ((4, 2), (3, 3), (64, 3), (600, 2)):
+        run(T, A, D)

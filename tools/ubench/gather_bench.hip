@@ -1,0 +1,83 @@
+// gather_bench.hip — microbenchmark of the strided column gather (diagnostic tool).
+// Each workgroup reads, for its column group, W bytes per row from T rows (row stride = ld bytes);
+// lanes take consecutive rows.  Reports useful GB/s and lane-requests/clk/CU.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+template <int NT, int UNROLL, int WIDTH>  // WIDTH = doubles per lane per row (2, 4, 8, 16)
+__global__ void __launch_bounds__(NT) k_gather(const double* __restrict__ base, long ld, int T,
+                                               long n_groups, double* __restrict__ out) {
+    double acc = 0.0;
+    const int tid = threadIdx.x;
+    // XCD-aware: blocks sharing an XCD take adjacent column groups
+    const int nwg = gridDim.x;
+    long slot = blockIdx.x;
+    if (nwg % 8 == 0) slot = (long)(blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    for (long g = slot; g < n_groups; g += nwg) {
+        const double* col = base + g * WIDTH;
+        for (int t0 = 0; t0 < T; t0 += NT * UNROLL) {
+            double2 v[UNROLL][WIDTH / 2];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                int t = t0 + tid + k * NT;
+                t = t < T ? t : T - 1;
+                const double2* p = reinterpret_cast<const double2*>(col + (long)t * ld);
+#pragma unroll
+                for (int w = 0; w < WIDTH / 2; ++w) v[k][w] = p[w];
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k)
+#pragma unroll
+                for (int w = 0; w < WIDTH / 2; ++w) acc += v[k][w].x + v[k][w].y;
+        }
+    }
+    out[(long)blockIdx.x * NT + tid] = acc;
+}
+
+template <int NT, int UNROLL, int WIDTH>
+void run(const double* d, long ld, int T, long C, int wg_per_cu, double* out) {
+    const long n_groups = C / WIDTH;
+    int nwg = 256 * wg_per_cu;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9;
+    for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_gather<NT, UNROLL, WIDTH>), dim3(nwg), dim3(NT), 0, 0, d, ld, T, n_groups, out);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double bytes = (double)T * C * 8;
+    const double reqs = (double)T * n_groups;  // lane-row requests
+    printf("NT=%4d unroll=%2d width=%3dB wg/cu=%d : %8.3f ms  %7.1f GB/s useful  %.3f lane-req/clk/CU (2.1GHz)\n",
+           NT, UNROLL, WIDTH * 8, wg_per_cu, best, bytes / best / 1e6, reqs / (best * 1e-3 * 2.1e9 * 256));
+}
+
+int main(int argc, char** argv) {
+    const int T = argc > 1 ? atoi(argv[1]) : 10000;
+    const long A = argc > 2 ? atol(argv[2]) : 20000;
+    const long C = A * 3;
+    double* d; CK(hipMalloc(&d, sizeof(double) * T * C));
+    CK(hipMemset(d, 0, sizeof(double) * T * C));
+    double* out; CK(hipMalloc(&out, sizeof(double) * 256 * 8 * 1024));
+    printf("T=%d C=%ld (%.2f GB)\n", T, C, T * C * 8 / 1e9);
+    run<256, 8, 2>(d, C, T, C, 1, out);
+    run<256, 20, 2>(d, C, T, C, 1, out);
+    run<256, 40, 2>(d, C, T, C, 1, out);
+    run<512, 20, 2>(d, C, T, C, 1, out);
+    run<1024, 10, 2>(d, C, T, C, 1, out);
+    run<256, 10, 2>(d, C, T, C, 4, out);
+    run<256, 10, 2>(d, C, T, C, 8, out);
+    run<1024, 10, 2>(d, C, T, C, 2, out);
+    run<256, 20, 4>(d, C, T, C, 1, out);
+    run<256, 10, 4>(d, C, T, C, 4, out);
+    run<256, 10, 8>(d, C, T, C, 4, out);
+    run<256, 5, 16>(d, C, T, C, 4, out);
+    run<1024, 10, 4>(d, C, T, C, 2, out);
+    run<1024, 5, 8>(d, C, T, C, 2, out);
+    run<1024, 2, 16>(d, C, T, C, 2, out);
+    return 0;
+}

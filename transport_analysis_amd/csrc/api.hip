@@ -347,20 +347,20 @@ int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int 
         const int64_t n_pairs = (A * D + 1) / 2;
         int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg
                                            : (int64_t)ctx->n_cu * plan->max_wg_per_cu(vec ? 0 : 1);
-        nwg = std::max<int64_t>(2, std::min(nwg, 2 * n_pairs));
-        if (nwg >= 16) nwg -= nwg % 16;  // XCD-aware walk: (8 XCDs) x (pass A, pass B)
-        nwg -= nwg % 2;
-        const int64_t n_slots = nwg / 2;
-        if ((rc = ensure(ctx, ctx->partial, sizeof(double) * (size_t)nwg * plan->M))) return rc;
+        nwg = std::max<int64_t>(1, std::min(nwg, n_pairs));
+        if (nwg >= 8) nwg -= nwg % 8;  // XCD-aware walk
+        const size_t acc_blk = (size_t)((plan->K_last * plan->R_last + 1) / 2) * 2 * plan->NT;
+        const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * acc_blk;
+        if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
         if ((rc = ensure(ctx, ctx->spec, sizeof(double) * 2 * plan->M))) return rc;
         a.partial = (double*)ctx->partial.p;
+        TA_HIP_TRY(ctx, hipMemsetAsync(a.partial, 0, acc_bytes, st));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
         TA_HIP_TRY(ctx, plan->accum(vec, (int)nwg, st, a));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-        for (int pass = 0; pass < 2; ++pass)
-            TA_HIP_TRY(ctx, launch_sum_partials(a.partial + (size_t)pass * n_slots * plan->M,
-                                                (int)n_slots, plan->M,
-                                                (double*)ctx->spec.p + (size_t)pass * plan->M, st));
+        TA_HIP_TRY(ctx, launch_sum_partials_perm(a.partial, (int)nwg, plan->M, plan->NT, plan->R_last,
+                                                 plan->K_last, plan->TASKS_last,
+                                                 (double*)ctx->spec.p, st));
         a.spec = (const double*)ctx->spec.p;
         a.lagsum = d_lagsum;
         TA_HIP_TRY(ctx, plan->finalize(st, a));

@@ -17,6 +17,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef TA_AGPR_FENCE_HOOK
+#define TA_AGPR_FENCE_HOOK()
+#endif
+
 namespace ta {
 
 struct cd {
@@ -279,6 +283,10 @@ __device__ __forceinline__ void fwd_stage_lds_seeded(cd* __restrict__ lds, cd se
                                                      Hook&& after_task) {
     using SI = StageInfo<P, s>;
     static_assert(P::NT % SI::L == 0, "seeded stage needs NT % L == 0");
+    // The seed is the same for every column pair, so LICM would hoist the whole power
+    // chain (R-1 complex values per stage) out of the pair loop and spill it; laundering
+    // the seed keeps the chain where it is used.
+    asm volatile("" : "+v"(seed.x), "+v"(seed.y));
     const cd seed2 = cmul(seed, seed);
 #pragma unroll
     for (int m = 0; m < SI::K; ++m) {
@@ -289,7 +297,9 @@ __device__ __forceinline__ void fwd_stage_lds_seeded(cd* __restrict__ lds, cd se
             cd v[SI::R];
 #pragma unroll
             for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(base + j * SI::L)];
+            TA_AGPR_FENCE_HOOK();
             Dft<SI::R>::run(v);
+            TA_AGPR_FENCE_HOOK();
             cd wo = seed, we = seed2;  // seed^q for the current odd / even q
             v[1] = cmul(v[1], wo);
             if constexpr (SI::R > 2) v[2] = cmul(v[2], we);
@@ -303,9 +313,11 @@ __device__ __forceinline__ void fwd_stage_lds_seeded(cd* __restrict__ lds, cd se
                     v[q] = cmul(v[q], we);
                 }
             }
+            TA_AGPR_FENCE_HOOK();
 #pragma unroll
             for (int q = 0; q < SI::R; ++q) lds[sw(base + q * SI::L)] = v[q];
         }
+        TA_AGPR_FENCE_HOOK();
         // all lanes (also those without a butterfly in this round) run the hook
         __builtin_amdgcn_sched_barrier(0);
         after_task(m);

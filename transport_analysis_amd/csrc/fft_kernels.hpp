@@ -24,6 +24,9 @@
 // tw2 is the single twiddle table W_{2M}^n = exp(-i pi n / M), n < 2M.
 // Algorithmic HBM bytes: every input element is needed once: T*A*D*8 bytes.
 #pragma once
+#include <hip/hip_runtime.h>
+#include "agpr_slots.inc"
+#define TA_AGPR_FENCE_HOOK() TA_AGPR_FENCE()
 #include "fft_engine.hpp"
 
 namespace ta {
@@ -144,115 +147,164 @@ __device__ __forceinline__ void forward_pass_acc(
 // s_waitcnt vmcnt drains it early.
 //
 // partial: [2][gridDim.x][P::M] float64 in the transform's digit-reversed bin order.
-// The gathered pair and the accumulators are "cold" for most of an iteration; at
-// one wave per SIMD a wave owns 512 registers, of which VALU instructions can only
-// address the first 256.  They are parked in the upper half (the AGPRs) explicitly:
-// the gather is issued as global_load_dwordx4 with an AGPR destination (inline asm,
-// so the compiler neither waits for it nor spills it), and TA_PIN_A forces a value
-// into the AGPR class at a program point so no long-lived VGPR copy survives.
-typedef double d2 __attribute__((ext_vector_type(2)));
-#define TA_PIN_A(x) asm volatile("" : "+a"(x))
+// ---- K1+K2: accumulate power spectra over column pairs ------------------------
+//
+// Register plan.  At one wave per SIMD a wave owns 512 registers, of which VALU
+// instructions can only address the lower 256 (v0..v255); the upper half (a0..a255,
+// the AGPRs) is reachable by v_accvgpr_read/write and by global loads/stores.  The
+// gathered column pair (up to 40 complex f64 = 160 dwords per thread) and one
+// accumulator set (up to 48 f64 = 96 dwords) are "cold" for most of an iteration and
+// are kept there EXPLICITLY, at fixed register numbers, through the accessors of
+// agpr_slots.inc (inline asm; the file is compiled with
+// -mllvm -amdgpu-spill-vgpr-to-agpr=0 so the compiler itself never touches an AGPR).
+// That makes the software pipeline deterministic: the gather is issued as
+// global_load_dwordx4 with an AGPR destination, nobody waits for it or spills it, and
+// the compiler's own 256 VGPRs are left for one butterfly's working set.
+#include <type_traits>
+#include <utility>
 
-template <class P>
-using FirstRegs = d2[StageInfo<P, 0>::K][StageInfo<P, 0>::R];
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        (f(std::integral_constant<int, I>{}), ...);
+    }(std::make_integer_sequence<int, N>{});
+}
 
-// Issue gather loads [lo, hi) (flat index m*R + j) of one column pair (no wait).
-// Rows past the end (t >= T, the zero padding) re-read row T-1 and are zeroed when
-// the registers are consumed, so the loads are branch-free.
+constexpr int kAgprV = 0;      // a[0..159]: gathered pair, 4 dwords per complex value
+constexpr int kAgprAcc = 160;  // a[160..255]: accumulators, 2 dwords per bin
+
+template <int I>
+__device__ __forceinline__ double ag_read_f64() {
+    return __hiloint2double((int)AG<I + 1>::r(), (int)AG<I>::r());
+}
+template <int I>
+__device__ __forceinline__ void ag_write_f64(double x) {
+    AG<I>::w((unsigned)__double2loint(x));
+    AG<I + 1>::w((unsigned)__double2hiint(x));
+}
+
+// Issue gather loads [LO, HI) (flat index f = m*R0 + j -> a[4f..4f+3]) of one column pair.
+// Rows past the end (t >= T, the zero padding) re-read row T-1 and are zeroed when the
+// registers are read, so the loads are branch-free.  Non-VEC (rows not 16-byte aligned or
+// an odd last column): two 8-byte loads, or one plus a zero imaginary part.
 template <class P, bool VEC, int LO, int HI>
-__device__ __forceinline__ void gather_issue_range(FirstRegs<P>& v, const double* __restrict__ col,
-                                                   long ld_row, int T, bool has2, int tid) {
+__device__ __forceinline__ void gather_issue_range(const double* __restrict__ col, long ld_row,
+                                                   int T, bool has2, int tid) {
     using SI = StageInfo<P, 0>;
-#pragma unroll
-    for (int f = LO; f < HI; ++f) {
-        if (f < SI::K * SI::R) {
-            const int m = f / SI::R, j = f % SI::R;
+    // compute this piece's addresses here and now (hoisted out, the 40 row addresses of a
+    // pair would occupy 80 VGPRs for the whole pass)
+    asm volatile("" : "+v"(tid), "+s"(ld_row));
+    static_for<(HI > LO ? HI - LO : 0)>([&](auto i) {
+        constexpr int f = LO + decltype(i)::value;
+        if constexpr (f < SI::K * SI::R) {
+            constexpr int m = f / SI::R, j = f % SI::R;
             const int t = tid + m * P::NT + j * SI::L;
             const int tc = t < T ? t : T - 1;
             const double* p = col + (long)tc * ld_row;
             if constexpr (VEC) {
-                v[m][j] = *reinterpret_cast<const d2*>(p);
+                ag_load4<kAgprV + 4 * f>(p);
             } else {
-                d2 z;
-                z.x = p[0];
-                z.y = has2 ? p[1] : 0.0;
-                v[m][j] = z;
+                ag_load2<kAgprV + 4 * f>(p);
+                if (has2) {
+                    ag_load2<kAgprV + 4 * f + 2>(p + 1);
+                } else {
+                    AG<kAgprV + 4 * f + 2>::w(0u);
+                    AG<kAgprV + 4 * f + 3>::w(0u);
+                }
             }
         }
-    }
+    });
 }
 
-template <class P, bool VEC>
-__device__ __forceinline__ void gather_issue(FirstRegs<P>& v, const double* __restrict__ col,
-                                             long ld_row, int T, bool has2, int tid) {
-    using SI = StageInfo<P, 0>;
-    gather_issue_range<P, VEC, 0, SI::K * SI::R>(v, col, ld_row, T, has2, tid);
-}
+// number of VMEM instructions gather_issue_range issues per element
+template <bool VEC>
+constexpr int loads_per_elem() { return VEC ? 1 : 2; }
 
-template <class P, bool VEC>
-__device__ __forceinline__ void gather_wait(FirstRegs<P>& v) {
+// First stage from the parked pair (read-only: pass B reads it again).
+template <class P, bool PASSB>
+__device__ __forceinline__ void first_stage_from_agpr(cd* __restrict__ lds,
+                                                      const cd* __restrict__ tw2, int T, int tid) {
     using SI = StageInfo<P, 0>;
-    (void)v;
-}
-
-// First stage from the gathered registers.
-template <class P, bool PASSB, bool VEC>
-__device__ __forceinline__ void first_stage_from_regs(cd* __restrict__ lds,
-                                                      const cd* __restrict__ tw2,
-                                                      FirstRegs<P>& v, int T, int tid) {
-    using SI = StageInfo<P, 0>;
-#pragma unroll
-    for (int m = 0; m < SI::K; ++m) {
+    static_for<SI::K>([&](auto mm) {
+        constexpr int m = decltype(mm)::value;
         const int u = tid + m * P::NT;
         if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
             cd w[SI::R];
-#pragma unroll
-            for (int j = 0; j < SI::R; ++j) {
+            static_for<SI::R>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                constexpr int a = kAgprV + 4 * (m * SI::R + j);
                 const bool live = u + j * SI::L < T;  // rows past the end are zero padding
-                w[j] = cd{live ? v[m][j].x : 0.0, live ? v[m][j].y : 0.0};
-            }
+                const double x = ag_read_f64<a>(), y = ag_read_f64<a + 2>();
+                w[j] = cd{live ? x : 0.0, live ? y : 0.0};
+            });
             if constexpr (PASSB) {
                 // lane-uniform part of the twist: W_{2 R0}^j = tw2[j * L]
 #pragma unroll
                 for (int j = 1; j < SI::R; ++j) w[j] = cmul(w[j], tw2[j * SI::L]);
             }
+            TA_AGPR_FENCE();
             Dft<SI::R>::run(w);
+            TA_AGPR_FENCE();
 #pragma unroll
             for (int q = PASSB ? 0 : 1; q < SI::R; ++q)
                 w[q] = cmul(w[q], tw2[u * (2 * q + (PASSB ? 1 : 0))]);
+            TA_AGPR_FENCE();
 #pragma unroll
             for (int q = 0; q < SI::R; ++q) lds[sw(u + q * SI::L)] = w[q];
         }
-        // one butterfly's twiddle loads at a time
-        __builtin_amdgcn_sched_barrier(0);
-    }
+        TA_AGPR_FENCE();
+        __builtin_amdgcn_sched_barrier(0);  // one butterfly's twiddle loads at a time
+    });
 }
 
-// Last forward stage fused with |.|^2 accumulation; accumulators parked in AGPRs.
-template <class P, bool VEC, class Hook>
-__device__ __forceinline__ void last_stage_acc_parked(
-    const cd* __restrict__ lds,
-    double (&acc)[StageInfo<P, P::S - 1>::K][StageInfo<P, P::S - 1>::R], int tid, Hook&& after_task) {
+// Last forward stage fused with |.|^2 accumulation into the parked accumulators.
+template <class P, class Hook>
+__device__ __forceinline__ void last_stage_acc_agpr(const cd* __restrict__ lds, int tid,
+                                                    Hook&& after_task) {
     using SI = StageInfo<P, P::S - 1>;
-#pragma unroll
-    for (int m = 0; m < SI::K; ++m) {
+    static_for<SI::K>([&](auto mm) {
+        constexpr int m = decltype(mm)::value;
         const int u = tid + m * P::NT;
         if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
             cd v[SI::R];
 #pragma unroll
             for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(u * SI::R + j)];
+            TA_AGPR_FENCE();
             Dft<SI::R>::run(v);
-#pragma unroll
-            for (int q = 0; q < SI::R; ++q) {
-                acc[m][q] += norm2(v[q]);
-                if constexpr (VEC) TA_PIN_A(acc[m][q]);
-            }
+            TA_AGPR_FENCE();
+            static_for<SI::R>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                constexpr int a = kAgprAcc + 2 * (m * SI::R + q);
+                ag_write_f64<a>(ag_read_f64<a>() + norm2(v[q]));
+            });
         }
-        asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         after_task(m);
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
+}
+
+// Accumulator swap between the AGPRs and this workgroup's private block in global
+// memory (L2/MALL resident), laid out [quad][thread] so a wave's accesses are contiguous;
+// a thread only ever touches its own slots, so program order is the only ordering needed.
+template <class P>
+constexpr int acc_quads() {
+    return (StageInfo<P, P::S - 1>::K * StageInfo<P, P::S - 1>::R * 2 + 3) / 4;
+}
+template <class P>
+__device__ __forceinline__ void acc_swap_in(const double* __restrict__ blk, int tid) {
+    static_for<acc_quads<P>()>([&](auto qq) {
+        constexpr int q = decltype(qq)::value;
+        ag_load4<kAgprAcc + 4 * q>(blk + 2 * ((long)q * P::NT + tid));
+    });
+}
+template <class P>
+__device__ __forceinline__ void acc_swap_out(double* __restrict__ blk, int tid) {
+    asm volatile("s_nop 4" ::: "memory");  // VALU AGPR writes -> VMEM store data (no auto padding in asm)
+    static_for<acc_quads<P>()>([&](auto qq) {
+        constexpr int q = decltype(qq)::value;
+        ag_store4<kAgprAcc + 4 * q>(blk + 2 * ((long)q * P::NT + tid));
+    });
 }
 
 template <class P, int s>
@@ -262,14 +314,14 @@ __device__ __forceinline__ cd stage_seed(const cd* __restrict__ tw2, int tid) {
     else return cd{1.0, 0.0};
 }
 
-// Number of butterfly rounds a thread runs in the seeded mid stages s..S-2 and in the
-// last stage: the slots between which the next pair's gather loads are spread.
+// Number of butterfly rounds a thread runs in the seeded mid stages s..S-2 (MIDSLOTS)
+// and in the last stage: the slots between which the next pair's gather loads are spread.
 template <class P, int s>
-constexpr int slots_from() {
+constexpr int mid_slots_from() {
     if constexpr (s <= P::S - 2)
-        return (stage_seedable<P, s>() ? StageInfo<P, s>::K : 0) + slots_from<P, s + 1>();
+        return (stage_seedable<P, s>() ? StageInfo<P, s>::K : 0) + mid_slots_from<P, s + 1>();
     else
-        return StageInfo<P, P::S - 1>::K;
+        return 0;
 }
 
 // mid stages 1..S-2 (plans have S <= 5, so at most three of them).  `hook(slot)` is
@@ -299,10 +351,7 @@ constexpr bool plan_all_mid_seedable() {
     return ok;
 }
 
-// One pass type (A or B) over this workgroup's share of the column pairs.
-// STAMP (diagnostic builds only): lane 0 of wave 0 accumulates s_memtime deltas per
-// phase into stamps[0..7] = {wait+first stage, barrier, prefetch issue, mid stages,
-// last stage, end barrier, -, iterations}.
+// STAMP (diagnostic builds only): lane 0 accumulates s_memtime deltas per phase.
 #define TA_STAMP(idx)                                                              \
     if constexpr (STAMP) {                                                         \
         __builtin_amdgcn_sched_barrier(0);                                         \
@@ -313,61 +362,97 @@ constexpr bool plan_all_mid_seedable() {
         st_prev = now_;                                                            \
     }
 
-template <class P, bool VEC, bool PASSB, bool STAMP = false>
-__device__ __forceinline__ void accum_body(cd* lds, const double* __restrict__ vel, long ld_row,
-                                           long pair_stride, int T, long n_cols,
-                                           const cd* __restrict__ tw2, double* __restrict__ out,
-                                           int slot, int n_slots,
-                                           unsigned long long* __restrict__ stamps = nullptr) {
+// Persistent workgroups (one wave per SIMD at the big plans).  A workgroup gathers a
+// column pair ONCE and runs both passes from the parked registers (A: even bins, B: odd
+// bins), so every input element is requested from L2 once.  With a grid that is a
+// multiple of 8, blocks b and b+8 share an XCD and an XCD's workgroups take consecutive
+// pairs, so the 8 pairs of a 128-byte line go through one L2 and the line leaves HBM once.
+//
+// Per pair:  wait gather -> first stage A -> [swap in acc A] mid A -> last A [swap out]
+//            -> first stage B -> [swap in acc B] mid B -> last B [swap out], with the NEXT
+//            pair's gather loads spread between pass B's butterfly rounds.
+// The 16-byte strided gather is L2-request-bound (a pure gather of this shape peaks at
+// ~2.3 TB/s on MI355X, ~0.27 lane-requests/clk/CU); issued as one burst its 40 loads per
+// thread would stall the wave for longer than a whole pass takes.
+//
+// accg: [gridDim.x][2][acc_quads*2*NT] float64 (pass A block, pass B block), zeroed by
+// the caller; k_sum_partials_perm restores the transform's digit-reversed bin order.
+template <class P, bool VEC, bool STAMP = false>
+__global__ void __launch_bounds__(P::NT)
+    k_fft_accum(const double* __restrict__ vel, long ld_row, long pair_stride, int T, long n_cols,
+                const cd* __restrict__ tw2, double* __restrict__ accg, int flags,
+                unsigned long long* __restrict__ stamps = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd* lds = reinterpret_cast<cd*>(smem_raw);
+    using SL = StageInfo<P, P::S - 1>;
+    using S0 = StageInfo<P, 0>;
+    static_assert(P::S <= 5, "seed array sized for S <= 5");
+    static_assert(S0::K * S0::R * 4 <= kAgprAcc, "gathered pair does not fit a[0..159]");
+    static_assert(kAgprAcc + acc_quads<P>() * 4 <= 256, "accumulators do not fit a[160..255]");
+    constexpr long ACC_BLK = (long)acc_quads<P>() * 2 * P::NT;
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_prev = 0;
     if constexpr (STAMP) st_prev = __builtin_amdgcn_s_memtime();
-    using SL = StageInfo<P, P::S - 1>;
-    static_assert(P::S <= 5, "seed array sized for S <= 5");
+
+    const int nwg = gridDim.x, wg = blockIdx.x;
+    int slot = wg;
+    if (nwg % 8 == 0) slot = (wg % 8) * (nwg / 8) + wg / 8;
     int tid = threadIdx.x;
-    double acc[SL::K][SL::R];
-#pragma unroll
-    for (int m = 0; m < SL::K; ++m)
-#pragma unroll
-        for (int q = 0; q < SL::R; ++q) {
-            acc[m][q] = 0.0;
-            if constexpr (VEC) TA_PIN_A(acc[m][q]);
-        }
+    double* blkA = accg + (long)wg * 2 * ACC_BLK;
+    double* blkB = blkA + ACC_BLK;
+
     cd seed[4];
     seed[0] = cd{1.0, 0.0};
     seed[1] = stage_seed<P, (P::S > 2 ? 1 : 0)>(tw2, tid);
     seed[2] = stage_seed<P, (P::S > 3 ? 2 : 0)>(tw2, tid);
     seed[3] = stage_seed<P, (P::S > 4 ? 3 : 0)>(tw2, tid);
 
+    constexpr int NLOAD = S0::K * S0::R;
+    constexpr int MIDSLOTS = mid_slots_from<P, 1>();
+    constexpr int NSLOT = MIDSLOTS + SL::K;
+    constexpr int PER = (NLOAD + NSLOT - 1) / NSLOT;
+    constexpr int MID_VMEM = MIDSLOTS * PER * loads_per_elem<VEC>();  // issued before last B
+    static_assert(NSLOT <= 24, "extend the TA_PIECE list");
+
     const long n_pairs = (n_cols + 1) / 2;
-    FirstRegs<P> v;
     long pair = slot;
     if (pair < n_pairs)
-        gather_issue<P, VEC>(v, vel + pair * pair_stride, ld_row, T, 2 * pair + 1 < n_cols, tid);
+        gather_issue_range<P, VEC, 0, NLOAD>(vel + pair * pair_stride, ld_row, T,
+                                             2 * pair + 1 < n_cols, tid);
+    auto no_hook = [](int) {};
     while (pair < n_pairs) {
         // per-lane addresses and table offsets depend on tid/ld_row only: keep LICM from
         // hoisting (and spilling) them out of the pair loop
         asm volatile("" : "+s"(tw2), "+s"(ld_row), "+v"(tid));
-        gather_wait<P, VEC>(v);
-        first_stage_from_regs<P, PASSB, VEC>(lds, tw2, v, T, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the gathered pair has landed
+        // ---- pass A: even bins
+        first_stage_from_agpr<P, false>(lds, tw2, T, tid);
         TA_STAMP(0)
         __syncthreads();
+        acc_swap_in<P>(blkA, tid);
+        mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, no_hook);
         TA_STAMP(1)
-        const long next = pair + n_slots;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // accumulators A are in
+        last_stage_acc_agpr<P>(lds, tid, no_hook);
+        acc_swap_out<P>(blkA, tid);
+        TA_STAMP(2)
+        __syncthreads();
+        // ---- pass B: odd bins; after its first stage the parked pair is dead and is
+        // refilled with the next pair while pass B's butterflies run
+        first_stage_from_agpr<P, true>(lds, tw2, T, tid);
+        TA_STAMP(3)
+        __syncthreads();
+        acc_swap_in<P>(blkB, tid);
+        const long next = pair + nwg;
         const bool more = next < n_pairs;
         const double* ncol = vel + (more ? next : pair) * pair_stride;
         const bool nhas2 = 2 * (more ? next : pair) + 1 < n_cols;
-        // the next pair's gather, spread over the butterfly rounds of this pair: the
-        // divergent loads are L2-request-bound (~0.36 lane-requests/clk/CU), so issued in
-        // one burst they would stall the wave for as long as the whole transform takes
-        constexpr int NSLOT = slots_from<P, 1>();
-        constexpr int NLOAD = StageInfo<P, 0>::K * StageInfo<P, 0>::R;
-        constexpr int PER = (NLOAD + NSLOT - 1) / NSLOT;
-        auto hook = [&](int slot) {
+        const bool nhas2_all = VEC || nhas2;
+        auto hook = [&](int slot_) {
             if (more) {
 #define TA_PIECE(S)                                                                         \
-    if (slot == S)                                                                          \
-        gather_issue_range<P, VEC, (S)*PER, ((S) + 1) * PER>(v, ncol, ld_row, T, nhas2, tid);
+    if (slot_ == S)                                                                         \
+        gather_issue_range<P, VEC, (S)*PER, ((S) + 1) * PER>(ncol, ld_row, T, nhas2, tid);
                 TA_PIECE(0) TA_PIECE(1) TA_PIECE(2) TA_PIECE(3) TA_PIECE(4) TA_PIECE(5)
                 TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
                 TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)
@@ -375,63 +460,27 @@ __device__ __forceinline__ void accum_body(cd* lds, const double* __restrict__ v
 #undef TA_PIECE
             }
         };
-        static_assert(NSLOT <= 24, "extend the TA_PIECE list");
-        TA_STAMP(2)
         mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, hook);
-        TA_STAMP(3)
-        last_stage_acc_parked<P, VEC>(lds, acc, tid,
-                                      [&](int m) { hook(NSLOT - StageInfo<P, P::S - 1>::K + m); });
         TA_STAMP(4)
-        __syncthreads();
+        // accumulators B were requested before the gather pieces issued so far: wait until
+        // only those (younger) gather loads are outstanding
+        // (inline asm, not the s_waitcnt builtin: the compiler's waitcnt pass deletes
+        // builtin waits it considers redundant, and it cannot see the asm-issued loads)
+        if (more && nhas2_all && MID_VMEM < 64)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MID_VMEM < 64 ? MID_VMEM : 0) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last_stage_acc_agpr<P>(lds, tid, [&](int m) { hook(MIDSLOTS + m); });
+        acc_swap_out<P>(blkB, tid);
         TA_STAMP(5)
+        __syncthreads();
         if constexpr (STAMP) st_acc[7] += 1;
         pair = next;
     }
     if constexpr (STAMP) {
         if (threadIdx.x == 0)
-            for (int i = 0; i < 8; ++i) stamps[i] = st_acc[i];
+            for (int i = 0; i < 8; ++i) stamps[8 * (long)wg + i] = st_acc[i];
     }
-#pragma unroll
-    for (int m = 0; m < SL::K; ++m) {
-        const int u = tid + m * P::NT;
-        if (SL::TASKS % P::NT == 0 || u < SL::TASKS) {
-#pragma unroll
-            for (int q = 0; q < SL::R; ++q) out[u * SL::R + q] = acc[m][q];
-        }
-    }
-}
-
-// Persistent workgroups; gridDim.x even.  Workgroup -> (pass, slot): with a grid
-// that is a multiple of 16, blocks b and b+8 share an XCD, the A and the B workgroup
-// of a slot sit on the same XCD and an XCD's slots take consecutive pairs, so the 16
-// readers of a 128-byte line (8 pairs x 2 passes) go through one L2.
-// partial: [2][gridDim.x/2][P::M], digit-reversed bin order.
-template <class P, bool VEC, bool STAMP = false>
-__global__ void __launch_bounds__(P::NT)
-    k_fft_accum(const double* __restrict__ vel, long ld_row, long pair_stride, int T, long n_cols,
-                const cd* __restrict__ tw2, double* __restrict__ partial, int flags,
-                unsigned long long* __restrict__ stamps = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cd* lds = reinterpret_cast<cd*>(smem_raw);
-    const int nwg = gridDim.x, wg = blockIdx.x;
-    const int n_slots = nwg / 2;
-    int pass, slot;
-    if (nwg % 16 == 0) {
-        const int xcd = wg % 8, r = wg / 8, per_xcd = nwg / 16;
-        pass = r & 1;
-        slot = xcd * per_xcd + (r >> 1);
-    } else {
-        pass = wg & 1;
-        slot = wg >> 1;
-    }
-    double* out = partial + ((long)pass * n_slots + slot) * P::M;
-    unsigned long long* st = STAMP ? stamps + 8 * (long)wg : nullptr;
-    if (pass == 0)
-        accum_body<P, VEC, false, STAMP>(lds, vel, ld_row, pair_stride, T, n_cols, tw2, out, slot,
-                                         n_slots, st);
-    else
-        accum_body<P, VEC, true, STAMP>(lds, vel, ld_row, pair_stride, T, n_cols, tw2, out, slot,
-                                        n_slots, st);
 }
 
 // Shared epilogue: LDS holds q = IDFT_M(P_A + i P_B) in natural order.

@@ -26,7 +26,9 @@ int main(int argc, char** argv) {
     for (int n = 0; n < 2 * P::M; ++n) tw[n] = cd{cos(M_PI * n / P::M), -sin(M_PI * n / P::M)};
     cd* d_tw; CK(hipMalloc(&d_tw, sizeof(cd) * tw.size()));
     CK(hipMemcpy(d_tw, tw.data(), sizeof(cd) * tw.size(), hipMemcpyHostToDevice));
-    double* partial; CK(hipMalloc(&partial, sizeof(double) * (size_t)nwg * P::M));
+    const size_t accn = (size_t)nwg * 2 * acc_quads<P>() * 2 * P::NT;
+    double* partial; CK(hipMalloc(&partial, sizeof(double) * accn));
+    CK(hipMemset(partial, 0, sizeof(double) * accn));
     unsigned long long* st; CK(hipMalloc(&st, 8 * sizeof(unsigned long long) * nwg));
     const size_t lds = (size_t)P::lds_elems() * sizeof(cd);
     auto kern = k_fft_accum<P, true, true>;
@@ -43,7 +45,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(hs.data(), st, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost));
     double sum[8] = {0};
     for (int w = 0; w < nwg; ++w) for (int i = 0; i < 8; ++i) sum[i] += (double)hs[8 * w + i];
-    const char* names[8] = {"wait+first", "barrier1", "prefetch-issue", "mid", "last", "barrier-end", "-", "iters"};
+    const char* names[8] = {"wait+firstA", "bar+accin+midA", "lastA+accout", "bar+firstB", "bar+accin+midB(+gather)", "lastB(+gather)+accout", "-", "iters"};
     double tot = 0; for (int i = 0; i < 6; ++i) tot += sum[i];
     for (int i = 0; i < 8; ++i)
         printf("%-16s %12.0f cycles/iter  (%.1f%%)\n", names[i], sum[i] / sum[7], i < 6 ? 100.0 * sum[i] / tot : 0.0);

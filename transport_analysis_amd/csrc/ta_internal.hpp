@@ -20,7 +20,7 @@ struct FftArgs {
     long n_atoms;  // by_particle
     int D;
     const cd* tw2;        // W_{2M}^n, n < 2M
-    double* partial;      // accum: [2][nwg/2][M]
+    double* partial;      // accum: [nwg][2][quads*2*NT] float64, zeroed by the caller
     const double* spec;   // finalize: [2][M]
     double* lagsum;       // finalize: [T]
     double* by_particle;  // by_particle: (T, ld_bp)
@@ -30,6 +30,7 @@ struct FftArgs {
 
 struct PlanEntry {
     int M, NT, S;
+    int R_last, TASKS_last, K_last;  // accumulator block per pass: [quads][NT] x 4 dwords
     size_t lds_bytes;
     hipError_t (*accum)(bool vec, int nwg, hipStream_t st, const FftArgs& a);
     hipError_t (*finalize)(hipStream_t st, const FftArgs& a);
@@ -51,6 +52,9 @@ int direct_max_wg_per_cu(int mode, int nt, size_t lds_bytes);
 
 hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,
                                hipStream_t st);
+// spec[pass*M + u*R + q] = sum over workgroups of their accumulator (m, q), u = tid + m*NT
+hipError_t launch_sum_partials_perm(const double* partial, int n_parts, int M, int NT, int R, int K,
+                                    int TASKS, double* out, hipStream_t st);
 hipError_t launch_widen_f32(const float* in, double* out, long n, hipStream_t st);
 
 }  // namespace ta
