@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/regs.sh file.hip [grep-pattern]  — VGPR / scratch / occupancy per kernel
 cd /root/repo/transport_analysis_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++20 -mllvm -amdgpu-spill-vgpr-to-agpr=0 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Rpass-analysis=kernel-resource-usage -c $1 -o /tmp/regs_x.o 2>&1 | python3 -c "
+/opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Rpass-analysis=kernel-resource-usage -c $1 -o /tmp/regs_x.o 2>&1 | python3 -c "
 import sys,re
 name=None; d={}
 for l in sys.stdin:

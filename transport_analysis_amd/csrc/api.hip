@@ -88,28 +88,35 @@ const PlanEntry* find_plan(int64_t n_frames) {
     return best;
 }
 
-int get_tables(ta_ctx* ctx, int M, Tables* out) {
+int get_tables(ta_ctx* ctx, int M, int R0, Tables* out) {
     auto it = ctx->tables.find(M);
     if (it != ctx->tables.end()) {
         *out = it->second;
         return TA_OK;
     }
-    std::vector<cd> a(2 * (size_t)M);
+    // [0,2M): W_2M^n.  [2M,3M) and [3M,4M): the first-stage twiddles of pass A and pass B,
+    // W_2M^{u(2q+B)} stored [q][u] (u < M/R0) so that a wave's 64 consecutive butterflies read
+    // 1 KB contiguous (from the main table the same values sit 2q+B elements apart: one L2
+    // request per lane).
+    std::vector<cd> a(4 * (size_t)M);
     const long double pi = 3.141592653589793238462643383279502884L;
-    for (int n = 0; n < 2 * M; ++n) {
-        // reduce to the first octant so that symmetric entries are exact mirrors
+    auto w2m = [&](long n) {
+        n %= 2L * M;
+        if (n == 0) return cd{1.0, 0.0};
+        if (n == M) return cd{-1.0, 0.0};
+        if (2 * n == M) return cd{0.0, -1.0};
+        if (2 * n == 3L * M) return cd{0.0, 1.0};
         long double h = pi * (long double)n / (long double)M;
-        a[n] = cd{(double)cosl(h), (double)-sinl(h)};
-    }
-    a[0] = cd{1.0, 0.0};
-    a[M] = cd{-1.0, 0.0};
-    if (M % 2 == 0) {
-        a[M / 2] = cd{0.0, -1.0};
-        a[3 * M / 2] = cd{0.0, 1.0};
-    }
+        return cd{(double)cosl(h), (double)-sinl(h)};
+    };
+    for (long n = 0; n < 2L * M; ++n) a[n] = w2m(n);
+    const long L0 = M / R0;
+    for (int B = 0; B < 2; ++B)
+        for (long q = 0; q < R0; ++q)
+            for (long u = 0; u < L0; ++u) a[(2 + B) * (size_t)M + q * L0 + u] = w2m(u * (2 * q + B));
     Tables t;
-    TA_HIP_TRY(ctx, hipMalloc((void**)&t.tw2, sizeof(cd) * 2 * M));
-    TA_HIP_TRY(ctx, hipMemcpy(t.tw2, a.data(), sizeof(cd) * 2 * M, hipMemcpyHostToDevice));
+    TA_HIP_TRY(ctx, hipMalloc((void**)&t.tw2, sizeof(cd) * 4 * M));
+    TA_HIP_TRY(ctx, hipMemcpy(t.tw2, a.data(), sizeof(cd) * 4 * M, hipMemcpyHostToDevice));
     ctx->tables[M] = t;
     *out = t;
     return TA_OK;
@@ -331,7 +338,7 @@ int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int 
         return TA_OK;
     }
     Tables tb;
-    if ((rc = get_tables(ctx, plan->M, &tb))) return rc;
+    if ((rc = get_tables(ctx, plan->M, plan->R_first, &tb))) return rc;
     FftArgs a{};
     a.vel = d_vel;
     a.ld_row = ld_row;

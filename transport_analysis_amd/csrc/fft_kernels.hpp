@@ -26,7 +26,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "agpr_slots.inc"
-#define TA_AGPR_FENCE_HOOK() TA_AGPR_FENCE()
+namespace ta {
+template <class P>
+__device__ __forceinline__ void agpr_fence();
+}
+#define TA_AGPR_FENCE_HOOK() ::ta::agpr_fence<P>()
 #include "fft_engine.hpp"
 
 namespace ta {
@@ -170,8 +174,22 @@ __device__ __forceinline__ void static_for(F&& f) {
     }(std::make_integer_sequence<int, N>{});
 }
 
-constexpr int kAgprV = 0;      // a[0..159]: gathered pair, 4 dwords per complex value
-constexpr int kAgprAcc = 160;  // a[160..255]: accumulators, 2 dwords per bin
+// Manual slots sit at the TOP of the AGPR file: [agpr_base<P>(), 256) = gathered pair
+// (4 dwords per complex value) followed by the accumulators (2 dwords per bin).  Everything
+// below is left to the compiler: under register pressure it parks values of its own in the
+// lowest free AGPRs and cannot be told that the manual slots are live.  The fences below
+// keep its live ranges out of the manual range and tools/check_agpr.py verifies that at
+// build time.
+template <class P>
+constexpr int agpr_acc_dwords() {
+    return (StageInfo<P, P::S - 1>::K * StageInfo<P, P::S - 1>::R * 2 + 3) / 4 * 4;
+}
+template <class P>
+constexpr int agpr_base() {  // multiple of 16
+    return (256 - 4 * StageInfo<P, 0>::K * StageInfo<P, 0>::R - agpr_acc_dwords<P>()) / 16 * 16;
+}
+template <class P>
+constexpr int agpr_acc_base() { return agpr_base<P>() + 4 * StageInfo<P, 0>::K * StageInfo<P, 0>::R; }
 
 template <int I>
 __device__ __forceinline__ double ag_read_f64() {
@@ -202,14 +220,14 @@ __device__ __forceinline__ void gather_issue_range(const double* __restrict__ co
             const int tc = t < T ? t : T - 1;
             const double* p = col + (long)tc * ld_row;
             if constexpr (VEC) {
-                ag_load4<kAgprV + 4 * f>(p);
+                ag_load4<agpr_base<P>() + 4 * f>(p);
             } else {
-                ag_load2<kAgprV + 4 * f>(p);
+                ag_load2<agpr_base<P>() + 4 * f>(p);
                 if (has2) {
-                    ag_load2<kAgprV + 4 * f + 2>(p + 1);
+                    ag_load2<agpr_base<P>() + 4 * f + 2>(p + 1);
                 } else {
-                    AG<kAgprV + 4 * f + 2>::w(0u);
-                    AG<kAgprV + 4 * f + 3>::w(0u);
+                    AG<agpr_base<P>() + 4 * f + 2>::w(0u);
+                    AG<agpr_base<P>() + 4 * f + 3>::w(0u);
                 }
             }
         }
@@ -232,7 +250,7 @@ __device__ __forceinline__ void first_stage_from_agpr(cd* __restrict__ lds,
             cd w[SI::R];
             static_for<SI::R>([&](auto jj) {
                 constexpr int j = decltype(jj)::value;
-                constexpr int a = kAgprV + 4 * (m * SI::R + j);
+                constexpr int a = agpr_base<P>() + 4 * (m * SI::R + j);
                 const bool live = u + j * SI::L < T;  // rows past the end are zero padding
                 const double x = ag_read_f64<a>(), y = ag_read_f64<a + 2>();
                 w[j] = cd{live ? x : 0.0, live ? y : 0.0};
@@ -242,17 +260,18 @@ __device__ __forceinline__ void first_stage_from_agpr(cd* __restrict__ lds,
 #pragma unroll
                 for (int j = 1; j < SI::R; ++j) w[j] = cmul(w[j], tw2[j * SI::L]);
             }
-            TA_AGPR_FENCE();
+            agpr_fence<P>();
             Dft<SI::R>::run(w);
-            TA_AGPR_FENCE();
+            agpr_fence<P>();
+            // W_2M^{u(2q+B)} from the [q][u] first-stage table (coalesced)
+            const cd* __restrict__ tw0 = tw2 + (PASSB ? 3 : 2) * P::M;
 #pragma unroll
-            for (int q = PASSB ? 0 : 1; q < SI::R; ++q)
-                w[q] = cmul(w[q], tw2[u * (2 * q + (PASSB ? 1 : 0))]);
-            TA_AGPR_FENCE();
+            for (int q = PASSB ? 0 : 1; q < SI::R; ++q) w[q] = cmul(w[q], tw0[q * SI::L + u]);
+            agpr_fence<P>();
 #pragma unroll
             for (int q = 0; q < SI::R; ++q) lds[sw(u + q * SI::L)] = w[q];
         }
-        TA_AGPR_FENCE();
+        agpr_fence<P>();
         __builtin_amdgcn_sched_barrier(0);  // one butterfly's twiddle loads at a time
     });
 }
@@ -269,12 +288,12 @@ __device__ __forceinline__ void last_stage_acc_agpr(const cd* __restrict__ lds, 
             cd v[SI::R];
 #pragma unroll
             for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(u * SI::R + j)];
-            TA_AGPR_FENCE();
+            agpr_fence<P>();
             Dft<SI::R>::run(v);
-            TA_AGPR_FENCE();
+            agpr_fence<P>();
             static_for<SI::R>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
-                constexpr int a = kAgprAcc + 2 * (m * SI::R + q);
+                constexpr int a = agpr_acc_base<P>() + 2 * (m * SI::R + q);
                 ag_write_f64<a>(ag_read_f64<a>() + norm2(v[q]));
             });
         }
@@ -292,10 +311,16 @@ constexpr int acc_quads() {
     return (StageInfo<P, P::S - 1>::K * StageInfo<P, P::S - 1>::R * 2 + 3) / 4;
 }
 template <class P>
+__device__ __forceinline__ void agpr_fence() {
+    static_assert(agpr_base<P>() >= 0, "manual AGPR slots exceed the AGPR file");
+    agpr_fence_from<agpr_base<P>()>();
+}
+
+template <class P>
 __device__ __forceinline__ void acc_swap_in(const double* __restrict__ blk, int tid) {
     static_for<acc_quads<P>()>([&](auto qq) {
         constexpr int q = decltype(qq)::value;
-        ag_load4<kAgprAcc + 4 * q>(blk + 2 * ((long)q * P::NT + tid));
+        ag_load4<agpr_acc_base<P>() + 4 * q>(blk + 2 * ((long)q * P::NT + tid));
     });
 }
 template <class P>
@@ -303,7 +328,7 @@ __device__ __forceinline__ void acc_swap_out(double* __restrict__ blk, int tid) 
     asm volatile("s_nop 4" ::: "memory");  // VALU AGPR writes -> VMEM store data (no auto padding in asm)
     static_for<acc_quads<P>()>([&](auto qq) {
         constexpr int q = decltype(qq)::value;
-        ag_store4<kAgprAcc + 4 * q>(blk + 2 * ((long)q * P::NT + tid));
+        ag_store4<agpr_acc_base<P>() + 4 * q>(blk + 2 * ((long)q * P::NT + tid));
     });
 }
 
@@ -387,8 +412,8 @@ __global__ void __launch_bounds__(P::NT)
     using SL = StageInfo<P, P::S - 1>;
     using S0 = StageInfo<P, 0>;
     static_assert(P::S <= 5, "seed array sized for S <= 5");
-    static_assert(S0::K * S0::R * 4 <= kAgprAcc, "gathered pair does not fit a[0..159]");
-    static_assert(kAgprAcc + acc_quads<P>() * 4 <= 256, "accumulators do not fit a[160..255]");
+    static_assert(agpr_acc_base<P>() + acc_quads<P>() * 4 <= 256, "manual AGPR slots exceed a255");
+    static_assert(agpr_base<P>() >= 16, "leave at least a0..a15 to the compiler");
     constexpr long ACC_BLK = (long)acc_quads<P>() * 2 * P::NT;
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_prev = 0;

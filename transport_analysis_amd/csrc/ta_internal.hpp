@@ -19,7 +19,7 @@ struct FftArgs {
     long n_cols;   // accum: columns of the shard (n_atoms * D)
     long n_atoms;  // by_particle
     int D;
-    const cd* tw2;        // W_{2M}^n, n < 2M
+    const cd* tw2;        // [0,2M): W_{2M}^n; [2M,3M): first-stage table pass A; [3M,4M): pass B
     double* partial;      // accum: [nwg][2][quads*2*NT] float64, zeroed by the caller
     const double* spec;   // finalize: [2][M]
     double* lagsum;       // finalize: [T]
@@ -30,6 +30,7 @@ struct FftArgs {
 
 struct PlanEntry {
     int M, NT, S;
+    int R_first;                     // first radix: layout of the first-stage twiddle tables
     int R_last, TASKS_last, K_last;  // accumulator block per pass: [quads][NT] x 4 dwords
     size_t lds_bytes;
     hipError_t (*accum)(bool vec, int nwg, hipStream_t st, const FftArgs& a);
