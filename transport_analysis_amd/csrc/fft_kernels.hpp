@@ -303,6 +303,31 @@ __device__ __forceinline__ void last_stage_acc_agpr(const cd* __restrict__ lds, 
     });
 }
 
+// Same, accumulating into an ordinary register array (the second accumulator set).
+template <class P, class Hook>
+__device__ __forceinline__ void last_stage_acc_regs(
+    const cd* __restrict__ lds,
+    double (&acc)[StageInfo<P, P::S - 1>::K][StageInfo<P, P::S - 1>::R], int tid, Hook&& after_task) {
+    using SI = StageInfo<P, P::S - 1>;
+    static_for<SI::K>([&](auto mm) {
+        constexpr int m = decltype(mm)::value;
+        const int u = tid + m * P::NT;
+        if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
+            cd v[SI::R];
+#pragma unroll
+            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(u * SI::R + j)];
+            agpr_fence<P>();
+            Dft<SI::R>::run(v);
+            agpr_fence<P>();
+#pragma unroll
+            for (int q = 0; q < SI::R; ++q) acc[m][q] += norm2(v[q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        after_task(m);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
 // Accumulator swap between the AGPRs and this workgroup's private block in global
 // memory (L2/MALL resident), laid out [quad][thread] so a wave's accesses are contiguous;
 // a thread only ever touches its own slots, so program order is the only ordering needed.
@@ -436,8 +461,15 @@ __global__ void __launch_bounds__(P::NT)
     constexpr int MIDSLOTS = mid_slots_from<P, 1>();
     constexpr int NSLOT = MIDSLOTS + SL::K;
     constexpr int PER = (NLOAD + NSLOT - 1) / NSLOT;
-    constexpr int MID_VMEM = MIDSLOTS * PER * loads_per_elem<VEC>();  // issued before last B
     static_assert(NSLOT <= 24, "extend the TA_PIECE list");
+
+    // pass A accumulators: manual AGPR slots; pass B accumulators: ordinary registers
+    static_for<SL::K * SL::R>([&](auto dd) { ag_write_f64<agpr_acc_base<P>() + 2 * decltype(dd)::value>(0.0); });
+    double accB[SL::K][SL::R];
+#pragma unroll
+    for (int m = 0; m < SL::K; ++m)
+#pragma unroll
+        for (int q = 0; q < SL::R; ++q) accB[m][q] = 0.0;
 
     const long n_pairs = (n_cols + 1) / 2;
     long pair = slot;
@@ -454,12 +486,9 @@ __global__ void __launch_bounds__(P::NT)
         first_stage_from_agpr<P, false>(lds, tw2, T, tid);
         TA_STAMP(0)
         __syncthreads();
-        acc_swap_in<P>(blkA, tid);
         mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, no_hook);
         TA_STAMP(1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // accumulators A are in
         last_stage_acc_agpr<P>(lds, tid, no_hook);
-        acc_swap_out<P>(blkA, tid);
         TA_STAMP(2)
         __syncthreads();
         // ---- pass B: odd bins; after its first stage the parked pair is dead and is
@@ -467,12 +496,10 @@ __global__ void __launch_bounds__(P::NT)
         first_stage_from_agpr<P, true>(lds, tw2, T, tid);
         TA_STAMP(3)
         __syncthreads();
-        acc_swap_in<P>(blkB, tid);
         const long next = pair + nwg;
         const bool more = next < n_pairs;
         const double* ncol = vel + (more ? next : pair) * pair_stride;
         const bool nhas2 = 2 * (more ? next : pair) + 1 < n_cols;
-        const bool nhas2_all = VEC || nhas2;
         auto hook = [&](int slot_) {
             if (more) {
 #define TA_PIECE(S)                                                                         \
@@ -487,20 +514,22 @@ __global__ void __launch_bounds__(P::NT)
         };
         mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, hook);
         TA_STAMP(4)
-        // accumulators B were requested before the gather pieces issued so far: wait until
-        // only those (younger) gather loads are outstanding
-        // (inline asm, not the s_waitcnt builtin: the compiler's waitcnt pass deletes
-        // builtin waits it considers redundant, and it cannot see the asm-issued loads)
-        if (more && nhas2_all && MID_VMEM < 64)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MID_VMEM < 64 ? MID_VMEM : 0) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        last_stage_acc_agpr<P>(lds, tid, [&](int m) { hook(MIDSLOTS + m); });
-        acc_swap_out<P>(blkB, tid);
+        last_stage_acc_regs<P>(lds, accB, tid, [&](int m) { hook(MIDSLOTS + m); });
         TA_STAMP(5)
         __syncthreads();
         if constexpr (STAMP) st_acc[7] += 1;
         pair = next;
+    }
+    // write both accumulator sets to this workgroup's block ([quad][thread] layout)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    acc_swap_out<P>(blkA, tid);
+    {
+        double2* b = reinterpret_cast<double2*>(blkB);
+#pragma unroll
+        for (int m = 0; m < SL::K; ++m)
+#pragma unroll
+            for (int q = 0; q < SL::R; q += 2)
+                b[(long)((m * SL::R + q) / 2) * P::NT + tid] = make_double2(accB[m][q], accB[m][q + 1]);
     }
     if constexpr (STAMP) {
         if (threadIdx.x == 0)
