@@ -239,9 +239,10 @@ template <bool VEC>
 constexpr int loads_per_elem() { return VEC ? 1 : 2; }
 
 // First stage from the parked pair (read-only: pass B reads it again).
-template <class P, bool PASSB>
+template <class P, bool PASSB, class Hook>
 __device__ __forceinline__ void first_stage_from_agpr(cd* __restrict__ lds,
-                                                      const cd* __restrict__ tw2, int T, int tid) {
+                                                      const cd* __restrict__ tw2, int T, int tid,
+                                                      Hook&& after_task) {
     using SI = StageInfo<P, 0>;
     static_for<SI::K>([&](auto mm) {
         constexpr int m = decltype(mm)::value;
@@ -273,6 +274,8 @@ __device__ __forceinline__ void first_stage_from_agpr(cd* __restrict__ lds,
         }
         agpr_fence<P>();
         __builtin_amdgcn_sched_barrier(0);  // one butterfly's twiddle loads at a time
+        after_task(m);  // butterfly m's slots of the parked pair are dead from here on (pass B)
+        __builtin_amdgcn_sched_barrier(0);
     });
 }
 
@@ -459,9 +462,12 @@ __global__ void __launch_bounds__(P::NT)
 
     constexpr int NLOAD = S0::K * S0::R;
     constexpr int MIDSLOTS = mid_slots_from<P, 1>();
-    constexpr int NSLOT = MIDSLOTS + SL::K;
+    // gather slots: pass B's first-stage butterflies (each frees its own R0 registers), then
+    // the butterfly rounds of its mid and last stages
+    constexpr int NSLOT = S0::K + MIDSLOTS + SL::K;
     constexpr int PER = (NLOAD + NSLOT - 1) / NSLOT;
-    static_assert(NSLOT <= 24, "extend the TA_PIECE list");
+    static_assert(PER <= S0::R, "a first-stage slot may only refill registers already consumed");
+    static_assert(NSLOT <= 32, "extend the TA_PIECE list");
 
     // pass A accumulators: manual AGPR slots; pass B accumulators: ordinary registers
     static_for<SL::K * SL::R>([&](auto dd) { ag_write_f64<agpr_acc_base<P>() + 2 * decltype(dd)::value>(0.0); });
@@ -483,7 +489,7 @@ __global__ void __launch_bounds__(P::NT)
         asm volatile("" : "+s"(tw2), "+s"(ld_row), "+v"(tid));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the gathered pair has landed
         // ---- pass A: even bins
-        first_stage_from_agpr<P, false>(lds, tw2, T, tid);
+        first_stage_from_agpr<P, false>(lds, tw2, T, tid, no_hook);
         TA_STAMP(0)
         __syncthreads();
         mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, no_hook);
@@ -493,9 +499,6 @@ __global__ void __launch_bounds__(P::NT)
         __syncthreads();
         // ---- pass B: odd bins; after its first stage the parked pair is dead and is
         // refilled with the next pair while pass B's butterflies run
-        first_stage_from_agpr<P, true>(lds, tw2, T, tid);
-        TA_STAMP(3)
-        __syncthreads();
         const long next = pair + nwg;
         const bool more = next < n_pairs;
         const double* ncol = vel + (more ? next : pair) * pair_stride;
@@ -509,12 +512,17 @@ __global__ void __launch_bounds__(P::NT)
                 TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
                 TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)
                 TA_PIECE(18) TA_PIECE(19) TA_PIECE(20) TA_PIECE(21) TA_PIECE(22) TA_PIECE(23)
+                TA_PIECE(24) TA_PIECE(25) TA_PIECE(26) TA_PIECE(27) TA_PIECE(28) TA_PIECE(29)
+                TA_PIECE(30) TA_PIECE(31)
 #undef TA_PIECE
             }
         };
-        mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, hook);
+        first_stage_from_agpr<P, true>(lds, tw2, T, tid, hook);
+        TA_STAMP(3)
+        __syncthreads();
+        mid_stages_seeded<P, 1, S0::K>(lds, tw2, seed, tid, hook);
         TA_STAMP(4)
-        last_stage_acc_regs<P>(lds, accB, tid, [&](int m) { hook(MIDSLOTS + m); });
+        last_stage_acc_regs<P>(lds, accB, tid, [&](int m) { hook(S0::K + MIDSLOTS + m); });
         TA_STAMP(5)
         __syncthreads();
         if constexpr (STAMP) st_acc[7] += 1;
