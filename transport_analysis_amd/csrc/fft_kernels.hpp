@@ -338,6 +338,12 @@ template <class P>
 constexpr int acc_quads() {
     return (StageInfo<P, P::S - 1>::K * StageInfo<P, P::S - 1>::R * 2 + 3) / 4;
 }
+// Second accumulator set: ordinary registers for the big plans (one wave per SIMD has the
+// room); the smaller plans swap the single AGPR set through the workgroup's global block at
+// the pass boundaries instead (their extra register pressure would spill).
+template <class P>
+constexpr bool acc_b_in_regs() { return P::NT >= 256; }
+
 template <class P>
 __device__ __forceinline__ void agpr_fence() {
     static_assert(agpr_base<P>() >= 0, "manual AGPR slots exceed the AGPR file");
@@ -492,9 +498,13 @@ __global__ void __launch_bounds__(P::NT)
         first_stage_from_agpr<P, false>(lds, tw2, T, tid, no_hook);
         TA_STAMP(0)
         __syncthreads();
+        if constexpr (!acc_b_in_regs<P>()) acc_swap_in<P>(blkA, tid);
         mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, no_hook);
         TA_STAMP(1)
+        if constexpr (!acc_b_in_regs<P>())
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // accumulators A are in
         last_stage_acc_agpr<P>(lds, tid, no_hook);
+        if constexpr (!acc_b_in_regs<P>()) acc_swap_out<P>(blkA, tid);
         TA_STAMP(2)
         __syncthreads();
         // ---- pass B: odd bins; after its first stage the parked pair is dead and is
@@ -517,12 +527,45 @@ __global__ void __launch_bounds__(P::NT)
 #undef TA_PIECE
             }
         };
-        first_stage_from_agpr<P, true>(lds, tw2, T, tid, hook);
-        TA_STAMP(3)
-        __syncthreads();
-        mid_stages_seeded<P, 1, S0::K>(lds, tw2, seed, tid, hook);
-        TA_STAMP(4)
-        last_stage_acc_regs<P>(lds, accB, tid, [&](int m) { hook(S0::K + MIDSLOTS + m); });
+        if constexpr (acc_b_in_regs<P>()) {
+            first_stage_from_agpr<P, true>(lds, tw2, T, tid, hook);
+            TA_STAMP(3)
+            __syncthreads();
+            mid_stages_seeded<P, 1, S0::K>(lds, tw2, seed, tid, hook);
+            TA_STAMP(4)
+            last_stage_acc_regs<P>(lds, accB, tid, [&](int m) { hook(S0::K + MIDSLOTS + m); });
+        } else {
+            // accumulators B are requested before any gather piece, the gather starts after
+            // the first stage, and the wait before the last stage leaves exactly the gather
+            // loads issued in the mid stages outstanding (inline asm: the compiler's waitcnt
+            // pass deletes builtin waits it considers redundant and cannot see asm loads)
+            first_stage_from_agpr<P, true>(lds, tw2, T, tid, no_hook);
+            TA_STAMP(3)
+            __syncthreads();
+            acc_swap_in<P>(blkB, tid);
+            constexpr int PER2 = (NLOAD + MIDSLOTS + SL::K - 1) / (MIDSLOTS + SL::K);
+            constexpr int MID_VMEM = MIDSLOTS * PER2 * loads_per_elem<VEC>();
+            auto hook2 = [&](int slot_) {
+                if (more) {
+#define TA_PIECE(S)                                                                          \
+    if (slot_ == S)                                                                          \
+        gather_issue_range<P, VEC, (S)*PER2, ((S) + 1) * PER2>(ncol, ld_row, T, nhas2, tid);
+                    TA_PIECE(0) TA_PIECE(1) TA_PIECE(2) TA_PIECE(3) TA_PIECE(4) TA_PIECE(5)
+                    TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
+                    TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)
+                    TA_PIECE(18) TA_PIECE(19) TA_PIECE(20) TA_PIECE(21) TA_PIECE(22) TA_PIECE(23)
+#undef TA_PIECE
+                }
+            };
+            mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, hook2);
+            TA_STAMP(4)
+            if (more && (VEC || nhas2) && MID_VMEM < 64 && MIDSLOTS * PER2 <= NLOAD)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MID_VMEM < 64 ? MID_VMEM : 0) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            last_stage_acc_agpr<P>(lds, tid, [&](int m) { hook2(MIDSLOTS + m); });
+            acc_swap_out<P>(blkB, tid);
+        }
         TA_STAMP(5)
         __syncthreads();
         if constexpr (STAMP) st_acc[7] += 1;
@@ -530,8 +573,8 @@ __global__ void __launch_bounds__(P::NT)
     }
     // write both accumulator sets to this workgroup's block ([quad][thread] layout)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    acc_swap_out<P>(blkA, tid);
-    {
+    if constexpr (acc_b_in_regs<P>()) {
+        acc_swap_out<P>(blkA, tid);
         double2* b = reinterpret_cast<double2*>(blkB);
 #pragma unroll
         for (int m = 0; m < SL::K; ++m)
