@@ -86,7 +86,8 @@ int ta_stage_free(ta_ctx *ctx);
  *                   slab 0 = velocities, slab 1 = positions; `scale` is
  *                   1 / (2 * kB * mean(volumes) * temp_avg) (viscosity.py:229-231)
  * h_timeseries: (n_frames,) = mean over atoms; h_by_particle: (n_frames, n_atoms)
- * or NULL.                                                                   */
+ * or NULL.  n_frames above the largest on-chip FFT plan (10240) is evaluated by the
+ * direct correlator (same quantity: the reference asserts their equality).      */
 int ta_vacf_fft(ta_ctx *ctx, double *h_timeseries, double *h_by_particle);
 int ta_vacf_direct(ta_ctx *ctx, double *h_timeseries, double *h_by_particle);
 int ta_helfand_msd(ta_ctx *ctx, const double *h_masses, double scale, double *h_timeseries,

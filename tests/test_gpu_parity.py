@@ -135,6 +135,35 @@ def test_vacf_direct_vs_oracle_shapes(ctx, T, A, D):
     assert scale_rel_err(ts2, want_ts) < TOL
 
 
+@pytest.mark.parametrize("fft", [True, False])
+def test_vacf_long_trajectory(ctx, fft):
+    """n_frames beyond the on-chip limits (FFT plans stop at 10240, an LDS-resident column at
+    16376): the direct correlator with the column staged in global memory takes over."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(17001, 3, 3, seed=17)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
+    ts, bp = run_vacf(ctx, v, fft, True)
+    assert scale_rel_err(bp, want_bp) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL
+
+
+def test_helfand_long_trajectory(ctx):
+    from oracle import numpy_oracle as orc
+
+    T = 16500
+    v, x, m, vol = orc.synthetic_helfand(T, 2, 2, seed=18)
+    # direct oracle at this length is O(T^2) slab work: check a handful of lags exactly
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+    ts, bp = run_helfand(ctx, v, x, m, scale, True)
+    P = m[None, :, None] * v * x
+    for lag in (1, 2, 777, 8000, T - 1):
+        want = np.mean(np.square(P[:-lag] - P[lag:]).mean(axis=-1), axis=0) * scale
+        np.testing.assert_allclose(bp[lag], want, rtol=1e-11)
+        np.testing.assert_allclose(ts[lag], want.mean(), rtol=1e-11)
+    assert ts[0] == 0.0
+
+
 def test_vacf_config2_full_size(ctx):
     """BASELINE config[1]: 1000 x 10000 x 3 float64, FFT path vs the oracle."""
     from oracle import numpy_oracle as orc

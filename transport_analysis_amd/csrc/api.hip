@@ -36,7 +36,7 @@ struct ta_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     std::map<int, Tables> tables;
-    DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, f32_stage;
+    DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, f32_stage, stage_buf;
     // staging
     int64_t st_T = 0, st_A = 0;
     int st_D = 0, st_dtype = TA_F64, st_nslabs = 0;
@@ -135,22 +135,27 @@ int direct_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos,
                 const double* d_masses, int64_t T, int64_t A, int D, int64_t ld_row, double scale,
                 double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st) {
     const size_t lds = direct_lds_bytes((int)T);
-    if (lds > 160 * 1024)
-        return fail(ctx, TA_E_UNSUPPORTED,
-                    "direct correlator: n_frames exceeds the LDS-resident limit (16376 frames)");
+    // one column must be resident next to the compute units: in LDS when it fits (<= 16376
+    // frames), otherwise in an L2-resident per-workgroup staging buffer (slower, any length)
+    const bool global_stage = lds > 160 * 1024;
     const int L = direct_chunk();
     const int nchunks = (int)((T + L - 1) / L);
     const int npairs = (nchunks + 1) / 2;
     int nt = std::min(1024, std::max(64, (npairs + 63) / 64 * 64));
-    const int per_cu = direct_max_wg_per_cu(mode, nt, lds);
+    const int per_cu = direct_max_wg_per_cu(mode, nt, global_stage ? 0 : lds, global_stage);
     int64_t nwg = ctx->opt_direct_nwg > 0 ? ctx->opt_direct_nwg : (int64_t)ctx->n_cu * per_cu;
     nwg = std::max<int64_t>(1, std::min<int64_t>(nwg, A));
     int rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)nwg * T);
     if (rc) return rc;
+    double* stage_buf = nullptr;
+    if (global_stage) {
+        if ((rc = ensure(ctx, ctx->stage_buf, lds * (size_t)nwg))) return rc;
+        stage_buf = (double*)ctx->stage_buf.p;
+    }
     TA_HIP_TRY(ctx, hipMemsetAsync(ctx->ts_partial.p, 0, sizeof(double) * (size_t)nwg * T, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     TA_HIP_TRY(ctx, launch_direct(mode, d_vel, d_pos, d_masses, ld_row, (int)T, A, D, scale, d_bp,
-                                  ld_bp, (double*)ctx->ts_partial.p, (int)nwg, nt, lds, st));
+                                  ld_bp, (double*)ctx->ts_partial.p, (int)nwg, nt, lds, stage_buf, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)nwg, T, d_lagsum, st));
     return TA_OK;
@@ -216,7 +221,7 @@ int ta_ctx_destroy(ta_ctx* ctx) {
         hipFree(kv.second.tw2);
     }
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
-                      &ctx->masses, &ctx->f32_stage})
+                      &ctx->masses, &ctx->f32_stage, &ctx->stage_buf})
         if (b->p) hipFree(b->p);
     for (auto& ev : ctx->ev)
         if (ev) hipEventDestroy(ev);

@@ -63,37 +63,48 @@ template <int MODE>
 static hipError_t launch_mode(const double* vel, const double* pos, const double* masses,
                               long ld_row, int T, long n_atoms, int D, double scale,
                               double* by_particle, long ld_bp, double* ts_partial, int nwg, int nt,
-                              size_t lds_bytes, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE, kL>),
+                              size_t lds_bytes, double* stage_buf, hipStream_t st) {
+    if (stage_buf) {  // long trajectory: column staged in global memory, no LDS
+        hipLaunchKernelGGL((k_direct<MODE, kL, true>), dim3(nwg), dim3(nt), 0, st, vel, pos, masses,
+                           ld_row, T, n_atoms, D, scale, by_particle, ld_bp, ts_partial, stage_buf);
+        return hipGetLastError();
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE, kL, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_direct<MODE, kL>), dim3(nwg), dim3(nt), lds_bytes, st, vel, pos, masses,
-                       ld_row, T, n_atoms, D, scale, by_particle, ld_bp, ts_partial);
+    hipLaunchKernelGGL((k_direct<MODE, kL, false>), dim3(nwg), dim3(nt), lds_bytes, st, vel, pos,
+                       masses, ld_row, T, n_atoms, D, scale, by_particle, ld_bp, ts_partial,
+                       (double*)nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_direct(int mode, const double* vel, const double* pos, const double* masses,
                          long ld_row, int T, long n_atoms, int D, double scale,
                          double* by_particle, long ld_bp, double* ts_partial, int nwg, int nt,
-                         size_t lds_bytes, hipStream_t st) {
+                         size_t lds_bytes, double* stage_buf, hipStream_t st) {
     if (mode == MODE_VACF)
         return launch_mode<MODE_VACF>(vel, pos, masses, ld_row, T, n_atoms, D, scale, by_particle,
-                                      ld_bp, ts_partial, nwg, nt, lds_bytes, st);
+                                      ld_bp, ts_partial, nwg, nt, lds_bytes, stage_buf, st);
     return launch_mode<MODE_HELFAND>(vel, pos, masses, ld_row, T, n_atoms, D, scale, by_particle,
-                                     ld_bp, ts_partial, nwg, nt, lds_bytes, st);
+                                     ld_bp, ts_partial, nwg, nt, lds_bytes, stage_buf, st);
 }
 
-int direct_max_wg_per_cu(int mode, int nt, size_t lds_bytes) {
+int direct_max_wg_per_cu(int mode, int nt, size_t lds_bytes, bool global_stage) {
     int n = 0;
     hipError_t e;
-    if (mode == MODE_VACF) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE_VACF, kL>),
+    if (global_stage) {
+        if (mode == MODE_VACF)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE_VACF, kL, true>, nt, 0);
+        else
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE_HELFAND, kL, true>, nt, 0);
+    } else if (mode == MODE_VACF) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE_VACF, kL, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE_VACF, kL>, nt, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE_VACF, kL, false>, nt, lds_bytes);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE_HELFAND, kL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE_HELFAND, kL, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE_HELFAND, kL>, nt, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE_HELFAND, kL, false>, nt, lds_bytes);
     }
     if (e != hipSuccess || n < 1) n = 1;
     return n;

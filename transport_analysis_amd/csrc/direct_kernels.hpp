@@ -103,14 +103,19 @@ __device__ __forceinline__ void chunk_accumulate(const double* __restrict__ s, i
 }
 
 // grid.x: persistent workgroups over atoms.  ts_partial: [gridDim.x][T] (zeroed by caller).
-template <int MODE, int L>
+// GLOBAL_STAGE: trajectories too long for LDS (one column = (T/L+3)*(L+2)*8 bytes > 160 KiB)
+// stage the column in this workgroup's slice of `stage_buf` instead ([gridDim.x][n_slots]
+// float64, L1/L2 resident): same code, lower rate, no limit on n_frames.
+template <int MODE, int L, bool GLOBAL_STAGE>
 __global__ void __launch_bounds__(1024)
     k_direct(const double* __restrict__ vel, const double* __restrict__ pos,
              const double* __restrict__ masses, long ld_row, int T, long n_atoms, int D,
              double scale, double* __restrict__ by_particle, long ld_bp,
-             double* __restrict__ ts_partial) {
+             double* __restrict__ ts_partial, double* __restrict__ stage_buf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* s = reinterpret_cast<double*>(smem_raw);
+    if constexpr (GLOBAL_STAGE)
+        s = stage_buf + (long)blockIdx.x * ((long)((T + L - 1) / L + 3) * (L + 2));
     const int tid = threadIdx.x, nt = blockDim.x;
     const int nchunks = (T + L - 1) / L;
     const int npairs = (nchunks + 1) / 2;
