@@ -469,10 +469,12 @@ __global__ void __launch_bounds__(P::NT)
     constexpr int NLOAD = S0::K * S0::R;
     constexpr int MIDSLOTS = mid_slots_from<P, 1>();
     // gather slots: pass B's first-stage butterflies (each frees its own R0 registers), then
-    // the butterfly rounds of its mid and last stages
+    // the butterfly rounds of its mid and last stages.  A mid-stage round lasts about twice as
+    // long as a first- or last-stage round, so it carries twice the loads: the gather is
+    // L2-request-bound and anything issued faster than it drains only blocks the wave.
     constexpr int NSLOT = S0::K + MIDSLOTS + SL::K;
-    constexpr int PER = (NLOAD + NSLOT - 1) / NSLOT;
-    static_assert(PER <= S0::R, "a first-stage slot may only refill registers already consumed");
+    constexpr int UNIT = (NLOAD + S0::K + 2 * MIDSLOTS + SL::K - 1) / (S0::K + 2 * MIDSLOTS + SL::K);
+    static_assert(UNIT <= S0::R, "a first-stage slot may only refill registers already consumed");
     static_assert(NSLOT <= 32, "extend the TA_PIECE list");
 
     // pass A accumulators: manual AGPR slots; pass B accumulators: ordinary registers
@@ -515,9 +517,12 @@ __global__ void __launch_bounds__(P::NT)
         const bool nhas2 = 2 * (more ? next : pair) + 1 < n_cols;
         auto hook = [&](int slot_) {
             if (more) {
+#define TA_LO(S) ((S) <= S0::K ? (S)*UNIT                                                   \
+                 : (S) <= S0::K + MIDSLOTS ? S0::K * UNIT + ((S)-S0::K) * 2 * UNIT           \
+                                           : S0::K * UNIT + MIDSLOTS * 2 * UNIT + ((S)-S0::K - MIDSLOTS) * UNIT)
 #define TA_PIECE(S)                                                                         \
     if (slot_ == S)                                                                         \
-        gather_issue_range<P, VEC, (S)*PER, ((S) + 1) * PER>(ncol, ld_row, T, nhas2, tid);
+        gather_issue_range<P, VEC, TA_LO(S), TA_LO((S) + 1)>(ncol, ld_row, T, nhas2, tid);
                 TA_PIECE(0) TA_PIECE(1) TA_PIECE(2) TA_PIECE(3) TA_PIECE(4) TA_PIECE(5)
                 TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
                 TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)
@@ -525,6 +530,7 @@ __global__ void __launch_bounds__(P::NT)
                 TA_PIECE(24) TA_PIECE(25) TA_PIECE(26) TA_PIECE(27) TA_PIECE(28) TA_PIECE(29)
                 TA_PIECE(30) TA_PIECE(31)
 #undef TA_PIECE
+#undef TA_LO
             }
         };
         if constexpr (acc_b_in_regs<P>()) {
