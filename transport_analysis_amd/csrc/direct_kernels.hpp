@@ -60,7 +60,13 @@ __device__ __forceinline__ void chunk_accumulate(const double* __restrict__ s, i
     }
     const int span = T - k0;  // number of leading indices i with at least lag k0 valid
     const int nblk = (span + L - 1) / L;
-    for (int blk = 0; blk < nblk; ++blk) {
+    // blocks whose L x L tile is valid for every lag of the chunk: i + 2L - 2 + k0 < T
+    int nfull = (T - k0 - 2 * L + 1) / L + 1;
+    if (T - k0 - 2 * L + 1 < 0) nfull = 0;
+    if (nfull > nblk) nfull = nblk;
+    if (MODE == MODE_VACF) nfull = nblk;  // zero padding makes out-of-range products vanish
+    int blk = 0;
+    for (; blk < nfull; ++blk) {
         const int i = blk * L;
         double x[L], hi[L];
         lds_read_group<L>(s, i, x);
@@ -68,37 +74,38 @@ __device__ __forceinline__ void chunk_accumulate(const double* __restrict__ s, i
 #pragma unroll
         for (int a = 0; a < L; ++a) w[L + a] = hi[a];
         if (MODE == MODE_VACF) {
-            // zero padding makes out-of-range products vanish
 #pragma unroll
             for (int b = 0; b < L; ++b)
 #pragma unroll
                 for (int a = 0; a < L; ++a) acc[a] = fma(x[b], w[a + b], acc[a]);
         } else {
-            if (i + 2 * L - 1 + k0 < T) {  // block entirely valid for every lag of the chunk
 #pragma unroll
-                for (int b = 0; b < L; ++b)
+            for (int b = 0; b < L; ++b)
 #pragma unroll
-                    for (int a = 0; a < L; ++a) {
-                        const double d = x[b] - w[a + b];
-                        acc[a] = fma(d, d, acc[a]);
-                    }
-            } else {
-                // ragged end of the chunk (at most two blocks): a pair (i+b, i+b+k) only
-                // counts while i+b+k < T.  Rolled over b to keep the code small.
-#pragma unroll 1
-                for (int b = 0; b < L; ++b) {
-                    const double xb = s[lds_slot<L>(i + b)];
-#pragma unroll
-                    for (int a = 0; a < L; ++a) {
-                        const int e = i + b + k0 + a;
-                        const double d = xb - s[lds_slot<L>(e)];
-                        if (e < T) acc[a] = fma(d, d, acc[a]);
-                    }
+                for (int a = 0; a < L; ++a) {
+                    const double d = x[b] - w[a + b];
+                    acc[a] = fma(d, d, acc[a]);
                 }
-            }
         }
 #pragma unroll
         for (int a = 0; a < L; ++a) w[a] = w[L + a];
+    }
+    if (MODE == MODE_HELFAND) {
+        // ragged end of the chunk (at most two blocks): a pair (i+b, i+b+k) only counts
+        // while i+b+k < T.  Straight from the staged column, rolled over b: small code.
+        for (; blk < nblk; ++blk) {
+            const int i = blk * L;
+#pragma unroll 1
+            for (int b = 0; b < L; ++b) {
+                const double xb = s[lds_slot<L>(i + b)];
+#pragma unroll
+                for (int a = 0; a < L; ++a) {
+                    const int e = i + b + k0 + a;
+                    const double d = xb - s[lds_slot<L>(e)];
+                    if (e < T) acc[a] = fma(d, d, acc[a]);
+                }
+            }
+        }
     }
 }
 
