@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--mode", default="fft", choices=["fft", "direct", "helfand"])
     ap.add_argument("--by-particle", action="store_true",
                     help="also materialise vacf_by_particle (secondary number)")
+    ap.add_argument("--float32", action="store_true",
+                    help="direct / helfand modes: float32 products and block sums (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-atoms", type=int, default=0)
     return ap.parse_args()
@@ -108,6 +110,10 @@ def main():
 
     T, A, D = args.frames, args.atoms, args.dim
     ctx = _lib.Context(local_rank)
+    if args.float32:
+        if args.mode == "fft":
+            raise SystemExit("--float32 applies to --mode direct / helfand")
+        ctx.set_option("direct_f32", 1)
     gen = torch.Generator(device=dev)
     gen.manual_seed(20250824 + 3 + 1000 * rank)
     vel = torch.randn((T, A, D), dtype=torch.float64, device=dev, generator=gen)
@@ -196,7 +202,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": "f32 (f64 inputs and accumulators)" if args.float32 else "f64",
         "data": "synthetic",
         "config": {
             "workload": f"{'FFT' if args.mode == 'fft' else args.mode} VACF timeseries, {T} frames x {A} atoms x {D} float64 per GPU"

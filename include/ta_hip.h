@@ -121,8 +121,13 @@ int ta_last_timing(ta_ctx *ctx, float *total_ms, float *main_kernel_ms);
 /* FFT length bookkeeping for a given n_frames: *m_out = padded half-length M
  * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1).        */
 int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_stages);
-/* tuning knob (bench/experiments): number of persistent workgroups for the FFT
- * accumulate kernel; 0 = automatic. */
+/* options (key, value):
+ *   "direct_f32" 0|1 : direct correlators (ta_vacf_direct*, ta_helfand_msd*) evaluate
+ *                      products / squared differences and 32-term block sums in float32
+ *                      and add them into float64 accumulators (BASELINE configs[4]'s
+ *                      float32 path; ~1e-6 relative accuracy).  Default 0 = float64.
+ *   "fft_nwg", "direct_nwg" : persistent workgroup counts (0 = automatic);
+ *   "fft_debug" : diagnostics.                                                  */
 int ta_set_option(ta_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

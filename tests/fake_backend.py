@@ -50,5 +50,9 @@ class OracleContext:
         bp, ts = bp * scale, ts * scale
         return ts, (bp if by_particle else None)
 
+    def set_option(self, key, value):
+        self.options = getattr(self, 'options', {})
+        self.options[key] = int(value)
+
     def close(self):
         pass

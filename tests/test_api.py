@@ -204,6 +204,17 @@ def test_helfand_full_kat(backend, step_vtraj):
     assert_allclose(vh.results.timeseries, g("kat_helfand_poly_N5001_D1.npy"))
 
 
+def test_helfand_float32_switch(backend, step_vtraj):
+    """float32=True selects the library's float32 squared-difference path (configs[4])."""
+    vh = VH(step_vtraj.atoms, dim_type="xy", float32=True).run(start=10, stop=1000, step=10)
+    assert_allclose(vh.results.timeseries, g("kat_helfand_poly_10_1000_10_D2.npy"), rtol=5e-6)
+    assert vh.results.timeseries[0] == 0.0
+    if backend == "oracle-backed":
+        assert vh._ctx.options["direct_f32"] == 1
+    vh = VH(step_vtraj.atoms, dim_type="xy").run(start=10, stop=1000, step=10)
+    assert_allclose(vh.results.timeseries, g("kat_helfand_poly_10_1000_10_D2.npy"))
+
+
 @pytest.mark.parametrize("tag", ["T50_A6_D2", "T120_A17_D3"])
 def test_helfand_fit_and_volume(backend, tag):
     z = np.load(os.path.join(GOLDEN, f"rand_helfand_in_{tag}.npz"))

@@ -237,6 +237,54 @@ def test_helfand_vs_oracle_shapes(ctx, T, A, D):
     assert scale_rel_err(ts, want_ts) < TOL
 
 
+TOL_F32 = 2e-6  # float32 products / 32-term block sums, float64 accumulation
+
+
+@pytest.mark.parametrize("T,A,D", [(2, 3, 1), (17, 5, 2), (300, 21, 3), (1001, 7, 3), (5000, 3, 3)])
+def test_float32_direct_paths_vs_oracle(ctx, T, A, D):
+    """ta_set_option("direct_f32", 1): BASELINE configs[4]'s float32 Helfand path (and the
+    same switch on the direct VACF).  Tolerance: 2e-6 of the series scale."""
+    from oracle import numpy_oracle as orc
+
+    v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=4000 + T)
+    want_bp, want_ts = orc.helfand(v, x, m, vol, 300.0)
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+    ctx.set_option("direct_f32", 1)
+    try:
+        ts, bp = run_helfand(ctx, v, x, m, scale, True)
+        assert ts[0] == 0.0 and np.all(bp[0] == 0.0)
+        assert scale_rel_err(bp, want_bp) < TOL_F32
+        assert scale_rel_err(ts, want_ts) < TOL_F32
+        assert scale_rel_err(ts, want_ts) > 0.0 or T < 8  # really the float32 kernel
+        want_bp, want_ts = orc.vacf_windowed(v)
+        ts, bp = run_vacf(ctx, v, False, True)
+        assert scale_rel_err(bp, want_bp) < TOL_F32
+        assert scale_rel_err(ts, want_ts) < TOL_F32
+    finally:
+        ctx.set_option("direct_f32", 0)
+    ts, _ = run_helfand(ctx, v, x, m, scale, False)
+    assert scale_rel_err(ts, orc.helfand(v, x, m, vol, 300.0)[1]) < TOL  # switch is off again
+
+
+@pytest.mark.parametrize("T", [20000, 28000])
+def test_float32_helfand_long_trajectory(ctx, T):
+    """20000 frames (configs[4]) fits LDS as float32; 28000 takes the L2-staged variant."""
+    from oracle import numpy_oracle as orc
+
+    v, x, m, vol = orc.synthetic_helfand(T, 2, 3, seed=19)
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+    ctx.set_option("direct_f32", 1)
+    try:
+        ts, bp = run_helfand(ctx, v, x, m, scale, True)
+    finally:
+        ctx.set_option("direct_f32", 0)
+    P = m[None, :, None] * v * x
+    for lag in (1, 2, 777, 8000, T - 1):
+        want = np.mean(np.square(P[:-lag] - P[lag:]).mean(axis=-1), axis=0) * scale
+        np.testing.assert_allclose(bp[lag], want, rtol=5e-6, atol=5e-6 * scale * np.max(np.abs(P)) ** 2)
+    assert ts[0] == 0.0
+
+
 def test_f32_staging_is_lossless(ctx):
     """MDAnalysis hands out float32; staging float32 and widening on the device
     must give exactly what staging the upcast float64 gives."""

@@ -49,6 +49,8 @@ struct ta_ctx {
     int64_t opt_fft_nwg = 0;
     int64_t opt_direct_nwg = 0;
     int64_t opt_fft_debug = 0;
+    int64_t opt_direct_f32 = 0;
+    int64_t opt_direct_groups = 0;
 };
 
 namespace {
@@ -134,30 +136,44 @@ int check_shape(ta_ctx* ctx, int64_t T, int64_t A, int D, int64_t ld_row) {
 int direct_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos,
                 const double* d_masses, int64_t T, int64_t A, int D, int64_t ld_row, double scale,
                 double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st) {
-    const size_t lds = direct_lds_bytes((int)T);
+    const bool f32 = ctx->opt_direct_f32 != 0;
+    const size_t col = direct_lds_bytes((int)T, f32);  // one staged column
     // one column must be resident next to the compute units: in LDS when it fits (<= 16376
-    // frames), otherwise in an L2-resident per-workgroup staging buffer (slower, any length)
-    const bool global_stage = lds > 160 * 1024;
+    // frames in float64, <= 27296 in the float32 path), otherwise in an L2-resident
+    // per-group staging buffer (slower, any length)
+    const size_t lds_cap = 160 * 1024;
+    const bool global_stage = col > lds_cap;
     const int L = direct_chunk();
     const int nchunks = (int)((T + L - 1) / L);
     const int npairs = (nchunks + 1) / 2;
-    int nt = std::min(1024, std::max(64, (npairs + 63) / 64 * 64));
-    const int per_cu = direct_max_wg_per_cu(mode, nt, global_stage ? 0 : lds, global_stage);
+    // a column group = W waves (one thread per chunk pair); a workgroup = G groups working on
+    // G atoms at once, so that one workgroup fills a CU's 16 wave slots (G*W <= 16) and its
+    // waves are dealt evenly to the 4 SIMDs
+    const int W = std::min(16, (npairs + 63) / 64);
+    int G = 16 / W;
+    if (!global_stage) G = (int)std::min<size_t>(G, lds_cap / col);
+    if (ctx->opt_direct_groups > 0) G = (int)std::min<int64_t>(G, ctx->opt_direct_groups);
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(G, A));
+    const int gnt = W * 64, nt = G * gnt;
+    const size_t lds = global_stage ? 0 : col * (size_t)G;
+    const int per_cu = direct_max_wg_per_cu(mode, f32, nt, lds, global_stage);
     int64_t nwg = ctx->opt_direct_nwg > 0 ? ctx->opt_direct_nwg : (int64_t)ctx->n_cu * per_cu;
-    nwg = std::max<int64_t>(1, std::min<int64_t>(nwg, A));
-    int rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)nwg * T);
+    nwg = std::max<int64_t>(1, std::min<int64_t>(nwg, (A + G - 1) / G));
+    const size_t rows = (size_t)nwg * G;
+    int rc = ensure(ctx, ctx->ts_partial, sizeof(double) * rows * T);
     if (rc) return rc;
-    double* stage_buf = nullptr;
+    void* stage_buf = nullptr;
     if (global_stage) {
-        if ((rc = ensure(ctx, ctx->stage_buf, lds * (size_t)nwg))) return rc;
-        stage_buf = (double*)ctx->stage_buf.p;
+        if ((rc = ensure(ctx, ctx->stage_buf, col * rows))) return rc;
+        stage_buf = ctx->stage_buf.p;
     }
-    TA_HIP_TRY(ctx, hipMemsetAsync(ctx->ts_partial.p, 0, sizeof(double) * (size_t)nwg * T, st));
+    TA_HIP_TRY(ctx, hipMemsetAsync(ctx->ts_partial.p, 0, sizeof(double) * rows * T, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    TA_HIP_TRY(ctx, launch_direct(mode, d_vel, d_pos, d_masses, ld_row, (int)T, A, D, scale, d_bp,
-                                  ld_bp, (double*)ctx->ts_partial.p, (int)nwg, nt, lds, stage_buf, st));
+    TA_HIP_TRY(ctx, launch_direct(mode, f32, d_vel, d_pos, d_masses, ld_row, (int)T, A, D, scale, d_bp,
+                                  ld_bp, (double*)ctx->ts_partial.p, (int)nwg, nt, lds, stage_buf,
+                                  gnt, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-    TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)nwg, T, d_lagsum, st));
+    TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)rows, T, d_lagsum, st));
     return TA_OK;
 }
 
@@ -235,6 +251,8 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     if (!strcmp(key, "fft_nwg")) ctx->opt_fft_nwg = value;
     else if (!strcmp(key, "direct_nwg")) ctx->opt_direct_nwg = value;
     else if (!strcmp(key, "fft_debug")) ctx->opt_fft_debug = value;
+    else if (!strcmp(key, "direct_f32")) ctx->opt_direct_f32 = value;
+    else if (!strcmp(key, "direct_groups")) ctx->opt_direct_groups = value;
     else return fail(ctx, TA_E_INVALID, std::string("unknown option ") + key);
     return TA_OK;
 }

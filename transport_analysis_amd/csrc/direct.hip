@@ -54,60 +54,71 @@ constexpr int kL = 8;
 
 int direct_chunk() { return kL; }
 
-size_t direct_lds_bytes(int T) {
+size_t direct_lds_bytes(int T, bool f32) {
     const int nchunks = (T + kL - 1) / kL;
-    return (size_t)(nchunks + 3) * (kL + 2) * sizeof(double);
+    return f32 ? (size_t)(nchunks + 3) * group_stride<kL, float>() * sizeof(float)
+               : (size_t)(nchunks + 3) * group_stride<kL, double>() * sizeof(double);
 }
 
-template <int MODE>
+template <int MODE, typename Real>
 static hipError_t launch_mode(const double* vel, const double* pos, const double* masses,
                               long ld_row, int T, long n_atoms, int D, double scale,
                               double* by_particle, long ld_bp, double* ts_partial, int nwg, int nt,
-                              size_t lds_bytes, double* stage_buf, hipStream_t st) {
+                              size_t lds_bytes, void* stage_buf, int gnt, hipStream_t st) {
     if (stage_buf) {  // long trajectory: column staged in global memory, no LDS
-        hipLaunchKernelGGL((k_direct<MODE, kL, true>), dim3(nwg), dim3(nt), 0, st, vel, pos, masses,
-                           ld_row, T, n_atoms, D, scale, by_particle, ld_bp, ts_partial, stage_buf);
+        hipLaunchKernelGGL((k_direct<MODE, kL, true, Real>), dim3(nwg), dim3(nt), 0, st, vel, pos,
+                           masses, ld_row, T, n_atoms, D, scale, by_particle, ld_bp, ts_partial,
+                           stage_buf, gnt);
         return hipGetLastError();
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE, kL, false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE, kL, false, Real>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_direct<MODE, kL, false>), dim3(nwg), dim3(nt), lds_bytes, st, vel, pos,
-                       masses, ld_row, T, n_atoms, D, scale, by_particle, ld_bp, ts_partial,
-                       (double*)nullptr);
+    hipLaunchKernelGGL((k_direct<MODE, kL, false, Real>), dim3(nwg), dim3(nt), lds_bytes, st, vel,
+                       pos, masses, ld_row, T, n_atoms, D, scale, by_particle, ld_bp, ts_partial,
+                       (void*)nullptr, gnt);
     return hipGetLastError();
 }
 
-hipError_t launch_direct(int mode, const double* vel, const double* pos, const double* masses,
-                         long ld_row, int T, long n_atoms, int D, double scale,
-                         double* by_particle, long ld_bp, double* ts_partial, int nwg, int nt,
-                         size_t lds_bytes, double* stage_buf, hipStream_t st) {
-    if (mode == MODE_VACF)
-        return launch_mode<MODE_VACF>(vel, pos, masses, ld_row, T, n_atoms, D, scale, by_particle,
-                                      ld_bp, ts_partial, nwg, nt, lds_bytes, stage_buf, st);
-    return launch_mode<MODE_HELFAND>(vel, pos, masses, ld_row, T, n_atoms, D, scale, by_particle,
-                                     ld_bp, ts_partial, nwg, nt, lds_bytes, stage_buf, st);
+hipError_t launch_direct(int mode, bool f32, const double* vel, const double* pos,
+                         const double* masses, long ld_row, int T, long n_atoms, int D,
+                         double scale, double* by_particle, long ld_bp, double* ts_partial, int nwg,
+                         int nt, size_t lds_bytes, void* stage_buf, int gnt, hipStream_t st) {
+#define TA_GO(M, R)                                                                              \
+    return launch_mode<M, R>(vel, pos, masses, ld_row, T, n_atoms, D, scale, by_particle, ld_bp, \
+                             ts_partial, nwg, nt, lds_bytes, stage_buf, gnt, st)
+    if (mode == MODE_VACF) {
+        if (f32) TA_GO(MODE_VACF, float);
+        TA_GO(MODE_VACF, double);
+    }
+    if (f32) TA_GO(MODE_HELFAND, float);
+    TA_GO(MODE_HELFAND, double);
+#undef TA_GO
 }
 
-int direct_max_wg_per_cu(int mode, int nt, size_t lds_bytes, bool global_stage) {
+template <int MODE, bool GS, typename Real>
+static int occ(int nt, size_t lds_bytes) {
     int n = 0;
-    hipError_t e;
-    if (global_stage) {
-        if (mode == MODE_VACF)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE_VACF, kL, true>, nt, 0);
-        else
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE_HELFAND, kL, true>, nt, 0);
-    } else if (mode == MODE_VACF) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE_VACF, kL, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE_VACF, kL, false>, nt, lds_bytes);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE_HELFAND, kL, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE_HELFAND, kL, false>, nt, lds_bytes);
+    if (!GS)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE, kL, GS, Real>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE, kL, GS, Real>, nt,
+                                                                GS ? 0 : lds_bytes);
+    return (e != hipSuccess || n < 1) ? 1 : n;
+}
+
+int direct_max_wg_per_cu(int mode, bool f32, int nt, size_t lds_bytes, bool global_stage) {
+    const int key = (mode == MODE_VACF ? 0 : 4) + (f32 ? 2 : 0) + (global_stage ? 1 : 0);
+    switch (key) {
+        case 0: return occ<MODE_VACF, false, double>(nt, lds_bytes);
+        case 1: return occ<MODE_VACF, true, double>(nt, lds_bytes);
+        case 2: return occ<MODE_VACF, false, float>(nt, lds_bytes);
+        case 3: return occ<MODE_VACF, true, float>(nt, lds_bytes);
+        case 4: return occ<MODE_HELFAND, false, double>(nt, lds_bytes);
+        case 5: return occ<MODE_HELFAND, true, double>(nt, lds_bytes);
+        case 6: return occ<MODE_HELFAND, false, float>(nt, lds_bytes);
+        default: return occ<MODE_HELFAND, true, float>(nt, lds_bytes);
     }
-    if (e != hipSuccess || n < 1) n = 1;
-    return n;
 }
 
 hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,

@@ -27,16 +27,20 @@ namespace ta {
 
 enum { MODE_VACF = 0, MODE_HELFAND = 1 };
 
-template <int L>
-__device__ __forceinline__ int lds_slot(int e) {  // element index -> f64 slot
-    return (e / L) * (L + 2) + (e % L);
+// Staged column layout: groups of L values followed by 16 bytes of padding.
+template <int L, typename Real>
+constexpr int group_stride() { return L + 16 / (int)sizeof(Real); }
+
+template <int L, typename Real>
+__device__ __forceinline__ int lds_slot(int e) {  // element index -> slot
+    return (e / L) * group_stride<L, Real>() + (e % L);
 }
 
 template <int L>
 __device__ __forceinline__ void lds_read_group(const double* __restrict__ s, int e,
                                                double (&out)[L]) {
     // e is a multiple of L: one padded group, 16-byte aligned
-    const double2* p = reinterpret_cast<const double2*>(s + (e / L) * (L + 2));
+    const double2* p = reinterpret_cast<const double2*>(s + (e / L) * group_stride<L, double>());
 #pragma unroll
     for (int i = 0; i < L / 2; ++i) {
         double2 t = p[i];
@@ -45,19 +49,28 @@ __device__ __forceinline__ void lds_read_group(const double* __restrict__ s, int
     }
 }
 
+template <int L>
+__device__ __forceinline__ void lds_read_group(const float* __restrict__ s, int e,
+                                               float (&out)[L]) {
+    const float4* p = reinterpret_cast<const float4*>(s + (e / L) * group_stride<L, float>());
+#pragma unroll
+    for (int i = 0; i < L / 4; ++i) {
+        float4 t = p[i];
+        out[4 * i] = t.x;
+        out[4 * i + 1] = t.y;
+        out[4 * i + 2] = t.z;
+        out[4 * i + 3] = t.w;
+    }
+}
+
 // Accumulate one chunk (lags k0..k0+L-1) of one staged column into acc[L].
-// n_valid = number of staged samples (T); the LDS copy is zero-padded beyond it.
+// The staged copy is zero-padded beyond T.
 template <int MODE, int L>
 __device__ __forceinline__ void chunk_accumulate(const double* __restrict__ s, int T, int k0,
                                                  double (&acc)[L]) {
-    // window w[0..2L): series values at i+k0 .. i+k0+2L-1 ; x[0..L): values at i..i+L-1
-    double w[2 * L];
-    {
-        double lo[L];
-        lds_read_group<L>(s, k0, lo);
-#pragma unroll
-        for (int a = 0; a < L; ++a) w[a] = lo[a];
-    }
+    // per block: x[0..L) = values at i..i+L-1 and the window lo ++ hi = values at
+    // i+k0 .. i+k0+2L-1.  Blocks go two at a time so that the window halves swap roles
+    // instead of being copied.
     const int span = T - k0;  // number of leading indices i with at least lag k0 valid
     const int nblk = (span + L - 1) / L;
     // blocks whose L x L tile is valid for every lag of the chunk: i + 2L - 2 + k0 < T
@@ -65,31 +78,35 @@ __device__ __forceinline__ void chunk_accumulate(const double* __restrict__ s, i
     if (T - k0 - 2 * L + 1 < 0) nfull = 0;
     if (nfull > nblk) nfull = nblk;
     if (MODE == MODE_VACF) nfull = nblk;  // zero padding makes out-of-range products vanish
-    int blk = 0;
-    for (; blk < nfull; ++blk) {
-        const int i = blk * L;
-        double x[L], hi[L];
-        lds_read_group<L>(s, i, x);
-        lds_read_group<L>(s, i + k0 + L, hi);
-#pragma unroll
-        for (int a = 0; a < L; ++a) w[L + a] = hi[a];
-        if (MODE == MODE_VACF) {
-#pragma unroll
-            for (int b = 0; b < L; ++b)
-#pragma unroll
-                for (int a = 0; a < L; ++a) acc[a] = fma(x[b], w[a + b], acc[a]);
-        } else {
-#pragma unroll
-            for (int b = 0; b < L; ++b)
-#pragma unroll
-                for (int a = 0; a < L; ++a) {
-                    const double d = x[b] - w[a + b];
-                    acc[a] = fma(d, d, acc[a]);
-                }
-        }
-#pragma unroll
-        for (int a = 0; a < L; ++a) w[a] = w[L + a];
+#define TA_TILE_F64(LO, HI)                                                          \
+    _Pragma("unroll") for (int b = 0; b < L; ++b) _Pragma("unroll") for (int a = 0; a < L; ++a) { \
+        const double wv = (a + b < L) ? LO[(a + b) % L] : HI[(a + b) % L];           \
+        if (MODE == MODE_VACF) {                                                     \
+            acc[a] = fma(x[b], wv, acc[a]);                                          \
+        } else {                                                                     \
+            const double dd = x[b] - wv;                                             \
+            acc[a] = fma(dd, dd, acc[a]);                                            \
+        }                                                                            \
     }
+    double wa[L], wb[L], x[L];
+    lds_read_group<L>(s, k0, wa);
+    int blk = 0;
+    for (; blk + 1 < nfull; blk += 2) {
+        const int i = blk * L;
+        lds_read_group<L>(s, i, x);
+        lds_read_group<L>(s, i + k0 + L, wb);
+        TA_TILE_F64(wa, wb)
+        lds_read_group<L>(s, i + L, x);
+        lds_read_group<L>(s, i + k0 + 2 * L, wa);
+        TA_TILE_F64(wb, wa)
+    }
+    if (blk < nfull) {
+        lds_read_group<L>(s, blk * L, x);
+        lds_read_group<L>(s, blk * L + k0 + L, wb);
+        TA_TILE_F64(wa, wb)
+        ++blk;
+    }
+#undef TA_TILE_F64
     if (MODE == MODE_HELFAND) {
         // ragged end of the chunk (at most two blocks): a pair (i+b, i+b+k) only counts
         // while i+b+k < T.  Straight from the staged column, rolled over b: small code.
@@ -97,11 +114,11 @@ __device__ __forceinline__ void chunk_accumulate(const double* __restrict__ s, i
             const int i = blk * L;
 #pragma unroll 1
             for (int b = 0; b < L; ++b) {
-                const double xb = s[lds_slot<L>(i + b)];
+                const double xb = s[lds_slot<L, double>(i + b)];
 #pragma unroll
                 for (int a = 0; a < L; ++a) {
                     const int e = i + b + k0 + a;
-                    const double d = xb - s[lds_slot<L>(e)];
+                    const double d = xb - s[lds_slot<L, double>(e)];
                     if (e < T) acc[a] = fma(d, d, acc[a]);
                 }
             }
@@ -109,32 +126,144 @@ __device__ __forceinline__ void chunk_accumulate(const double* __restrict__ s, i
     }
 }
 
-// grid.x: persistent workgroups over atoms.  ts_partial: [gridDim.x][T] (zeroed by caller).
-// GLOBAL_STAGE: trajectories too long for LDS (one column = (T/L+3)*(L+2)*8 bytes > 160 KiB)
-// stage the column in this workgroup's slice of `stage_buf` instead ([gridDim.x][n_slots]
-// float64, L1/L2 resident): same code, lower rate, no limit on n_frames.
-template <int MODE, int L, bool GLOBAL_STAGE>
+// ---- float32 path: packed math (v_pk_add_f32 / v_pk_fma_f32, two float32 per lane) ------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void lds_read_pairs(const float* __restrict__ s, int e,
+                                               v2f (&out)[4]) {
+    // e is a multiple of 8: one padded group of 8 floats as 4 register pairs
+    const float4* p = reinterpret_cast<const float4*>(s + (e / 8) * group_stride<8, float>());
+    const float4 t0 = p[0], t1 = p[1];
+    out[0] = v2f{t0.x, t0.y};
+    out[1] = v2f{t0.z, t0.w};
+    out[2] = v2f{t1.x, t1.y};
+    out[3] = v2f{t1.z, t1.w};
+}
+
+// One 8 x 8 tile on register pairs.  X[bp] = (x[2bp], x[2bp+1]); the window w[0..16) is lo ++ hi
+// as natural pairs E[k] = (w[2k], w[2k+1]); odd lags need O[k] = (w[2k+1], w[2k+2]).  part[a]
+// holds two half-sums of lag a (even and odd b), added together at the flush.
+template <int MODE>
+__device__ __forceinline__ void tile_f32(const v2f (&X)[4], const v2f (&lo)[4],
+                                         const v2f (&hi)[4], v2f (&part)[8]) {
+    v2f E[8], O[7];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        E[k] = lo[k];
+        E[4 + k] = hi[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) O[k] = __builtin_shufflevector(E[k], E[k + 1], 1, 2);
+#pragma unroll
+    for (int bp = 0; bp < 4; ++bp)
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const int idx = a + 2 * bp;
+            const v2f W = (a & 1) ? O[(idx - 1) / 2] : E[idx / 2];
+            if (MODE == MODE_VACF) {
+                part[a] = __builtin_elementwise_fma(X[bp], W, part[a]);
+            } else {
+                const v2f d = X[bp] - W;
+                part[a] = __builtin_elementwise_fma(d, d, part[a]);
+            }
+        }
+}
+
+// float32 chunk: products / squared differences and 64-term sums per lag in float32 (two
+// packed 32-term half-sums), added into the float64 accumulators every 8 blocks.  Blocks go
+// two at a time so the window halves swap roles instead of being copied.
+template <int MODE, int L>
+__device__ __forceinline__ void chunk_accumulate(const float* __restrict__ s, int T, int k0,
+                                                 double (&acc)[L]) {
+    static_assert(L == 8, "packed float32 tile is written for 8-lag chunks");
+    const int span = T - k0;
+    const int nblk = (span + L - 1) / L;
+    int nfull = (T - k0 - 2 * L + 1) / L + 1;
+    if (T - k0 - 2 * L + 1 < 0) nfull = 0;
+    if (nfull > nblk) nfull = nblk;
+    if (MODE == MODE_VACF) nfull = nblk;
+    v2f part[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) part[a] = v2f{0.f, 0.f};
+    auto flush = [&]() {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            acc[a] += (double)(part[a].x + part[a].y);
+            part[a] = v2f{0.f, 0.f};
+        }
+    };
+    v2f A[4], B[4], X[4];
+    lds_read_pairs(s, k0, A);
+    int blk = 0;
+    for (; blk + 1 < nfull; blk += 2) {
+        const int i = blk * L;
+        lds_read_pairs(s, i, X);
+        lds_read_pairs(s, i + k0 + L, B);
+        tile_f32<MODE>(X, A, B, part);
+        lds_read_pairs(s, i + L, X);
+        lds_read_pairs(s, i + k0 + 2 * L, A);
+        tile_f32<MODE>(X, B, A, part);
+        if (((blk + 2) & 7) == 0) flush();
+    }
+    if (blk < nfull) {
+        lds_read_pairs(s, blk * L, X);
+        lds_read_pairs(s, blk * L + k0 + L, B);
+        tile_f32<MODE>(X, A, B, part);
+        ++blk;
+    }
+    flush();
+    if (MODE == MODE_HELFAND) {
+        for (; blk < nblk; ++blk) {  // ragged end, as in the float64 version
+            const int i = blk * L;
+#pragma unroll 1
+            for (int b = 0; b < L; ++b) {
+                const float xb = s[lds_slot<L, float>(i + b)];
+#pragma unroll
+                for (int a = 0; a < L; ++a) {
+                    const int e = i + b + k0 + a;
+                    const float d = xb - s[lds_slot<L, float>(e)];
+                    if (e < T) acc[a] = fma((double)d, (double)d, acc[a]);
+                }
+            }
+        }
+    }
+}
+
+// grid.x: persistent workgroups.  A workgroup is n_groups = blockDim.x / gnt column groups of
+// gnt threads; group g of workgroup b works on atoms (b*n_groups + g) + k*gridDim.x*n_groups,
+// each group with its own staged column, so that a compute unit's 16 wave slots are filled by
+// ONE workgroup whose waves the hardware spreads evenly over the four SIMDs.
+// ts_partial: [gridDim.x * n_groups][T] (zeroed by caller).
+// GLOBAL_STAGE: trajectories too long for LDS (one column = (T/L+3) padded groups > 160 KiB)
+// stage the column in the group's slice of `stage_buf` instead ([gridDim.x * n_groups][n_slots],
+// L1/L2 resident): same code, lower rate, no limit on n_frames.
+template <int MODE, int L, bool GLOBAL_STAGE, typename Real>
 __global__ void __launch_bounds__(1024)
     k_direct(const double* __restrict__ vel, const double* __restrict__ pos,
              const double* __restrict__ masses, long ld_row, int T, long n_atoms, int D,
              double scale, double* __restrict__ by_particle, long ld_bp,
-             double* __restrict__ ts_partial, double* __restrict__ stage_buf) {
+             double* __restrict__ ts_partial, void* __restrict__ stage_buf, int gnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* s = reinterpret_cast<double*>(smem_raw);
-    if constexpr (GLOBAL_STAGE)
-        s = stage_buf + (long)blockIdx.x * ((long)((T + L - 1) / L + 3) * (L + 2));
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int n_groups = blockDim.x / gnt;
+    const int grp = threadIdx.x / gnt, tid = threadIdx.x - grp * gnt, nt = gnt;
     const int nchunks = (T + L - 1) / L;
     const int npairs = (nchunks + 1) / 2;
+    const long col_slots = (long)(nchunks + 3) * group_stride<L, Real>();
+    Real* s = reinterpret_cast<Real*>(smem_raw) + grp * col_slots;
+    if constexpr (GLOBAL_STAGE)
+        s = reinterpret_cast<Real*>(stage_buf) + ((long)blockIdx.x * n_groups + grp) * col_slots;
     // staged length: up to the end of the window any chunk can touch, zero padded
     const int n_stage = (nchunks + 3) * L;
-    double* ts_out = ts_partial + (long)blockIdx.x * T;
+    double* ts_out = ts_partial + ((long)blockIdx.x * n_groups + grp) * T;
 
-    for (long atom = blockIdx.x; atom < n_atoms; atom += gridDim.x) {
-        const double mass = (MODE == MODE_HELFAND) ? masses[atom] : 1.0;
+    for (long atom0 = (long)blockIdx.x * n_groups; atom0 < n_atoms;
+         atom0 += (long)gridDim.x * n_groups) {
+        const long atom = atom0 + grp;
+        const bool valid = atom < n_atoms;  // idle groups still take part in the barriers
+        const double mass = (MODE == MODE_HELFAND && valid) ? masses[atom] : 1.0;
         for (int pp0 = 0; pp0 < npairs; pp0 += nt) {
             const int pp = pp0 + tid;
-            const bool active = pp < npairs;
+            const bool active = valid && pp < npairs;
             const int j1 = pp, j2 = nchunks - 1 - pp;
             double acc1[L], acc2[L];
 #pragma unroll
@@ -143,12 +272,12 @@ __global__ void __launch_bounds__(1024)
                 __syncthreads();  // previous column fully consumed
                 for (int e = tid; e < n_stage; e += nt) {
                     double val = 0.0;
-                    if (e < T) {
+                    if (valid && e < T) {
                         const long g = (long)e * ld_row + atom * D + d;
                         val = vel[g];
                         if (MODE == MODE_HELFAND) val = (mass * val) * pos[g];
                     }
-                    s[lds_slot<L>(e)] = val;
+                    s[lds_slot<L, Real>(e)] = (Real)val;
                 }
                 __syncthreads();
                 if (active) {

@@ -28,6 +28,10 @@ class ViscosityHelfand(AnalysisBase):
     by_particle : bool, keyword-only, default True — materialise
         ``results.visc_by_particle``; ``False`` computes the timeseries only.
     device : int, keyword-only — GPU index (default ``$TA_AMD_DEVICE`` or 0).
+    float32 : bool, keyword-only, default False — form the mass-weighted
+        velocity-position products in float64, then evaluate the squared differences and
+        their block sums in float32 (accumulated into float64): ~1e-6 relative accuracy
+        instead of 1e-10, about twice the throughput.
 
     Attributes
     ----------
@@ -41,6 +45,7 @@ class ViscosityHelfand(AnalysisBase):
                  **kwargs):
         self._want_by_particle = bool(kwargs.pop("by_particle", True))
         self._device = int(kwargs.pop("device", os.environ.get("TA_AMD_DEVICE", 0)))
+        self._float32 = bool(kwargs.pop("float32", False))
         super().__init__(atomgroup.universe.trajectory, **kwargs)
 
         if isinstance(atomgroup, UpdatingAtomGroup):
@@ -61,6 +66,7 @@ class ViscosityHelfand(AnalysisBase):
         """Two pinned slabs (velocities, positions) + volumes + masses (:111-142)."""
         if self._ctx is None:
             self._ctx = _lib.Context(self._device)
+        self._ctx.set_option("direct_f32", int(self._float32))
         self._velocities, self._positions = self._ctx.stage_alloc(
             self.n_frames, self.n_particles, self.dim_fac, n_slabs=2)
         self._volumes = np.zeros(self.n_frames)
