@@ -5,10 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from transport_analysis_amd import _lib
 
-def run(mode, T, A, D, nwg, f32):
+def run(mode, T, A, D, nwg, f32, chunk=0):
     ctx = _lib.Context(0)
     ctx.set_option("direct_nwg", nwg)
     ctx.set_option("direct_f32", f32)
+    ctx.set_option("direct_chunk", chunk)
     vel = torch.randn((T, A, D), dtype=torch.float64, device="cuda")
     pos = 30 + 0.002 * torch.cumsum(vel, 0) if mode == "helfand" else None
     m = torch.ones(A, dtype=torch.float64, device="cuda")
@@ -26,9 +27,9 @@ def run(mode, T, A, D, nwg, f32):
 if __name__ == "__main__":
     for mode, T, A in (("vacf", 5000, 12800), ("helfand", 5000, 5120), ("helfand", 20000, 2048), ("vacf", 1000, 30000), ("vacf", 10000, 4096)):
         for f32 in (0, 1):
-            for nwg in (0,):
+            for chunk in (8, 10, 0):
                 try:
-                    ms = run(mode, T, A, 3, nwg, f32)
+                    ms = run(mode, T, A, 3, 0, f32, chunk)
                 except Exception as e:
                     ms = float("nan")
-                print(f"{mode} T={T} A={A} f32={f32} nwg={nwg}: {ms:.2f} ms", flush=True)
+                print(f"{mode} T={T} A={A} f32={f32} chunk={chunk}: {ms:.2f} ms", flush=True)

@@ -51,6 +51,7 @@ struct ta_ctx {
     int64_t opt_fft_debug = 0;
     int64_t opt_direct_f32 = 0;
     int64_t opt_direct_groups = 0;
+    int64_t opt_direct_chunk = 0;
 };
 
 namespace {
@@ -137,26 +138,42 @@ int direct_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos,
                 const double* d_masses, int64_t T, int64_t A, int D, int64_t ld_row, double scale,
                 double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st) {
     const bool f32 = ctx->opt_direct_f32 != 0;
-    const size_t col = direct_lds_bytes((int)T, f32);  // one staged column
-    // one column must be resident next to the compute units: in LDS when it fits (<= 16376
-    // frames in float64, <= 27296 in the float32 path), otherwise in an L2-resident
-    // per-group staging buffer (slower, any length)
+    // Shape of the launch.  A thread owns one chunk pair (2L lags); a column group = W waves;
+    // a workgroup = G groups working on G atoms at once, so that ONE workgroup fills a CU's
+    // 16 wave slots (G*W <= 16) and its waves are dealt evenly to the 4 SIMDs.  The column
+    // must be resident next to the compute units: in LDS when it fits (float64: <= 16376
+    // frames, float32: <= 27296), otherwise in an L2-resident per-group staging buffer
+    // (slower, any length).  L (8 or 10 lags per chunk) is the one that wastes fewer lanes
+    // and SIMD slots for this n_frames.
     const size_t lds_cap = 160 * 1024;
-    const bool global_stage = col > lds_cap;
-    const int L = direct_chunk();
-    const int nchunks = (int)((T + L - 1) / L);
-    const int npairs = (nchunks + 1) / 2;
-    // a column group = W waves (one thread per chunk pair); a workgroup = G groups working on
-    // G atoms at once, so that one workgroup fills a CU's 16 wave slots (G*W <= 16) and its
-    // waves are dealt evenly to the 4 SIMDs
-    const int W = std::min(16, (npairs + 63) / 64);
-    int G = 16 / W;
-    if (!global_stage) G = (int)std::min<size_t>(G, lds_cap / col);
-    if (ctx->opt_direct_groups > 0) G = (int)std::min<int64_t>(G, ctx->opt_direct_groups);
-    G = (int)std::max<int64_t>(1, std::min<int64_t>(G, A));
+    struct Shape { int L, W, G; size_t col; bool gs; double eff; } best{0, 0, 0, 0, false, -1.0};
+    for (int L : {8, 10}) {
+        if (ctx->opt_direct_chunk > 0 && L != ctx->opt_direct_chunk) continue;
+        if (!direct_chunk_supported(L)) continue;
+        Shape c;
+        c.L = L;
+        c.col = direct_lds_bytes((int)T, f32, L);
+        c.gs = c.col > lds_cap;
+        const int npairs = ((int)((T + L - 1) / L) + 1) / 2;
+        c.W = std::min(16, (npairs + 63) / 64);
+        c.G = 16 / c.W;
+        if (!c.gs) c.G = (int)std::min<size_t>(c.G, lds_cap / c.col);
+        if (ctx->opt_direct_groups > 0) c.G = (int)std::min<int64_t>(c.G, ctx->opt_direct_groups);
+        c.G = (int)std::max<int64_t>(1, std::min<int64_t>(c.G, A));
+        const int rounds = (npairs + c.W * 64 - 1) / (c.W * 64);
+        const int waves = c.G * c.W;
+        c.eff = (double)npairs / ((double)rounds * c.W * 64) *   // active lanes
+                (double)waves / (4.0 * ((waves + 3) / 4)) *      // SIMD balance
+                (1.0 - 0.6 / L);                                 // per-tile overhead
+        if (c.eff > best.eff) best = c;
+    }
+    if (best.eff < 0) return fail(ctx, TA_E_INVALID, "direct_chunk option: unsupported chunk size");
+    const int L = best.L, W = best.W, G = best.G;
+    const size_t col = best.col;
+    const bool global_stage = best.gs;
     const int gnt = W * 64, nt = G * gnt;
     const size_t lds = global_stage ? 0 : col * (size_t)G;
-    const int per_cu = direct_max_wg_per_cu(mode, f32, nt, lds, global_stage);
+    const int per_cu = direct_max_wg_per_cu(mode, f32, L, nt, lds, global_stage);
     int64_t nwg = ctx->opt_direct_nwg > 0 ? ctx->opt_direct_nwg : (int64_t)ctx->n_cu * per_cu;
     nwg = std::max<int64_t>(1, std::min<int64_t>(nwg, (A + G - 1) / G));
     const size_t rows = (size_t)nwg * G;
@@ -169,7 +186,7 @@ int direct_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos,
     }
     TA_HIP_TRY(ctx, hipMemsetAsync(ctx->ts_partial.p, 0, sizeof(double) * rows * T, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    TA_HIP_TRY(ctx, launch_direct(mode, f32, d_vel, d_pos, d_masses, ld_row, (int)T, A, D, scale, d_bp,
+    TA_HIP_TRY(ctx, launch_direct(mode, f32, L, d_vel, d_pos, d_masses, ld_row, (int)T, A, D, scale, d_bp,
                                   ld_bp, (double*)ctx->ts_partial.p, (int)nwg, nt, lds, stage_buf,
                                   gnt, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
@@ -253,6 +270,7 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "fft_debug")) ctx->opt_fft_debug = value;
     else if (!strcmp(key, "direct_f32")) ctx->opt_direct_f32 = value;
     else if (!strcmp(key, "direct_groups")) ctx->opt_direct_groups = value;
+    else if (!strcmp(key, "direct_chunk")) ctx->opt_direct_chunk = value;
     else return fail(ctx, TA_E_INVALID, std::string("unknown option ") + key);
     return TA_OK;
 }

@@ -50,75 +50,64 @@ hipError_t launch_sum_partials_perm(const double* partial, int n_parts, int M, i
     return hipGetLastError();
 }
 
-constexpr int kL = 8;
+// compiled chunk sizes (lags per chunk); the launcher picks the one that fills the CU best
+#define TA_DIRECT_CHUNKS(X) X(8) X(10)
 
-int direct_chunk() { return kL; }
-
-size_t direct_lds_bytes(int T, bool f32) {
-    const int nchunks = (T + kL - 1) / kL;
-    return f32 ? (size_t)(nchunks + 3) * group_stride<kL, float>() * sizeof(float)
-               : (size_t)(nchunks + 3) * group_stride<kL, double>() * sizeof(double);
+size_t direct_lds_bytes(int T, bool f32, int L) {
+    const int nchunks = (T + L - 1) / L;
+    return (size_t)(nchunks + 3) * group_stride_dwords(L, f32 ? 1 : 2) * 4;
 }
 
-template <int MODE, typename Real>
-static hipError_t launch_mode(const double* vel, const double* pos, const double* masses,
-                              long ld_row, int T, long n_atoms, int D, double scale,
-                              double* by_particle, long ld_bp, double* ts_partial, int nwg, int nt,
-                              size_t lds_bytes, void* stage_buf, int gnt, hipStream_t st) {
-    if (stage_buf) {  // long trajectory: column staged in global memory, no LDS
-        hipLaunchKernelGGL((k_direct<MODE, kL, true, Real>), dim3(nwg), dim3(nt), 0, st, vel, pos,
-                           masses, ld_row, T, n_atoms, D, scale, by_particle, ld_bp, ts_partial,
-                           stage_buf, gnt);
-        return hipGetLastError();
+static const void* direct_kernel(int mode, bool f32, int L, bool gs) {
+#define TA_K(M, LL, GS, R) reinterpret_cast<const void*>(k_direct<M, LL, GS, R>)
+#define TA_X(LL)                                                                         \
+    if (L == LL) {                                                                       \
+        if (mode == MODE_VACF) {                                                         \
+            if (f32) return gs ? TA_K(MODE_VACF, LL, true, float) : TA_K(MODE_VACF, LL, false, float); \
+            return gs ? TA_K(MODE_VACF, LL, true, double) : TA_K(MODE_VACF, LL, false, double);        \
+        }                                                                                \
+        if (f32) return gs ? TA_K(MODE_HELFAND, LL, true, float) : TA_K(MODE_HELFAND, LL, false, float); \
+        return gs ? TA_K(MODE_HELFAND, LL, true, double) : TA_K(MODE_HELFAND, LL, false, double);       \
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE, kL, false, Real>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_direct<MODE, kL, false, Real>), dim3(nwg), dim3(nt), lds_bytes, st, vel,
-                       pos, masses, ld_row, T, n_atoms, D, scale, by_particle, ld_bp, ts_partial,
-                       (void*)nullptr, gnt);
-    return hipGetLastError();
+    TA_DIRECT_CHUNKS(TA_X)
+#undef TA_X
+#undef TA_K
+    return nullptr;
 }
 
-hipError_t launch_direct(int mode, bool f32, const double* vel, const double* pos,
+bool direct_chunk_supported(int L) {
+#define TA_X(LL) if (L == LL) return true;
+    TA_DIRECT_CHUNKS(TA_X)
+#undef TA_X
+    return false;
+}
+
+hipError_t launch_direct(int mode, bool f32, int L, const double* vel, const double* pos,
                          const double* masses, long ld_row, int T, long n_atoms, int D,
                          double scale, double* by_particle, long ld_bp, double* ts_partial, int nwg,
                          int nt, size_t lds_bytes, void* stage_buf, int gnt, hipStream_t st) {
-#define TA_GO(M, R)                                                                              \
-    return launch_mode<M, R>(vel, pos, masses, ld_row, T, n_atoms, D, scale, by_particle, ld_bp, \
-                             ts_partial, nwg, nt, lds_bytes, stage_buf, gnt, st)
-    if (mode == MODE_VACF) {
-        if (f32) TA_GO(MODE_VACF, float);
-        TA_GO(MODE_VACF, double);
+    const bool gs = stage_buf != nullptr;  // long trajectory: column staged in global memory
+    const void* fn = direct_kernel(mode, f32, L, gs);
+    if (!fn) return hipErrorInvalidValue;
+    if (!gs) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return e;
     }
-    if (f32) TA_GO(MODE_HELFAND, float);
-    TA_GO(MODE_HELFAND, double);
-#undef TA_GO
+    void* args[] = {&vel, &pos, &masses, &ld_row, &T, &n_atoms, &D, &scale, &by_particle,
+                    &ld_bp, &ts_partial, &stage_buf, &gnt};
+    return hipLaunchKernel(fn, dim3(nwg), dim3(nt), args, gs ? 0 : lds_bytes, st);
 }
 
-template <int MODE, bool GS, typename Real>
-static int occ(int nt, size_t lds_bytes) {
+int direct_max_wg_per_cu(int mode, bool f32, int L, int nt, size_t lds_bytes, bool global_stage) {
+    const void* fn = direct_kernel(mode, f32, L, global_stage);
+    if (!fn) return 1;
     int n = 0;
-    if (!GS)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_direct<MODE, kL, GS, Real>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_direct<MODE, kL, GS, Real>, nt,
-                                                                GS ? 0 : lds_bytes);
+    if (!global_stage)
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, nt,
+                                                                global_stage ? 0 : lds_bytes);
     return (e != hipSuccess || n < 1) ? 1 : n;
-}
-
-int direct_max_wg_per_cu(int mode, bool f32, int nt, size_t lds_bytes, bool global_stage) {
-    const int key = (mode == MODE_VACF ? 0 : 4) + (f32 ? 2 : 0) + (global_stage ? 1 : 0);
-    switch (key) {
-        case 0: return occ<MODE_VACF, false, double>(nt, lds_bytes);
-        case 1: return occ<MODE_VACF, true, double>(nt, lds_bytes);
-        case 2: return occ<MODE_VACF, false, float>(nt, lds_bytes);
-        case 3: return occ<MODE_VACF, true, float>(nt, lds_bytes);
-        case 4: return occ<MODE_HELFAND, false, double>(nt, lds_bytes);
-        case 5: return occ<MODE_HELFAND, true, double>(nt, lds_bytes);
-        case 6: return occ<MODE_HELFAND, false, float>(nt, lds_bytes);
-        default: return occ<MODE_HELFAND, true, float>(nt, lds_bytes);
-    }
 }
 
 hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,

@@ -27,9 +27,18 @@ namespace ta {
 
 enum { MODE_VACF = 0, MODE_HELFAND = 1 };
 
-// Staged column layout: groups of L values followed by 16 bytes of padding.
+// Staged column layout: groups of L values padded to a stride of 4 (mod 8) dwords: groups
+// stay 16-byte aligned for ds_read_b128 and the 16 lanes a b128 read services together
+// (consecutive chunks) fall on 16 different 4-dword bank sets.
+constexpr int group_stride_dwords(int L, int elem_dwords) {
+    int s = L * elem_dwords;
+    while (s % 8 != 4) ++s;
+    return s;
+}
 template <int L, typename Real>
-constexpr int group_stride() { return L + 16 / (int)sizeof(Real); }
+constexpr int group_stride() {  // in elements
+    return group_stride_dwords(L, (int)sizeof(Real) / 4) / ((int)sizeof(Real) / 4);
+}
 
 template <int L, typename Real>
 __device__ __forceinline__ int lds_slot(int e) {  // element index -> slot
@@ -52,7 +61,8 @@ __device__ __forceinline__ void lds_read_group(const double* __restrict__ s, int
 template <int L>
 __device__ __forceinline__ void lds_read_group(const float* __restrict__ s, int e,
                                                float (&out)[L]) {
-    const float4* p = reinterpret_cast<const float4*>(s + (e / L) * group_stride<L, float>());
+    const float* g = s + (e / L) * group_stride<L, float>();
+    const float4* p = reinterpret_cast<const float4*>(g);
 #pragma unroll
     for (int i = 0; i < L / 4; ++i) {
         float4 t = p[i];
@@ -60,6 +70,11 @@ __device__ __forceinline__ void lds_read_group(const float* __restrict__ s, int 
         out[4 * i + 1] = t.y;
         out[4 * i + 2] = t.z;
         out[4 * i + 3] = t.w;
+    }
+    if constexpr (L % 4 == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(g + L - 2);
+        out[L - 2] = t.x;
+        out[L - 1] = t.y;
     }
 }
 
@@ -129,35 +144,34 @@ __device__ __forceinline__ void chunk_accumulate(const double* __restrict__ s, i
 // ---- float32 path: packed math (v_pk_add_f32 / v_pk_fma_f32, two float32 per lane) ------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+template <int L>
 __device__ __forceinline__ void lds_read_pairs(const float* __restrict__ s, int e,
-                                               v2f (&out)[4]) {
-    // e is a multiple of 8: one padded group of 8 floats as 4 register pairs
-    const float4* p = reinterpret_cast<const float4*>(s + (e / 8) * group_stride<8, float>());
-    const float4 t0 = p[0], t1 = p[1];
-    out[0] = v2f{t0.x, t0.y};
-    out[1] = v2f{t0.z, t0.w};
-    out[2] = v2f{t1.x, t1.y};
-    out[3] = v2f{t1.z, t1.w};
+                                               v2f (&out)[L / 2]) {
+    // e is a multiple of L: one padded group of L floats as L/2 register pairs
+    float t[L];
+    lds_read_group<L>(s, e, t);
+#pragma unroll
+    for (int k = 0; k < L / 2; ++k) out[k] = v2f{t[2 * k], t[2 * k + 1]};
 }
 
-// One 8 x 8 tile on register pairs.  X[bp] = (x[2bp], x[2bp+1]); the window w[0..16) is lo ++ hi
-// as natural pairs E[k] = (w[2k], w[2k+1]); odd lags need O[k] = (w[2k+1], w[2k+2]).  part[a]
-// holds two half-sums of lag a (even and odd b), added together at the flush.
-template <int MODE>
-__device__ __forceinline__ void tile_f32(const v2f (&X)[4], const v2f (&lo)[4],
-                                         const v2f (&hi)[4], v2f (&part)[8]) {
-    v2f E[8], O[7];
+// One L x L tile on register pairs.  X[bp] = (x[2bp], x[2bp+1]); the window w[0..2L) is
+// lo ++ hi as natural pairs E[k] = (w[2k], w[2k+1]); odd lags need O[k] = (w[2k+1], w[2k+2]).
+// part[a] holds two half-sums of lag a (even and odd b), added together at the flush.
+template <int MODE, int L>
+__device__ __forceinline__ void tile_f32(const v2f (&X)[L / 2], const v2f (&lo)[L / 2],
+                                         const v2f (&hi)[L / 2], v2f (&part)[L]) {
+    v2f E[L], O[L - 1];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < L / 2; ++k) {
         E[k] = lo[k];
-        E[4 + k] = hi[k];
+        E[L / 2 + k] = hi[k];
     }
 #pragma unroll
-    for (int k = 0; k < 7; ++k) O[k] = __builtin_shufflevector(E[k], E[k + 1], 1, 2);
+    for (int k = 0; k < L - 1; ++k) O[k] = __builtin_shufflevector(E[k], E[k + 1], 1, 2);
 #pragma unroll
-    for (int bp = 0; bp < 4; ++bp)
+    for (int bp = 0; bp < L / 2; ++bp)
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
+        for (int a = 0; a < L; ++a) {
             const int idx = a + 2 * bp;
             const v2f W = (a & 1) ? O[(idx - 1) / 2] : E[idx / 2];
             if (MODE == MODE_VACF) {
@@ -169,46 +183,46 @@ __device__ __forceinline__ void tile_f32(const v2f (&X)[4], const v2f (&lo)[4],
         }
 }
 
-// float32 chunk: products / squared differences and 64-term sums per lag in float32 (two
-// packed 32-term half-sums), added into the float64 accumulators every 8 blocks.  Blocks go
-// two at a time so the window halves swap roles instead of being copied.
+// float32 chunk: products / squared differences and 8L-term sums per lag in float32 (two
+// packed half-sums), added into the float64 accumulators every 8 blocks.  Blocks go two at
+// a time so the window halves swap roles instead of being copied.
 template <int MODE, int L>
 __device__ __forceinline__ void chunk_accumulate(const float* __restrict__ s, int T, int k0,
                                                  double (&acc)[L]) {
-    static_assert(L == 8, "packed float32 tile is written for 8-lag chunks");
+    static_assert(L % 2 == 0, "packed float32 tile needs an even chunk");
     const int span = T - k0;
     const int nblk = (span + L - 1) / L;
     int nfull = (T - k0 - 2 * L + 1) / L + 1;
     if (T - k0 - 2 * L + 1 < 0) nfull = 0;
     if (nfull > nblk) nfull = nblk;
     if (MODE == MODE_VACF) nfull = nblk;
-    v2f part[8];
+    v2f part[L];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) part[a] = v2f{0.f, 0.f};
+    for (int a = 0; a < L; ++a) part[a] = v2f{0.f, 0.f};
     auto flush = [&]() {
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
+        for (int a = 0; a < L; ++a) {
             acc[a] += (double)(part[a].x + part[a].y);
             part[a] = v2f{0.f, 0.f};
         }
     };
-    v2f A[4], B[4], X[4];
-    lds_read_pairs(s, k0, A);
+    v2f A[L / 2], B[L / 2], X[L / 2];
+    lds_read_pairs<L>(s, k0, A);
     int blk = 0;
     for (; blk + 1 < nfull; blk += 2) {
         const int i = blk * L;
-        lds_read_pairs(s, i, X);
-        lds_read_pairs(s, i + k0 + L, B);
-        tile_f32<MODE>(X, A, B, part);
-        lds_read_pairs(s, i + L, X);
-        lds_read_pairs(s, i + k0 + 2 * L, A);
-        tile_f32<MODE>(X, B, A, part);
+        lds_read_pairs<L>(s, i, X);
+        lds_read_pairs<L>(s, i + k0 + L, B);
+        tile_f32<MODE, L>(X, A, B, part);
+        lds_read_pairs<L>(s, i + L, X);
+        lds_read_pairs<L>(s, i + k0 + 2 * L, A);
+        tile_f32<MODE, L>(X, B, A, part);
         if (((blk + 2) & 7) == 0) flush();
     }
     if (blk < nfull) {
-        lds_read_pairs(s, blk * L, X);
-        lds_read_pairs(s, blk * L + k0 + L, B);
-        tile_f32<MODE>(X, A, B, part);
+        lds_read_pairs<L>(s, blk * L, X);
+        lds_read_pairs<L>(s, blk * L + k0 + L, B);
+        tile_f32<MODE, L>(X, A, B, part);
         ++blk;
     }
     flush();

@@ -43,13 +43,13 @@ const std::vector<PlanEntry>& plans_pow2();
 const std::vector<PlanEntry>& plans_five();
 
 // direct.hip
-hipError_t launch_direct(int mode, bool f32, const double* vel, const double* pos,
+hipError_t launch_direct(int mode, bool f32, int L, const double* vel, const double* pos,
                          const double* masses, long ld_row, int T, long n_atoms, int D,
                          double scale, double* by_particle, long ld_bp, double* ts_partial, int nwg,
                          int nt, size_t lds_bytes, void* stage_buf, int gnt, hipStream_t st);
-int direct_chunk();                       // L
-size_t direct_lds_bytes(int T, bool f32);
-int direct_max_wg_per_cu(int mode, bool f32, int nt, size_t lds_bytes, bool global_stage);
+bool direct_chunk_supported(int L);       // lags per chunk compiled in (8, 10)
+size_t direct_lds_bytes(int T, bool f32, int L);
+int direct_max_wg_per_cu(int mode, bool f32, int L, int nt, size_t lds_bytes, bool global_stage);
 
 hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,
                                hipStream_t st);
