@@ -416,15 +416,20 @@ int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int 
         int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg
                                            : (int64_t)ctx->n_cu * plan->max_wg_per_cu(2);
         nwg = std::max<int64_t>(1, std::min(nwg, A));
-        if ((rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)nwg * T))) return rc;
+        if (nwg >= 8) nwg -= nwg % 8;  // XCD-aware walk
+        // accumulator swap blocks of the small plans (as in the timeseries path)
+        const size_t acc_blk = (size_t)((plan->K_last * plan->R_last + 1) / 2) * 2 * plan->NT;
+        const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * acc_blk;
+        if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
+        a.partial = (double*)ctx->partial.p;
         a.by_particle = d_bp;
         a.ld_bp = ld_bp;
-        a.ts_partial = (double*)ctx->ts_partial.p;
-        TA_HIP_TRY(ctx, hipMemsetAsync(a.ts_partial, 0, sizeof(double) * (size_t)nwg * T, st));
+        TA_HIP_TRY(ctx, hipMemsetAsync(a.partial, 0, acc_bytes, st));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
         TA_HIP_TRY(ctx, plan->by_particle((int)nwg, st, a));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-        TA_HIP_TRY(ctx, launch_sum_partials(a.ts_partial, (int)nwg, T, d_lagsum, st));
+        // lag sums = row sums of the by-particle array (velocityautocorr.py:214)
+        TA_HIP_TRY(ctx, launch_row_sums(d_bp, T, A, ld_bp, d_lagsum, st));
     }
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     ctx->timing_valid = true;

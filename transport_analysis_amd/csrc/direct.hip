@@ -118,6 +118,32 @@ hipError_t launch_sum_partials(const double* partial, int n_parts, long n, doubl
     return hipGetLastError();
 }
 
+// out[n] = sum_a bp[n*ld + a]: the lag sums of a by-particle result (one workgroup per lag).
+__global__ void __launch_bounds__(256) k_row_sums(const double* __restrict__ bp, long n_cols,
+                                                  long ld, double* __restrict__ out) {
+    __shared__ double part[4];
+    const double* row = bp + (long)blockIdx.x * ld;
+    double s0 = 0.0, s1 = 0.0;
+    long a = threadIdx.x;
+    for (; a + 256 < n_cols; a += 512) {
+        s0 += row[a];
+        s1 += row[a + 256];
+    }
+    if (a < n_cols) s0 += row[a];
+    double s = s0 + s1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+hipError_t launch_row_sums(const double* bp, long n_rows, long n_cols, long ld, double* out,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(k_row_sums, dim3((unsigned)n_rows), dim3(256), 0, st, bp, n_cols, ld, out);
+    return hipGetLastError();
+}
+
 __global__ void k_widen_f32(const float* __restrict__ in, double* __restrict__ out, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;

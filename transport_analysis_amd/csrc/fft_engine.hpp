@@ -242,13 +242,16 @@ __device__ __forceinline__ void inv_stage_lds(cd* __restrict__ lds, const cd* __
             const int blk = u / SI::L, b = u - blk * SI::L;
             const int base = blk * SI::N + b;
             cd v[SI::R];
+            TA_AGPR_FENCE_HOOK();
 #pragma unroll
             for (int q = 0; q < SI::R; ++q) v[q] = lds[sw(base + q * SI::L)];
             if (SI::L > 1) {
 #pragma unroll
                 for (int q = 1; q < SI::R; ++q) v[q] = cmulc(v[q], tw2[q * b * SI::TWSTEP]);
             }
+            TA_AGPR_FENCE_HOOK();
             idft<SI::R>(v);
+            TA_AGPR_FENCE_HOOK();
 #pragma unroll
             for (int j = 0; j < SI::R; ++j) lds[sw(base + j * SI::L)] = v[j];
         }

@@ -410,6 +410,22 @@ constexpr bool plan_all_mid_seedable() {
     return ok;
 }
 
+// Shared epilogue: LDS holds q = IDFT_M(P_A + i P_B) in natural order.
+// lag-n value = Re(a + conj(W_{2M}^n) * b) / (2M) / (T-n), with
+// a = (q[n] + conj(q[M-n]))/2, b = (q[n] - conj(q[M-n]))/(2i).
+template <class P>
+__device__ __forceinline__ double lag_value(const cd* __restrict__ lds,
+                                            const cd* __restrict__ tw2, int n, int T) {
+    const cd qn = lds[sw(n)];
+    const cd qm = lds[sw((P::M - n) % P::M)];
+    const cd a = {0.5 * (qn.x + qm.x), 0.5 * (qn.y - qm.y)};
+    // (qn - conj(qm)) / (2i) = ( (qn.y + qm.y) - i (qn.x - qm.x) ) / 2
+    const cd b = {0.5 * (qn.y + qm.y), -0.5 * (qn.x - qm.x)};
+    const cd w = tw2[n];  // exp(-i pi n / M); need its conjugate
+    const double re = a.x + (b.x * w.x + b.y * w.y);
+    return re / (2.0 * (double)P::M) / (double)(T - n);
+}
+
 // STAMP (diagnostic builds only): lane 0 accumulates s_memtime deltas per phase.
 #define TA_STAMP(idx)                                                              \
     if constexpr (STAMP) {                                                         \
@@ -436,11 +452,19 @@ constexpr bool plan_all_mid_seedable() {
 //
 // accg: [gridDim.x][2][acc_quads*2*NT] float64 (pass A block, pass B block), zeroed by
 // the caller; k_sum_partials_perm restores the transform's digit-reversed bin order.
-template <class P, bool VEC, bool STAMP = false>
+//
+// BYP (by-particle mode): a workgroup takes whole atoms (atom = slot + k*gridDim.x; units of
+// an atom: (x,y) then (z,0) for D = 3, one unit for D <= 2); after an atom's last unit the
+// two accumulator sets are the atom's own power spectrum: they go to LDS, one inverse
+// transform, and the lag values are written to
+// by_particle[:, atom] while the NEXT atom's first unit is already in flight into the parked
+// registers (the lag sums over atoms are row sums of by_particle: k_row_sums).
+template <class P, bool VEC, bool STAMP = false, bool BYP = false>
 __global__ void __launch_bounds__(P::NT)
     k_fft_accum(const double* __restrict__ vel, long ld_row, long pair_stride, int T, long n_cols,
                 const cd* __restrict__ tw2, double* __restrict__ accg, int flags,
-                unsigned long long* __restrict__ stamps = nullptr) {
+                unsigned long long* __restrict__ stamps = nullptr, int D = 0, long n_atoms = 0,
+                double* __restrict__ by_particle = nullptr, long ld_bp = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
     using SL = StageInfo<P, P::S - 1>;
@@ -485,13 +509,23 @@ __global__ void __launch_bounds__(P::NT)
 #pragma unroll
         for (int q = 0; q < SL::R; ++q) accB[m][q] = 0.0;
 
-    const long n_pairs = (n_cols + 1) / 2;
-    long pair = slot;
-    if (pair < n_pairs)
-        gather_issue_range<P, VEC, 0, NLOAD>(vel + pair * pair_stride, ld_row, T,
-                                             2 * pair + 1 < n_cols, tid);
+    // work units of this workgroup: unit i = column pair slot + i*nwg, or (BYP) unit
+    // i % ppa of atom slot + (i / ppa)*nwg
+    const int ppa = BYP ? (D + 1) / 2 : 1;
+    const long n_mine = BYP ? (slot < n_atoms ? ((n_atoms - slot + nwg - 1) / nwg) * ppa : 0)
+                            : ((n_cols + 1) / 2 > slot ? ((n_cols + 1) / 2 - slot + nwg - 1) / nwg : 0);
+    auto unit_col = [&](long i) -> const double* {
+        if constexpr (BYP) return vel + (slot + (i / ppa) * nwg) * D + 2 * (i % ppa);
+        else return vel + (slot + i * nwg) * pair_stride;
+    };
+    auto unit_has2 = [&](long i) -> bool {
+        if constexpr (BYP) return 2 * (int)(i % ppa) + 1 < D;
+        else return 2 * (slot + i * nwg) + 1 < n_cols;
+    };
+    long unit = 0;
+    if (unit < n_mine) gather_issue_range<P, VEC, 0, NLOAD>(unit_col(0), ld_row, T, unit_has2(0), tid);
     auto no_hook = [](int) {};
-    while (pair < n_pairs) {
+    while (unit < n_mine) {
         // per-lane addresses and table offsets depend on tid/ld_row only: keep LICM from
         // hoisting (and spilling) them out of the pair loop
         asm volatile("" : "+s"(tw2), "+s"(ld_row), "+v"(tid));
@@ -511,10 +545,10 @@ __global__ void __launch_bounds__(P::NT)
         __syncthreads();
         // ---- pass B: odd bins; after its first stage the parked pair is dead and is
         // refilled with the next pair while pass B's butterflies run
-        const long next = pair + nwg;
-        const bool more = next < n_pairs;
-        const double* ncol = vel + (more ? next : pair) * pair_stride;
-        const bool nhas2 = 2 * (more ? next : pair) + 1 < n_cols;
+        const long next = unit + 1;
+        const bool more = next < n_mine;
+        const double* ncol = unit_col(more ? next : unit);
+        const bool nhas2 = unit_has2(more ? next : unit);
         auto hook = [&](int slot_) {
             if (more) {
 #define TA_LO(S) ((S) <= S0::K ? (S)*UNIT                                                   \
@@ -575,8 +609,77 @@ __global__ void __launch_bounds__(P::NT)
         TA_STAMP(5)
         __syncthreads();
         if constexpr (STAMP) st_acc[7] += 1;
-        pair = next;
+        if constexpr (BYP) {
+            if ((int)(unit % ppa) == ppa - 1) {
+                const long atom = slot + (unit / ppa) * nwg;
+                // ---- this atom's spectrum -> LDS (digit-reversed order), accumulators reset
+                if constexpr (acc_b_in_regs<P>()) {
+                    static_for<SL::K>([&](auto mm) {
+                        constexpr int m = decltype(mm)::value;
+                        const int u = tid + m * P::NT;
+                        if (SL::TASKS % P::NT == 0 || u < SL::TASKS) {
+                            static_for<SL::R>([&](auto qq) {
+                                constexpr int q = decltype(qq)::value;
+                                constexpr int a = agpr_acc_base<P>() + 2 * (m * SL::R + q);
+                                lds[sw(u * SL::R + q)] = cd{ag_read_f64<a>(), accB[m][q]};
+                                ag_write_f64<a>(0.0);
+                                accB[m][q] = 0.0;
+                            });
+                        }
+                    });
+                } else {
+                    // both sets were swapped out to the workgroup's blocks: [quad][thread] x 2
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const double2* ba = reinterpret_cast<const double2*>(blkA);
+                    const double2* bb = reinterpret_cast<const double2*>(blkB);
+#pragma unroll
+                    for (int m = 0; m < SL::K; ++m) {
+                        const int u = tid + m * P::NT;
+                        if (SL::TASKS % P::NT == 0 || u < SL::TASKS) {
+#pragma unroll
+                            for (int q = 0; q < SL::R; q += 2) {
+                                const int e = m * SL::R + q;  // even: SL::R is even or K == 1
+                                const double2 va = ba[(long)(e / 2) * P::NT + tid];
+                                const double2 vb = bb[(long)(e / 2) * P::NT + tid];
+                                lds[sw(u * SL::R + q)] = cd{va.x, vb.x};
+                                if (q + 1 < SL::R) lds[sw(u * SL::R + q + 1)] = cd{va.y, vb.y};
+                            }
+                        }
+                    }
+                    double2* za = reinterpret_cast<double2*>(blkA);
+                    double2* zb = reinterpret_cast<double2*>(blkB);
+#pragma unroll
+                    for (int q = 0; q < acc_quads<P>(); ++q) {
+                        za[(long)q * P::NT + tid] = make_double2(0.0, 0.0);
+                        zb[(long)q * P::NT + tid] = make_double2(0.0, 0.0);
+                    }
+                }
+                agpr_fence<P>();
+                __syncthreads();
+                inv_all_stages<P, P::S - 1>(lds, tw2, tid);
+                // lag values of this atom; the atom mean is a row sum over by_particle afterwards
+                // (k_row_sums), like the reference's mean(axis=1)
+                for (int n0 = tid; n0 < T; n0 += 4 * P::NT) {
+                    agpr_fence<P>();
+                    double val[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int n = n0 + k * P::NT;
+                        val[k] = lag_value<P>(lds, tw2, n < T ? n : 0, T);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int n = n0 + k * P::NT;
+                        if (n < T) by_particle[(long)n * ld_bp + atom] = val[k];
+                    }
+                }
+                agpr_fence<P>();
+                __syncthreads();
+            }
+        }
+        unit = next;
     }
+    if constexpr (BYP) return;
     // write both accumulator sets to this workgroup's block ([quad][thread] layout)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (acc_b_in_regs<P>()) {
@@ -594,22 +697,6 @@ __global__ void __launch_bounds__(P::NT)
     }
 }
 
-// Shared epilogue: LDS holds q = IDFT_M(P_A + i P_B) in natural order.
-// lag-n value = Re(a + conj(W_{2M}^n) * b) / (2M) / (T-n), with
-// a = (q[n] + conj(q[M-n]))/2, b = (q[n] - conj(q[M-n]))/(2i).
-template <class P>
-__device__ __forceinline__ double lag_value(const cd* __restrict__ lds,
-                                            const cd* __restrict__ tw2, int n, int T) {
-    const cd qn = lds[sw(n)];
-    const cd qm = lds[sw((P::M - n) % P::M)];
-    const cd a = {0.5 * (qn.x + qm.x), 0.5 * (qn.y - qm.y)};
-    // (qn - conj(qm)) / (2i) = ( (qn.y + qm.y) - i (qn.x - qm.x) ) / 2
-    const cd b = {0.5 * (qn.y + qm.y), -0.5 * (qn.x - qm.x)};
-    const cd w = tw2[n];  // exp(-i pi n / M); need its conjugate
-    const double re = a.x + (b.x * w.x + b.y * w.y);
-    return re / (2.0 * (double)P::M) / (double)(T - n);
-}
-
 // ---- K3 (timeseries path): one inverse transform of the summed spectrum --------
 // spec: [2][M] (pass A bins, pass B bins), digit-reversed order.
 template <class P>
@@ -623,54 +710,6 @@ __global__ void __launch_bounds__(P::NT)
     __syncthreads();
     inv_all_stages<P, P::S - 1>(lds, tw2, tid);
     for (int n = tid; n < T; n += P::NT) lagsum[n] = lag_value<P>(lds, tw2, n, T);
-}
-
-// ---- by-particle path: per-atom spectra, inverse transform per atom ------------
-// One workgroup per atom at a time: forward passes over the atom's columns
-// (D=1: (x,0); D=2: (x,y); D=3: (x,y),(z,0)), inverse, scatter into
-// by_particle[:, atom], and keep a running per-lag sum for the timeseries.
-// ts_partial: [gridDim.x][T].
-template <class P>
-__global__ void __launch_bounds__(P::NT)
-    k_fft_by_particle(const double* __restrict__ vel, long ld_row, int T, long n_atoms, int D,
-                      const cd* __restrict__ tw2, double* __restrict__ by_particle, long ld_bp,
-                      double* __restrict__ ts_partial) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cd* lds = reinterpret_cast<cd*>(smem_raw);
-    using SL = StageInfo<P, P::S - 1>;
-    const int tid = threadIdx.x;
-    double* ts = ts_partial + (long)blockIdx.x * T;  // zeroed by the caller
-
-    for (long atom = blockIdx.x; atom < n_atoms; atom += gridDim.x) {
-        double accA[SL::K][SL::R], accB[SL::K][SL::R];
-#pragma unroll
-        for (int m = 0; m < SL::K; ++m)
-#pragma unroll
-            for (int q = 0; q < SL::R; ++q) accA[m][q] = accB[m][q] = 0.0;
-        const double* base = vel + atom * D;
-        for (int c = 0; c < D; c += 2) {
-            const bool has2 = c + 1 < D;
-            forward_pass_acc<P, false, false>(lds, tw2, base + c, ld_row, T, has2, accA, tid);
-            forward_pass_acc<P, false, true>(lds, tw2, base + c, ld_row, T, has2, accB, tid);
-        }
-#pragma unroll
-        for (int m = 0; m < SL::K; ++m) {
-            const int u = tid + m * P::NT;
-            if (SL::TASKS % P::NT == 0 || u < SL::TASKS) {
-#pragma unroll
-                for (int q = 0; q < SL::R; ++q)
-                    lds[sw(u * SL::R + q)] = cd{accA[m][q], accB[m][q]};
-            }
-        }
-        __syncthreads();
-        inv_all_stages<P, P::S - 1>(lds, tw2, tid);
-        for (int n = tid; n < T; n += P::NT) {
-            const double val = lag_value<P>(lds, tw2, n, T);
-            by_particle[(long)n * ld_bp + atom] = val;
-            ts[n] += val;
-        }
-        __syncthreads();
-    }
 }
 
 }  // namespace ta

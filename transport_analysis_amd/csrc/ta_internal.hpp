@@ -51,6 +51,8 @@ bool direct_chunk_supported(int L);       // lags per chunk compiled in (8, 10)
 size_t direct_lds_bytes(int T, bool f32, int L);
 int direct_max_wg_per_cu(int mode, bool f32, int L, int nt, size_t lds_bytes, bool global_stage);
 
+hipError_t launch_row_sums(const double* bp, long n_rows, long n_cols, long ld, double* out,
+                           hipStream_t st);
 hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,
                                hipStream_t st);
 // spec[pass*M + u*R + q] = sum over workgroups of their accumulator (m, q), u = tid + m*NT
