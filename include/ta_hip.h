@@ -127,7 +127,9 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *                      and add them into float64 accumulators (BASELINE configs[4]'s
  *                      float32 path; ~1e-6 relative accuracy).  Default 0 = float64.
  *   "fft_nwg", "direct_nwg" : persistent workgroup counts (0 = automatic);
- *   "fft_debug" : diagnostics.                                                  */
+ *   "direct_chunk" 0|8|10, "direct_groups" n : force the direct correlators' lags per chunk /
+ *                      cap the atoms a workgroup works on at once (0 = automatic);
+ *   "fft_debug" : diagnostics.   Unknown keys return TA_E_INVALID.                */
 int ta_set_option(ta_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

@@ -12,6 +12,7 @@ from conftest import GOLDEN, scale_rel_err
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-10
+TOL_F32 = 2e-6  # float32 products / block sums, float64 accumulation
 
 
 def g(name):
@@ -102,7 +103,9 @@ def test_vacf_n10_notebook(ctx):
 
 SHAPES = [(1, 1, 1), (2, 3, 3), (5, 2, 2), (16, 7, 3), (17, 4, 1), (33, 9, 2), (100, 40, 3),
           (129, 3, 3), (257, 33, 3), (640, 11, 2), (641, 5, 3), (1000, 37, 3), (1025, 6, 1),
-          (2049, 3, 3), (2561, 4, 2), (4097, 2, 3), (5121, 2, 1), (10000, 3, 3), (10240, 2, 2)]
+          (2049, 3, 3), (2561, 4, 2), (4097, 2, 3), (5121, 2, 1), (10000, 3, 3), (10240, 2, 2),
+          # the remaining plan lengths: M = 32, 64, 80, 256, 512, 2048
+          (30, 5, 3), (64, 3, 2), (77, 4, 3), (200, 6, 1), (400, 5, 3), (2000, 3, 3)]
 
 
 @pytest.mark.parametrize("T,A,D", SHAPES)
@@ -133,6 +136,125 @@ def test_vacf_direct_vs_oracle_shapes(ctx, T, A, D):
     assert scale_rel_err(ts, want_ts) < TOL
     ts2, _ = run_vacf(ctx, v, False, False)
     assert scale_rel_err(ts2, want_ts) < TOL
+
+
+@pytest.mark.parametrize("T,A,D", [(100, 700, 3), (1000, 300, 2), (2561, 90, 3), (5121, 70, 3),
+                                   (10000, 50, 1), (640, 203, 3)])
+def test_fft_many_units_per_workgroup(ctx, T, A, D):
+    """Persistent workgroups walking several column pairs / atoms each (8 workgroups only):
+    the software pipeline across units and, by-particle, the per-atom inverse + reset."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(T, A, D, seed=5000 + T)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
+    ctx.set_option("fft_nwg", 8)
+    try:
+        ts, bp = run_vacf(ctx, v, True, True)
+        ts2, _ = run_vacf(ctx, v, True, False)
+    finally:
+        ctx.set_option("fft_nwg", 0)
+    assert scale_rel_err(bp, want_bp) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL
+    np.testing.assert_allclose(ts, bp.mean(axis=1), rtol=1e-12, atol=1e-13 * np.abs(ts).max())
+    assert scale_rel_err(ts2, want_ts) < TOL
+
+
+@pytest.mark.parametrize("T,A,D,nwg", [(300, 77, 3, 2), (64, 100, 2, 1), (1000, 41, 3, 3)])
+def test_direct_column_groups_ragged(ctx, T, A, D, nwg):
+    """Workgroups of several column groups with an atom count that is not a multiple of the
+    group count, several rounds per workgroup, both correlators and both arithmetic paths."""
+    from oracle import numpy_oracle as orc
+
+    v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=6000 + T)
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+    want_vbp, want_vts = orc.vacf_windowed(v)
+    want_hbp, want_hts = orc.helfand(v, x, m, vol, 300.0)
+    ctx.set_option("direct_nwg", nwg)
+    try:
+        for f32, tol in ((0, TOL), (1, TOL_F32)):
+            ctx.set_option("direct_f32", f32)
+            for chunk in (8, 10):
+                ctx.set_option("direct_chunk", chunk)
+                ts, bp = run_vacf(ctx, v, False, True)
+                assert scale_rel_err(bp, want_vbp) < tol and scale_rel_err(ts, want_vts) < tol
+                ts, bp = run_helfand(ctx, v, x, m, scale, True)
+                assert scale_rel_err(bp, want_hbp) < tol and scale_rel_err(ts, want_hts) < tol
+    finally:
+        ctx.set_option("direct_nwg", 0)
+        ctx.set_option("direct_f32", 0)
+        ctx.set_option("direct_chunk", 0)
+
+
+def test_device_entry_points_on_a_column_block(ctx):
+    """ta_*_dev on a shard that is a column block of a wider resident slab (ld_row > n_atoms*dim)
+    with a padded by-particle leading dimension: the multi-GPU calling convention."""
+    import torch
+
+    from oracle import numpy_oracle as orc
+
+    T, A_all, D, lo, hi = 257, 40, 3, 7, 29
+    v, x, m, vol = orc.synthetic_helfand(T, A_all, D, seed=77)
+    A = hi - lo
+    dv = torch.from_numpy(v).cuda()
+    dx = torch.from_numpy(x).cuda()
+    dm = torch.from_numpy(m[lo:hi].copy()).cuda()
+    ld_row, ld_bp = A_all * D, A + 5
+    st = torch.cuda.current_stream().cuda_stream
+    off = lo * D * 8
+    want_bp, _ = orc.vacf_fft_batched(v[:, lo:hi])
+    hbp, _ = orc.helfand(v[:, lo:hi], x[:, lo:hi], m[lo:hi], vol, 300.0)
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+    for which in ("fft", "direct", "helfand"):
+        lag = torch.zeros(T, dtype=torch.float64, device="cuda")
+        bp = torch.full((T, ld_bp), -7.0, dtype=torch.float64, device="cuda")
+        if which == "fft":
+            ctx.vacf_fft_dev(dv.data_ptr() + off, T, A, D, ld_row, lag.data_ptr(), bp.data_ptr(), ld_bp, st)
+        elif which == "direct":
+            ctx.vacf_direct_dev(dv.data_ptr() + off, T, A, D, ld_row, lag.data_ptr(), bp.data_ptr(), ld_bp, st)
+        else:
+            ctx.helfand_msd_dev(dv.data_ptr() + off, dx.data_ptr() + off, dm.data_ptr(), T, A, D, ld_row,
+                                scale, lag.data_ptr(), bp.data_ptr(), ld_bp, st)
+        torch.cuda.synchronize()
+        got = bp.cpu().numpy()
+        want = hbp if which == "helfand" else want_bp
+        assert scale_rel_err(got[:, :A], want) < TOL
+        assert np.all(got[:, A:] == -7.0)  # the padding columns are not touched
+        assert scale_rel_err(lag.cpu().numpy(), want.sum(axis=1)) < TOL
+        lag2 = torch.zeros(T, dtype=torch.float64, device="cuda")  # lag sums without by_particle
+        if which == "fft":
+            ctx.vacf_fft_dev(dv.data_ptr() + off, T, A, D, ld_row, lag2.data_ptr(), 0, 0, st)
+        elif which == "direct":
+            ctx.vacf_direct_dev(dv.data_ptr() + off, T, A, D, ld_row, lag2.data_ptr(), 0, 0, st)
+        else:
+            ctx.helfand_msd_dev(dv.data_ptr() + off, dx.data_ptr() + off, dm.data_ptr(), T, A, D, ld_row,
+                                scale, lag2.data_ptr(), 0, 0, st)
+        torch.cuda.synchronize()
+        assert scale_rel_err(lag2.cpu().numpy(), want.sum(axis=1)) < TOL
+
+
+def test_cabi_error_behaviour(ctx):
+    """Negative status + message instead of a crash (include/ta_hip.h conventions)."""
+    import torch
+
+    from transport_analysis_amd import _lib
+
+    c = _lib.Context(0)
+    with pytest.raises(_lib.TAError) as e:  # compute before staging
+        c.vacf_fft()
+    assert e.value.code == -4
+    buf = torch.zeros(64, dtype=torch.float64, device="cuda")
+    for args in ((buf.data_ptr(), 4, 2, 4, 8),      # dim 4
+                 (buf.data_ptr(), 4, 2, 3, 5),      # ld_row < n_atoms*dim
+                 (buf.data_ptr(), 0, 2, 3, 6),      # no frames
+                 (0, 4, 2, 3, 6)):                  # null slab
+        with pytest.raises(_lib.TAError) as e:
+            c.vacf_fft_dev(args[0], args[1], args[2], args[3], args[4], buf.data_ptr())
+        assert e.value.code == -1 and str(e.value)
+    with pytest.raises(_lib.TAError):  # by-particle leading dimension too small
+        c.vacf_direct_dev(buf.data_ptr(), 4, 2, 3, 6, buf.data_ptr(), buf.data_ptr(), 1)
+    with pytest.raises(_lib.TAError):
+        c.set_option("no_such_option", 1)
+    c.close()
 
 
 @pytest.mark.parametrize("fft", [True, False])
@@ -235,9 +357,6 @@ def test_helfand_vs_oracle_shapes(ctx, T, A, D):
     ts, bp = run_helfand(ctx, v, x, m, scale, True)
     assert scale_rel_err(bp, want_bp) < TOL
     assert scale_rel_err(ts, want_ts) < TOL
-
-
-TOL_F32 = 2e-6  # float32 products / 32-term block sums, float64 accumulation
 
 
 @pytest.mark.parametrize("T,A,D", [(2, 3, 1), (17, 5, 2), (300, 21, 3), (1001, 7, 3), (5000, 3, 3)])

@@ -46,6 +46,32 @@ def build(force=False):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 with
+    the same SONAME as /opt/rocm's; whichever is loaded first serves both libraries, and
+    torch.cuda fails ("No HIP GPUs are available") on top of a runtime that is not its own.
+    So when torch is installed but not loaded yet, its runtime is loaded first -- without
+    importing torch -- and libta_hip.so binds to it exactly as it does when the application
+    imported torch before us."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -55,6 +81,7 @@ def lib():
             f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
             " (hipcc --offload-arch=gfx950). transport_analysis_amd has no CPU fallback."
         )
+    _share_hip_runtime_with_torch()
     L = ctypes.CDLL(_SO)
     vp, i64, ci, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
     L.ta_abi_version.restype = ci
@@ -162,7 +189,7 @@ class Context:
 
     # -- host-facing compute -------------------------------------------
     def _host(self, fn, by_particle, *extra):
-        T, A, _ = self.shape
+        T, A, _ = getattr(self, "shape", None) or (1, 1, 1)  # unstaged: the library reports it
         ts = np.empty(T, dtype=np.float64)
         bp = np.empty((T, A), dtype=np.float64) if by_particle else None
         self._check(fn(self._h, *extra, _ptr(ts), _ptr(bp)))
