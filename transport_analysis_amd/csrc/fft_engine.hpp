@@ -265,17 +265,6 @@ __device__ __forceinline__ void inv_all_stages(cd* lds, const cd* tw2, int tid) 
     if constexpr (s > 0) inv_all_stages<P, s - 1>(lds, tw2, tid);
 }
 
-template <class P, int s>
-__device__ __forceinline__ void fwd_mid_stages(cd* lds, const cd* tw2, int tid) {
-    // runs stages s .. S-2 (each followed by a barrier)
-    if constexpr (s <= P::S - 2) {
-        fwd_stage_lds<P, s>(lds, tw2, tid);
-        __syncthreads();
-        fwd_mid_stages<P, s + 1>(lds, tw2, tid);
-    }
-}
-
-
 // In-LDS forward stage whose per-thread twiddle base b = u % L is the same for all
 // of the thread's butterflies (NT % L == 0): no table loads.  The twiddles
 // W^{q b} = seed^q are formed by repeated multiplication on the fly (two interleaved

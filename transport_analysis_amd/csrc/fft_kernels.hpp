@@ -35,122 +35,6 @@ __device__ __forceinline__ void agpr_fence();
 
 namespace ta {
 
-// ---- input access -----------------------------------------------------------
-// z[t] = col[t*ld_row] + i*col[t*ld_row + 1] (imaginary part 0 when !has2).
-template <bool VEC>
-__device__ __forceinline__ cd load_z(const double* __restrict__ col, long ld_row, int t,
-                                     bool has2) {
-    const double* p = col + (long)t * ld_row;
-    if constexpr (VEC) {
-        const double2 v = *reinterpret_cast<const double2*>(p);
-        return {v.x, v.y};
-    } else {
-        cd r;
-        r.x = p[0];
-        r.y = has2 ? p[1] : 0.0;
-        return r;
-    }
-}
-
-// First forward stage fused with the global load and (PASSB) the twist.
-template <class P, bool VEC, bool PASSB>
-__device__ __forceinline__ void fwd_first_stage(cd* __restrict__ lds, const cd* __restrict__ tw2,
-                                                const double* __restrict__ col, long ld_row,
-                                                int T, bool has2, int tid, int flags = 0) {
-    using SI = StageInfo<P, 0>;
-    cd v[SI::K][SI::R];
-    // all of the thread's loads first: K*R independent requests in flight
-#pragma unroll
-    for (int m = 0; m < SI::K; ++m) {
-        const int u = tid + m * P::NT;
-#pragma unroll
-        for (int j = 0; j < SI::R; ++j) {
-            const int t = u + j * SI::L;
-            cd z = {0.0, 0.0};
-            if ((SI::TASKS % P::NT == 0 || u < SI::TASKS) && t < T) {
-                if (flags & 1) z = cd{(double)t, 1.0};  // timing diagnostics only
-                else z = load_z<VEC>(col, ld_row, t, has2);
-            }
-            v[m][j] = z;
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < SI::K; ++m) {
-        const int u = tid + m * P::NT;
-        if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
-            if constexpr (PASSB) {
-                // lane-uniform part of the twist: W_{2 R0}^j = tw2[j * L]
-#pragma unroll
-                for (int j = 1; j < SI::R; ++j) v[m][j] = cmul(v[m][j], tw2[j * SI::L]);
-            }
-            Dft<SI::R>::run(v[m]);
-#pragma unroll
-            for (int q = PASSB ? 0 : 1; q < SI::R; ++q)
-                v[m][q] = cmul(v[m][q], tw2[u * (2 * q + (PASSB ? 1 : 0))]);
-#pragma unroll
-            for (int q = 0; q < SI::R; ++q) lds[sw(u + q * SI::L)] = v[m][q];
-        }
-    }
-}
-
-// Last forward stage fused with |.|^2 accumulation into registers.
-template <class P>
-__device__ __forceinline__ void fwd_last_stage_acc(
-    const cd* __restrict__ lds,
-    double (&acc)[StageInfo<P, P::S - 1>::K][StageInfo<P, P::S - 1>::R], int tid) {
-    using SI = StageInfo<P, P::S - 1>;
-    static_assert(SI::L == 1, "last stage must have unit stride");
-#pragma unroll
-    for (int m = 0; m < SI::K; ++m) {
-        const int u = tid + m * P::NT;
-        if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
-            cd v[SI::R];
-#pragma unroll
-            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(u * SI::R + j)];
-            Dft<SI::R>::run(v);
-#pragma unroll
-            for (int q = 0; q < SI::R; ++q) acc[m][q] += norm2(v[q]);
-        }
-        // one butterfly at a time in registers (IR-level and machine-level fence)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// One full forward pass (A or B) of one column pair, accumulated into acc.
-template <class P, bool VEC, bool PASSB>
-__device__ __forceinline__ void forward_pass_acc(
-    cd* lds, const cd* tw2, const double* col, long ld_row, int T, bool has2,
-    double (&acc)[StageInfo<P, P::S - 1>::K][StageInfo<P, P::S - 1>::R], int tid, int flags = 0) {
-    // The per-thread twiddles are the same for every column pair; left alone, LICM
-    // hoists ~50 complex values per thread out of the pair loop and spills them.
-    // Laundering the (wave-uniform) table pointer keeps them as L1/L2-served loads.
-    // Same for the per-lane gather addresses and table offsets (all functions of
-    // tid and ld_row only): recomputing them per pass is cheaper than spilling.
-    asm volatile("" : "+s"(tw2), "+s"(ld_row), "+v"(tid));
-    fwd_first_stage<P, VEC, PASSB>(lds, tw2, col, ld_row, T, has2, tid, flags);
-    __syncthreads();
-    if (flags & 2) return;  // timing diagnostics only: load + first stage
-    fwd_mid_stages<P, 1>(lds, tw2, tid);
-    fwd_last_stage_acc<P>(lds, acc, tid);
-    __syncthreads();
-}
-
-// ---- K1+K2: accumulate power spectra over column pairs ------------------------
-// Persistent workgroups, one wave per SIMD-slot budget (NT = M/40 or M/32 threads,
-// up to 512 VGPRs).  A workgroup gathers a column pair ONCE into registers and runs
-// both passes from them (A: even bins, B: odd bins), so every input element is
-// requested from L2 once; workgroups of one XCD (blockIdx % 8) take consecutive
-// pairs, so the 8 pairs sharing a 128-byte line are read through the same L2.
-//
-// Software pipeline per pair:
-//   wait(v) -> first stage A (v kept) -> mid/last A -> first stage B (v consumed)
-//   -> issue gather of the NEXT pair into v -> mid/last B (covers the gather)
-// The mid stages take their twiddles from per-thread seeds in registers and the
-// last stage works on LDS only: no VMEM between the prefetch and its use, so no
-// s_waitcnt vmcnt drains it early.
-//
-// partial: [2][gridDim.x][P::M] float64 in the transform's digit-reversed bin order.
 // ---- K1+K2: accumulate power spectra over column pairs ------------------------
 //
 // Register plan.  At one wave per SIMD a wave owns 512 registers, of which VALU
@@ -205,9 +89,11 @@ __device__ __forceinline__ void ag_write_f64(double x) {
 // Rows past the end (t >= T, the zero padding) re-read row T-1 and are zeroed when the
 // registers are read, so the loads are branch-free.  Non-VEC (rows not 16-byte aligned or
 // an odd last column): two 8-byte loads, or one plus a zero imaginary part.
+// kind (wave-uniform, non-VEC kernels): 0 = one column (imaginary part zero), 1 = two columns,
+// two 8-byte loads, 2 = two columns at a 16-byte aligned address, one load.
 template <class P, bool VEC, int LO, int HI>
 __device__ __forceinline__ void gather_issue_range(const double* __restrict__ col, long ld_row,
-                                                   int T, bool has2, int tid) {
+                                                   int T, int kind, int tid) {
     using SI = StageInfo<P, 0>;
     // compute this piece's addresses here and now (hoisted out, the 40 row addresses of a
     // pair would occupy 80 VGPRs for the whole pass)
@@ -221,9 +107,11 @@ __device__ __forceinline__ void gather_issue_range(const double* __restrict__ co
             const double* p = col + (long)tc * ld_row;
             if constexpr (VEC) {
                 ag_load4<agpr_base<P>() + 4 * f>(p);
+            } else if (kind == 2) {
+                ag_load4<agpr_base<P>() + 4 * f>(p);
             } else {
                 ag_load2<agpr_base<P>() + 4 * f>(p);
-                if (has2) {
+                if (kind == 1) {
                     ag_load2<agpr_base<P>() + 4 * f + 2>(p + 1);
                 } else {
                     AG<agpr_base<P>() + 4 * f + 2>::w(0u);
@@ -233,10 +121,6 @@ __device__ __forceinline__ void gather_issue_range(const double* __restrict__ co
         }
     });
 }
-
-// number of VMEM instructions gather_issue_range issues per element
-template <bool VEC>
-constexpr int loads_per_elem() { return VEC ? 1 : 2; }
 
 // First stage from the parked pair (read-only: pass B reads it again).
 template <class P, bool PASSB, class Hook>
@@ -423,7 +307,7 @@ __device__ __forceinline__ double lag_value(const cd* __restrict__ lds,
     const cd b = {0.5 * (qn.y + qm.y), -0.5 * (qn.x - qm.x)};
     const cd w = tw2[n];  // exp(-i pi n / M); need its conjugate
     const double re = a.x + (b.x * w.x + b.y * w.y);
-    return re / (2.0 * (double)P::M) / (double)(T - n);
+    return re / (2.0 * (double)P::M * (double)(T - n));  // 2M(T-n) < 2^53: exact product
 }
 
 // STAMP (diagnostic builds only): lane 0 accumulates s_memtime deltas per phase.
@@ -514,16 +398,33 @@ __global__ void __launch_bounds__(P::NT)
     const int ppa = BYP ? (D + 1) / 2 : 1;
     const long n_mine = BYP ? (slot < n_atoms ? ((n_atoms - slot + nwg - 1) / nwg) * ppa : 0)
                             : ((n_cols + 1) / 2 > slot ? ((n_cols + 1) / 2 - slot + nwg - 1) / nwg : 0);
+    // BYP, D = 3: the two-column unit is the 16-byte ALIGNED pair of the atom's three columns,
+    // (x,y) for even atoms and (y,z) for odd ones (the sum over the atom's columns does not
+    // care), so it is one load per row whenever the slab itself is 16-byte aligned.
+    const bool slab16 = ((reinterpret_cast<unsigned long long>(vel) | ((unsigned long long)ld_row * 8)) & 15) == 0;
     auto unit_col = [&](long i) -> const double* {
-        if constexpr (BYP) return vel + (slot + (i / ppa) * nwg) * D + 2 * (i % ppa);
-        else return vel + (slot + i * nwg) * pair_stride;
+        if constexpr (BYP) {
+            const long atom = slot + (i / ppa) * nwg;
+            if (D == 3) {
+                const int odd = (int)(atom & 1);
+                return vel + atom * 3 + ((i % ppa) == 0 ? odd : (odd ? 0 : 2));
+            }
+            return vel + atom * D;
+        } else {
+            return vel + (slot + i * nwg) * pair_stride;
+        }
     };
-    auto unit_has2 = [&](long i) -> bool {
-        if constexpr (BYP) return 2 * (int)(i % ppa) + 1 < D;
-        else return 2 * (slot + i * nwg) + 1 < n_cols;
+    auto unit_kind = [&](long i) -> int {
+        if constexpr (BYP) {
+            if (D == 3) return (i % ppa) == 0 ? (slab16 ? 2 : 1) : 0;
+            if (D == 2) return slab16 ? 2 : 1;
+            return 0;
+        } else {
+            return 2 * (slot + i * nwg) + 1 < n_cols ? 1 : 0;
+        }
     };
     long unit = 0;
-    if (unit < n_mine) gather_issue_range<P, VEC, 0, NLOAD>(unit_col(0), ld_row, T, unit_has2(0), tid);
+    if (unit < n_mine) gather_issue_range<P, VEC, 0, NLOAD>(unit_col(0), ld_row, T, unit_kind(0), tid);
     auto no_hook = [](int) {};
     while (unit < n_mine) {
         // per-lane addresses and table offsets depend on tid/ld_row only: keep LICM from
@@ -548,7 +449,7 @@ __global__ void __launch_bounds__(P::NT)
         const long next = unit + 1;
         const bool more = next < n_mine;
         const double* ncol = unit_col(more ? next : unit);
-        const bool nhas2 = unit_has2(more ? next : unit);
+        const int nkind = unit_kind(more ? next : unit);
         auto hook = [&](int slot_) {
             if (more) {
 #define TA_LO(S) ((S) <= S0::K ? (S)*UNIT                                                   \
@@ -556,7 +457,7 @@ __global__ void __launch_bounds__(P::NT)
                                            : S0::K * UNIT + MIDSLOTS * 2 * UNIT + ((S)-S0::K - MIDSLOTS) * UNIT)
 #define TA_PIECE(S)                                                                         \
     if (slot_ == S)                                                                         \
-        gather_issue_range<P, VEC, TA_LO(S), TA_LO((S) + 1)>(ncol, ld_row, T, nhas2, tid);
+        gather_issue_range<P, VEC, TA_LO(S), TA_LO((S) + 1)>(ncol, ld_row, T, nkind, tid);
                 TA_PIECE(0) TA_PIECE(1) TA_PIECE(2) TA_PIECE(3) TA_PIECE(4) TA_PIECE(5)
                 TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
                 TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)
@@ -584,12 +485,13 @@ __global__ void __launch_bounds__(P::NT)
             __syncthreads();
             acc_swap_in<P>(blkB, tid);
             constexpr int PER2 = (NLOAD + MIDSLOTS + SL::K - 1) / (MIDSLOTS + SL::K);
-            constexpr int MID_VMEM = MIDSLOTS * PER2 * loads_per_elem<VEC>();
+            constexpr int MID_VMEM1 = MIDSLOTS * PER2;      // one load per element
+            constexpr int MID_VMEM2 = 2 * MIDSLOTS * PER2;  // two 8-byte loads per element
             auto hook2 = [&](int slot_) {
                 if (more) {
 #define TA_PIECE(S)                                                                          \
     if (slot_ == S)                                                                          \
-        gather_issue_range<P, VEC, (S)*PER2, ((S) + 1) * PER2>(ncol, ld_row, T, nhas2, tid);
+        gather_issue_range<P, VEC, (S)*PER2, ((S) + 1) * PER2>(ncol, ld_row, T, nkind, tid);
                     TA_PIECE(0) TA_PIECE(1) TA_PIECE(2) TA_PIECE(3) TA_PIECE(4) TA_PIECE(5)
                     TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
                     TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)
@@ -599,8 +501,11 @@ __global__ void __launch_bounds__(P::NT)
             };
             mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, hook2);
             TA_STAMP(4)
-            if (more && (VEC || nhas2) && MID_VMEM < 64 && MIDSLOTS * PER2 <= NLOAD)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MID_VMEM < 64 ? MID_VMEM : 0) : "memory");
+            const bool two_loads = !VEC && nkind == 1;
+            if (more && MIDSLOTS * PER2 <= NLOAD && !two_loads && MID_VMEM1 < 64)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MID_VMEM1 < 64 ? MID_VMEM1 : 0) : "memory");
+            else if (more && MIDSLOTS * PER2 <= NLOAD && two_loads && MID_VMEM2 < 64)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MID_VMEM2 < 64 ? MID_VMEM2 : 0) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             last_stage_acc_agpr<P>(lds, tid, [&](int m) { hook2(MIDSLOTS + m); });
