@@ -259,8 +259,78 @@ __device__ __forceinline__ void inv_stage_lds(cd* __restrict__ lds, const cd* __
 }
 
 template <class P, int s>
+constexpr bool stage_seedable() {
+    return StageInfo<P, s>::L > 1 && (P::NT % StageInfo<P, s>::L == 0);
+}
+
+// Inverse stage without strided table gathers (15 scattered 16-byte loads per radix-16
+// butterfly are L2-request-bound): a seedable stage forms conj(W^{q b}) = conj(seed)^q from
+// one table entry per thread, like the forward pass; stage 0 (run last, b = u) reads the
+// forward pass-A first-stage table [q][u] = W_M^{q u} at tw2 + 2M, lane-contiguous.
+template <class P, int s>
+__device__ __forceinline__ void inv_stage_lds_fast(cd* __restrict__ lds,
+                                                   const cd* __restrict__ tw2, int tid) {
+    using SI = StageInfo<P, s>;
+    if constexpr (s == 0 && SI::L > 1) {
+        const cd* __restrict__ tbl = tw2 + 2 * P::M;
+#pragma unroll 1
+        for (int m = 0; m < SI::K; ++m) {
+            const int u = tid + m * P::NT;
+            if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
+                cd v[SI::R];
+                TA_AGPR_FENCE_HOOK();
+#pragma unroll
+                for (int q = 0; q < SI::R; ++q) v[q] = lds[sw(u + q * SI::L)];
+#pragma unroll
+                for (int q = 1; q < SI::R; ++q) v[q] = cmulc(v[q], tbl[q * SI::L + u]);
+                TA_AGPR_FENCE_HOOK();
+                idft<SI::R>(v);
+                TA_AGPR_FENCE_HOOK();
+#pragma unroll
+                for (int j = 0; j < SI::R; ++j) lds[sw(u + j * SI::L)] = v[j];
+            }
+        }
+    } else if constexpr (stage_seedable<P, s>()) {
+        const cd seed = tw2[(tid % SI::L) * SI::TWSTEP];
+        const cd seed2 = cmul(seed, seed);
+#pragma unroll 1
+        for (int m = 0; m < SI::K; ++m) {
+            const int u = tid + m * P::NT;
+            if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
+                const int blk = u / SI::L, b = u - blk * SI::L;
+                const int base = blk * SI::N + b;
+                cd v[SI::R];
+                TA_AGPR_FENCE_HOOK();
+#pragma unroll
+                for (int q = 0; q < SI::R; ++q) v[q] = lds[sw(base + q * SI::L)];
+                cd wo = seed, we = seed2;  // seed^q for the current odd / even q
+                v[1] = cmulc(v[1], wo);
+                if constexpr (SI::R > 2) v[2] = cmulc(v[2], we);
+#pragma unroll
+                for (int q = 3; q < SI::R; ++q) {
+                    if (q & 1) {
+                        wo = cmul(wo, seed2);
+                        v[q] = cmulc(v[q], wo);
+                    } else {
+                        we = cmul(we, seed2);
+                        v[q] = cmulc(v[q], we);
+                    }
+                }
+                TA_AGPR_FENCE_HOOK();
+                idft<SI::R>(v);
+                TA_AGPR_FENCE_HOOK();
+#pragma unroll
+                for (int j = 0; j < SI::R; ++j) lds[sw(base + j * SI::L)] = v[j];
+            }
+        }
+    } else {
+        inv_stage_lds<P, s>(lds, tw2, tid);
+    }
+}
+
+template <class P, int s>
 __device__ __forceinline__ void inv_all_stages(cd* lds, const cd* tw2, int tid) {
-    inv_stage_lds<P, s>(lds, tw2, tid);
+    inv_stage_lds_fast<P, s>(lds, tw2, tid);
     __syncthreads();
     if constexpr (s > 0) inv_all_stages<P, s - 1>(lds, tw2, tid);
 }
@@ -315,11 +385,6 @@ __device__ __forceinline__ void fwd_stage_lds_seeded(cd* __restrict__ lds, cd se
         after_task(m);
         __builtin_amdgcn_sched_barrier(0);
     }
-}
-
-template <class P, int s>
-constexpr bool stage_seedable() {
-    return StageInfo<P, s>::L > 1 && (P::NT % StageInfo<P, s>::L == 0);
 }
 
 }  // namespace ta
