@@ -61,7 +61,7 @@ def cpu_baseline(args, T, D):
     except Exception:
         pass
     if args.mode == "fft":
-        a = args.cpu_sample_atoms or max(8, int(3.0e7 // T))  # ~10-20 s of CPU work
+        a = args.cpu_sample_atoms or max(8, int(8.0e7 // T))  # ~10-15 s of CPU work
         v = orc.synthetic_velocities(T, a, D, seed=20250824 + 3)
         t0 = time.perf_counter()
         orc.vacf_fft(v)
