@@ -37,6 +37,74 @@ __global__ void __launch_bounds__(NT) k_gather(const double* __restrict__ base, 
     out[(long)blockIdx.x * NT + tid] = acc;
 }
 
+// Same gather with a soft grid-wide barrier every `every` column groups: all workgroups then
+// fetch the same rows at about the same time (DRAM row-buffer locality across workgroups).
+// The spin has an iteration cap, so a missing workgroup can delay but never hang the grid.
+template <int NT, int UNROLL, int WIDTH>
+__global__ void __launch_bounds__(NT) k_gather_sync(const double* __restrict__ base, long ld, int T,
+                                                    long n_groups, double* __restrict__ out,
+                                                    unsigned* __restrict__ counter, int every) {
+    double acc = 0.0;
+    const int tid = threadIdx.x;
+    const int nwg = gridDim.x;
+    long slot = blockIdx.x;
+    if (nwg % 8 == 0) slot = (long)(blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    unsigned round = 0;
+    for (long g = slot; g < n_groups; g += nwg) {
+        if (every > 0 && (round % every) == 0) {
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned want = (round / every + 1) * (unsigned)nwg;
+                for (int spin = 0; spin < 200000; ++spin) {
+                    if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __syncthreads();
+        }
+        ++round;
+        const double* col = base + g * WIDTH;
+        for (int t0 = 0; t0 < T; t0 += NT * UNROLL) {
+            double2 v[UNROLL][WIDTH / 2];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                int t = t0 + tid + k * NT;
+                t = t < T ? t : T - 1;
+                const double2* p = reinterpret_cast<const double2*>(col + (long)t * ld);
+#pragma unroll
+                for (int w = 0; w < WIDTH / 2; ++w) v[k][w] = p[w];
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k)
+#pragma unroll
+                for (int w = 0; w < WIDTH / 2; ++w) acc += v[k][w].x + v[k][w].y;
+        }
+    }
+    out[(long)blockIdx.x * NT + tid] = acc;
+}
+
+template <int NT, int UNROLL, int WIDTH>
+void run_sync(const double* d, long ld, int T, long C, int wg_per_cu, double* out, int every) {
+    const long n_groups = C / WIDTH;
+    int nwg = 256 * wg_per_cu;
+    unsigned* counter; CK(hipMalloc(&counter, 64));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9;
+    for (int r = 0; r < 3; ++r) {
+        CK(hipMemset(counter, 0, 64));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_gather_sync<NT, UNROLL, WIDTH>), dim3(nwg), dim3(NT), 0, 0, d, ld, T, n_groups, out, counter, every);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double bytes = (double)T * C * 8;
+    printf("SYNC every=%d NT=%4d unroll=%2d width=%3dB wg/cu=%d : %8.3f ms  %7.1f GB/s useful\n", every, NT, UNROLL,
+           WIDTH * 8, wg_per_cu, best, bytes / best / 1e6);
+    CK(hipFree(counter));
+}
+
 template <int NT, int UNROLL, int WIDTH>
 void run(const double* d, long ld, int T, long C, int wg_per_cu, double* out) {
     const long n_groups = C / WIDTH;
@@ -64,6 +132,12 @@ int main(int argc, char** argv) {
     CK(hipMemset(d, 0, sizeof(double) * T * C));
     double* out; CK(hipMalloc(&out, sizeof(double) * 256 * 8 * 1024));
     printf("T=%d C=%ld (%.2f GB)\n", T, C, T * C * 8 / 1e9);
+    run_sync<256, 20, 2>(d, C, T, C, 1, out, 0);
+    run_sync<256, 20, 2>(d, C, T, C, 1, out, 1);
+    run_sync<256, 20, 2>(d, C, T, C, 1, out, 4);
+    run_sync<256, 20, 2>(d, C, T, C, 1, out, 16);
+    run_sync<512, 20, 2>(d, C, T, C, 1, out, 1);
+    run_sync<1024, 10, 2>(d, C, T, C, 1, out, 1);
     run<256, 8, 2>(d, C, T, C, 1, out);
     run<256, 20, 2>(d, C, T, C, 1, out);
     run<256, 40, 2>(d, C, T, C, 1, out);

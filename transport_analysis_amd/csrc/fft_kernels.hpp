@@ -356,6 +356,7 @@ __global__ void __launch_bounds__(P::NT)
     static_assert(P::S <= 5, "seed array sized for S <= 5");
     static_assert(agpr_acc_base<P>() + acc_quads<P>() * 4 <= 256, "manual AGPR slots exceed a255");
     static_assert(agpr_base<P>() >= 16, "leave at least a0..a15 to the compiler");
+    asm volatile("; TA_AGPR_MANUAL_RANGE %0 %1" ::"n"(agpr_base<P>()), "n"(256));  // tools/check_agpr.py
     constexpr long ACC_BLK = (long)acc_quads<P>() * 2 * P::NT;
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_prev = 0;

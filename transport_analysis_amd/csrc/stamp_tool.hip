@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), lds, 0, vel, C, 2L, T, C, d_tw, partial, 0, st);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), lds, 0, vel, C, 2L, T, C, d_tw, partial, 0, st, 0, 0L, (double*)nullptr, 0L);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("rep %d: %.3f ms\n", rep, ms);
