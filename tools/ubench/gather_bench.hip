@@ -37,6 +37,37 @@ __global__ void __launch_bounds__(NT) k_gather(const double* __restrict__ base, 
     out[(long)blockIdx.x * NT + tid] = acc;
 }
 
+// Same with non-temporal loads (nt cache policy).
+template <int NT, int UNROLL, int WIDTH>  // WIDTH = doubles per lane per row (2, 4, 8, 16)
+__global__ void __launch_bounds__(NT) k_gather_nt(const double* __restrict__ base, long ld, int T,
+                                               long n_groups, double* __restrict__ out) {
+    double acc = 0.0;
+    const int tid = threadIdx.x;
+    // XCD-aware: blocks sharing an XCD take adjacent column groups
+    const int nwg = gridDim.x;
+    long slot = blockIdx.x;
+    if (nwg % 8 == 0) slot = (long)(blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8;
+    for (long g = slot; g < n_groups; g += nwg) {
+        const double* col = base + g * WIDTH;
+        for (int t0 = 0; t0 < T; t0 += NT * UNROLL) {
+            double2 v[UNROLL][WIDTH / 2];
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k) {
+                int t = t0 + tid + k * NT;
+                t = t < T ? t : T - 1;
+                const double2* p = reinterpret_cast<const double2*>(col + (long)t * ld);
+#pragma unroll
+                for (int w = 0; w < WIDTH / 2; ++w) { typedef double d2v __attribute__((ext_vector_type(2))); const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(&p[w])); v[k][w].x = t.x; v[k][w].y = t.y; }
+            }
+#pragma unroll
+            for (int k = 0; k < UNROLL; ++k)
+#pragma unroll
+                for (int w = 0; w < WIDTH / 2; ++w) acc += v[k][w].x + v[k][w].y;
+        }
+    }
+    out[(long)blockIdx.x * NT + tid] = acc;
+}
+
 // Same gather with a soft grid-wide barrier every `every` column groups: all workgroups then
 // fetch the same rows at about the same time (DRAM row-buffer locality across workgroups).
 // The spin has an iteration cap, so a missing workgroup can delay but never hang the grid.
@@ -132,6 +163,19 @@ int main(int argc, char** argv) {
     CK(hipMemset(d, 0, sizeof(double) * T * C));
     double* out; CK(hipMalloc(&out, sizeof(double) * 256 * 8 * 1024));
     printf("T=%d C=%ld (%.2f GB)\n", T, C, T * C * 8 / 1e9);
+    {
+        const long n_groups = C / 2;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        float best = 1e9;
+        for (int r = 0; r < 3; ++r) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL((k_gather_nt<256, 20, 2>), dim3(256), dim3(256), 0, 0, d, C, T, n_groups, out);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        printf("NT loads NT=256 unroll=20 width=16B : %8.3f ms  %7.1f GB/s useful\n", best, (double)T * C * 8 / best / 1e6);
+    }
     run_sync<256, 20, 2>(d, C, T, C, 1, out, 0);
     run_sync<256, 20, 2>(d, C, T, C, 1, out, 1);
     run_sync<256, 20, 2>(d, C, T, C, 1, out, 4);
