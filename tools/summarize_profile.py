@@ -9,7 +9,7 @@ import sys
 
 
 def short(name):
-    for key in ("k_fft_accum", "k_fft_finalize", "k_fft_by_particle", "k_direct", "k_sum_partials",
+    for key in ("k_fft_accum", "k_fft_finalize", "k_row_sums", "k_direct", "k_sum_partials",
                 "k_widen_f32"):
         if key in name:
             return key
