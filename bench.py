@@ -95,7 +95,7 @@ def cpu_baseline(args, T, D):
         n = len(all_cpus) if all_cpus else (os.cpu_count() or 1)
         t0 = time.perf_counter()
         if args.mode == "fft":
-            c_oracle.vacf_fft(v, n_threads=n)
+            c_oracle.vacf_fft_lagsum(v, n_threads=n)
         elif args.mode == "direct":
             c_oracle.vacf_windowed(v, n_threads=n)
         else:

@@ -129,6 +129,82 @@ int oracle_vacf_fft(const double *v, long T, long A, long D, double *by_particle
     return 0;
 }
 
+/* Throughput variant of oracle_vacf_fft for bench.py's all-cores CPU line: same arithmetic per
+ * column (tidynamics padding, full complex FFT, |F|^2, inverse, / (N - lag)), but only the
+ * lag-indexed SUM over atoms is produced (no (T, A) array), atoms are taken in blocks whose
+ * columns are first copied out of the (T, A, D) slab row by row (contiguous reads instead of
+ * one cache miss per sample), and the twiddles come from a per-thread table.  */
+static void fft_radix2_tab(double *re, double *im, long n, int sign, const double *cs) {
+    for (long i = 1, j = 0; i < n; ++i) {
+        long bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            double t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+    }
+    for (long len = 2; len <= n; len <<= 1) {
+        long half = len >> 1, step = n / len;
+        for (long s0 = 0; s0 < n; s0 += len)
+            for (long k = 0; k < half; ++k) {
+                double wr = cs[2 * k * step], wi = sign * cs[2 * k * step + 1];
+                long s = s0 + k, t = s + half;
+                double xr = re[t] * wr - im[t] * wi;
+                double xi = re[t] * wi + im[t] * wr;
+                re[t] = re[s] - xr; im[t] = im[s] - xi;
+                re[s] += xr;        im[s] += xi;
+            }
+    }
+}
+
+int oracle_vacf_fft_lagsum(const double *v, long T, long A, long D, double *lagsum,
+                           int n_threads) {
+    enum { BLK = 8 };
+    long L = 2 * tidynamics_n_fft(T);
+    int fail = 0;
+    for (long k = 0; k < T; ++k) lagsum[k] = 0.0;
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+    {
+        double *re = (double *)malloc(sizeof(double) * L);
+        double *im = (double *)malloc(sizeof(double) * L);
+        double *cs = (double *)malloc(sizeof(double) * L);          /* (cos, sin) of 2 pi k / L */
+        double *cols = (double *)malloc(sizeof(double) * BLK * D * T);
+        double *mine = (double *)calloc((size_t)T, sizeof(double));
+        if (!re || !im || !cs || !cols || !mine) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+            for (long k = 0; k < L / 2; ++k) {
+                cs[2 * k] = cos(2.0 * M_PI * (double)k / (double)L);
+                cs[2 * k + 1] = sin(2.0 * M_PI * (double)k / (double)L);
+            }
+#pragma omp for schedule(dynamic, 1)
+            for (long n0 = 0; n0 < A; n0 += BLK) {
+                long nb = A - n0 < BLK ? A - n0 : BLK, w = nb * D;
+                for (long i = 0; i < T; ++i)
+                    for (long c = 0; c < w; ++c) cols[c * T + i] = v[(i * A + n0) * D + c];
+                for (long c = 0; c < w; ++c) {
+                    memset(re, 0, sizeof(double) * L);
+                    memset(im, 0, sizeof(double) * L);
+                    memcpy(re, cols + c * T, sizeof(double) * T);
+                    fft_radix2_tab(re, im, L, -1, cs);
+                    for (long k = 0; k < L; ++k) {
+                        re[k] = re[k] * re[k] + im[k] * im[k];
+                        im[k] = 0.0;
+                    }
+                    fft_radix2_tab(re, im, L, +1, cs);
+                    for (long k = 0; k < T; ++k) mine[k] += (re[k] / (double)L) / (double)(T - k);
+                }
+            }
+#pragma omp critical
+            for (long k = 0; k < T; ++k) lagsum[k] += mine[k];
+        }
+        free(re); free(im); free(cs); free(cols); free(mine);
+    }
+    return fail ? -1 : 0;
+}
+
 /* viscosity.py:205-233.  diff = (m*v)*x at frame i minus (m*v)*x at i+lag,
  * squared, MEAN over dims, mean over the T-lag frame pairs; lag 0 stays 0;
  * everything divided by 2*kB*mean(volumes)*temp_avg. */

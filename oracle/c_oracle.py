@@ -25,6 +25,7 @@ def lib():
         L = ctypes.c_long
         _lib.oracle_vacf_windowed.argtypes = [dp, L, L, L, dp, dp, ctypes.c_int]
         _lib.oracle_vacf_fft.argtypes = [dp, L, L, L, dp, dp, ctypes.c_int]
+        _lib.oracle_vacf_fft_lagsum.argtypes = [dp, L, L, L, dp, ctypes.c_int]
         _lib.oracle_helfand.argtypes = [dp, dp, dp, dp, L, L, L, ctypes.c_double,
                                         ctypes.c_double, dp, dp, ctypes.c_int]
     return _lib
@@ -51,6 +52,17 @@ def vacf_windowed(v, n_threads=1):
 
 def vacf_fft(v, n_threads=1):
     return _vacf(lib().oracle_vacf_fft, v, n_threads)
+
+
+def vacf_fft_lagsum(v, n_threads=1):
+    """Sum over atoms of the per-atom FFT VACF (throughput variant for bench.py's CPU line)."""
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    T, A, D = v.shape
+    out = np.zeros(T)
+    rc = lib().oracle_vacf_fft_lagsum(_p(v), T, A, D, _p(out), n_threads)
+    if rc != 0:
+        raise RuntimeError(f"oracle returned {rc}")
+    return out
 
 
 def helfand(v, x, masses, volumes, temp_avg=300.0, boltzmann=8.314462159e-3, n_threads=1):

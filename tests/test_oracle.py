@@ -156,6 +156,9 @@ def test_c_oracle_vacf(tag):
     bp, ts = c_oracle.vacf_fft(v, n_threads=2)
     assert scale_rel_err(bp, g(f"ref_vacf_fft_bp_{tag}.npy")) < 1e-13
     assert scale_rel_err(ts, g(f"ref_vacf_fft_ts_{tag}.npy")) < 1e-13
+    # throughput variant used by bench.py's all-cores CPU line: same numbers, lag sums only
+    lagsum = c_oracle.vacf_fft_lagsum(v, n_threads=3)
+    assert scale_rel_err(lagsum / v.shape[1], g(f"ref_vacf_fft_ts_{tag}.npy")) < 1e-13
 
 
 @pytest.mark.parametrize("tag", ["T9_A1_D1", "T50_A6_D2", "T120_A17_D3"])
