@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""Diagnostic: kernel time of the FFT by-particle path (10000 x 20000 x 3)."""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from transport_analysis_amd import _lib
 T, A, D = 10000, 20000, 3
@@ -7,7 +9,7 @@ vel = torch.randn((T, A, D), dtype=torch.float64, device="cuda")
 out = torch.zeros(T, dtype=torch.float64, device="cuda")
 bp = torch.zeros((T, A), dtype=torch.float64, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-for flags in (0, 4, 8, 12):
+for flags in (0,):
     ctx = _lib.Context(0)
     ctx.set_option("fft_debug", flags)
     best = 1e9
