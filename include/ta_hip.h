@@ -24,9 +24,12 @@
  *     velocityautocorr.py:145-147, viscosity.py:117-119); pass NULL to skip.
  *   - pointers named d_* are DEVICE pointers valid on the context's GPU;
  *     pointers named h_* are host pointers.
- *   - `stream` is a hipStream_t (void*); NULL = the context's own stream.
- *     The *_dev entry points are asynchronous on that stream; host-facing
- *     entry points block until results are in the host buffers.
+ *   - `stream` is a hipStream_t (void*); NULL = the legacy default (null) stream, exactly
+ *     as for a HIP runtime call, so work queued by the caller on its default stream
+ *     (PyTorch's default stream is the null stream) is ordered with the library's.
+ *     The *_dev entry points are asynchronous on that stream; host-facing entry points
+ *     run on a private non-blocking stream of the context and block until results are
+ *     in the host buffers.
  *   - one context per analysis object; calls on one context are not re-entrant.
  *   - there is NO CPU fallback: without a usable GPU ta_ctx_create fails.
  */

@@ -301,6 +301,85 @@ def test_vacf_config2_full_size(ctx):
     assert scale_rel_err(tsd, want_ts) < TOL
 
 
+def _torch_lags(v, lags):
+    """sum over atoms and dims of <v(t) v(t+k)>, by slab products on the GPU (float64)."""
+    T = v.shape[0]
+    return [float((v[: T - k] * v[k:]).sum().item()) / (T - k) for k in lags]
+
+
+@pytest.mark.parametrize("mode,T,A", [("fft", 10000, 100000), ("direct", 5000, 50000)])
+def test_vacf_baseline_full_size_properties(ctx, mode, T, A):
+    """BASELINE configs[2] (FFT, 10000 x 100000 x 3) and configs[3] (windowed, 5000 x 50000 x 3)
+    at FULL size through the device-pointer entry points, checked by size-independent
+    properties: selected lags against slab products, lag 0 = mean squared speed, the two
+    algorithms agree, and v -> 2v gives EXACTLY 4x (power-of-two scaling is exact in binary
+    floating point through every step of both algorithms)."""
+    import torch
+
+    D = 3
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(20250824 + (3 if mode == "fft" else 4))
+    v = torch.randn((T, A, D), dtype=torch.float64, device="cuda", generator=gen)
+    st = torch.cuda.current_stream().cuda_stream
+    call = ctx.vacf_fft_dev if mode == "fft" else ctx.vacf_direct_dev
+    lag1 = torch.zeros(T, dtype=torch.float64, device="cuda")
+    call(v.data_ptr(), T, A, D, A * D, lag1.data_ptr(), 0, 0, st)
+    torch.cuda.synchronize()
+    lags = [0, 1, 2, 7, T // 3, T // 2, T - 2, T - 1]
+    want = _torch_lags(v, lags)
+    scale = want[0]
+    for k, w in zip(lags, want):
+        assert abs(float(lag1[k].item()) - w) < TOL * scale, (k, float(lag1[k].item()), w)
+    v *= 2.0
+    lag2 = torch.zeros(T, dtype=torch.float64, device="cuda")
+    call(v.data_ptr(), T, A, D, A * D, lag2.data_ptr(), 0, 0, st)
+    torch.cuda.synchronize()
+    assert torch.equal(lag2, 4.0 * lag1)
+    if mode == "direct":  # the other algorithm on the same data (the reference asserts equality)
+        lag3 = torch.zeros(T, dtype=torch.float64, device="cuda")
+        ctx.vacf_fft_dev(v.data_ptr(), T, A, D, A * D, lag3.data_ptr(), 0, 0, st)
+        torch.cuda.synchronize()
+        assert float((lag3 - lag2).abs().max().item()) < TOL * 4.0 * scale
+    del v
+    torch.cuda.empty_cache()
+
+
+def test_helfand_float32_baseline_shape_properties(ctx):
+    """BASELINE configs[4]'s per-GPU share in time (20000 frames, float32 path) on a 2000-atom
+    block: selected lags against slab differences in float64, lag 0 exactly 0, and the
+    float64 path on the same data within the float32 tolerance."""
+    import torch
+
+    T, A, D = 20000, 2000, 3
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(20250824 + 5)
+    v = torch.randn((T, A, D), dtype=torch.float64, device="cuda", generator=gen)
+    x = 30.0 + 0.002 * torch.cumsum(v, dim=0)
+    m = torch.tensor([15.999, 1.008, 1.008], dtype=torch.float64, device="cuda").repeat((A + 2) // 3)[:A].contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for f32 in (1, 0):
+        ctx.set_option("direct_f32", f32)
+        try:
+            lag = torch.zeros(T, dtype=torch.float64, device="cuda")
+            ctx.helfand_msd_dev(v.data_ptr(), x.data_ptr(), m.data_ptr(), T, A, D, A * D, 1.0,
+                                lag.data_ptr(), 0, 0, st)
+            torch.cuda.synchronize()
+        finally:
+            ctx.set_option("direct_f32", 0)
+        out[f32] = lag
+    P = m[None, :, None] * v * x
+    scale = None
+    for k in (1, 2, 100, T // 2, T - 1):
+        w = float(((P[: T - k] - P[k:]) ** 2).sum().item()) / (T - k) / D
+        scale = scale or w
+        assert abs(float(out[0][k].item()) - w) < TOL * max(w, scale)
+        assert abs(float(out[1][k].item()) - w) < TOL_F32 * max(w, scale)
+    assert float(out[0][0].item()) == 0.0 and float(out[1][0].item()) == 0.0
+    del v, x, P
+    torch.cuda.empty_cache()
+
+
 def test_vacf_linearity_and_lag0(ctx):
     """Size-independent properties: lag 0 equals the mean squared speed; the lag
     sums of two atom blocks add up to the lag sum of their union."""

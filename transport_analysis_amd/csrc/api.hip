@@ -364,7 +364,7 @@ int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int 
     if (!d_vel || !d_lagsum) return fail(ctx, TA_E_INVALID, "null device pointer");
     if (d_bp && ld_bp < A) return fail(ctx, TA_E_INVALID, "ld_bp smaller than n_atoms");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as for any HIP call
     ctx->timing_valid = false;
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     const PlanEntry* plan = find_plan(T);
@@ -443,7 +443,7 @@ int ta_vacf_direct_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, i
     if (!d_vel || !d_lagsum) return fail(ctx, TA_E_INVALID, "null device pointer");
     if (d_bp && ld_bp < A) return fail(ctx, TA_E_INVALID, "ld_bp smaller than n_atoms");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as for any HIP call
     ctx->timing_valid = false;
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     rc = direct_impl(ctx, MODE_VACF, d_vel, nullptr, nullptr, T, A, D, ld_row, 1.0, d_lagsum, d_bp,
@@ -463,7 +463,7 @@ int ta_helfand_msd_dev(ta_ctx* ctx, const double* d_vel, const double* d_pos, co
         return fail(ctx, TA_E_INVALID, "null device pointer");
     if (d_bp && ld_bp < A) return fail(ctx, TA_E_INVALID, "ld_bp smaller than n_atoms");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as for any HIP call
     ctx->timing_valid = false;
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     rc = direct_impl(ctx, MODE_HELFAND, d_vel, d_pos, d_masses, T, A, D, ld_row, scale, d_lagsum,
@@ -505,16 +505,16 @@ static int host_compute(ta_ctx* ctx, int which, const double* h_masses, double s
     }
     double* d_ls = (double*)ctx->out_lagsum.p;
     if (which == 0)
-        rc = ta_vacf_fft_dev(ctx, ctx->d_slabs[0], T, A, D, A * D, d_ls, d_bp, A, nullptr);
+        rc = ta_vacf_fft_dev(ctx, ctx->d_slabs[0], T, A, D, A * D, d_ls, d_bp, A, (void*)ctx->stream);
     else if (which == 1)
-        rc = ta_vacf_direct_dev(ctx, ctx->d_slabs[0], T, A, D, A * D, d_ls, d_bp, A, nullptr);
+        rc = ta_vacf_direct_dev(ctx, ctx->d_slabs[0], T, A, D, A * D, d_ls, d_bp, A, (void*)ctx->stream);
     else {
         if (!h_masses) return fail(ctx, TA_E_INVALID, "h_masses is NULL");
         if ((rc = ensure(ctx, ctx->masses, sizeof(double) * A))) return rc;
         TA_HIP_TRY(ctx, hipMemcpyAsync(ctx->masses.p, h_masses, sizeof(double) * A,
                                        hipMemcpyHostToDevice, ctx->stream));
         rc = ta_helfand_msd_dev(ctx, ctx->d_slabs[0], ctx->d_slabs[1], (const double*)ctx->masses.p,
-                                T, A, D, A * D, scale, d_ls, d_bp, A, nullptr);
+                                T, A, D, A * D, scale, d_ls, d_bp, A, (void*)ctx->stream);
     }
     if (rc) return rc;
     TA_HIP_TRY(ctx, hipMemcpyAsync(h_ts, d_ls, sizeof(double) * T, hipMemcpyDeviceToHost, ctx->stream));
