@@ -122,12 +122,33 @@ __device__ __forceinline__ void gather_issue_range(const double* __restrict__ co
     });
 }
 
+// Table reads that must not become flat loads: after the pointer laundering in the pair loop
+// the compiler no longer knows the address space of tw2 and would emit flat_load + a wait for
+// vmcnt(0) AND lgkmcnt(0), i.e. for every gather load in flight.  Wave-uniform entries go
+// through the constant address space (s_load, counted by lgkmcnt only), per-lane entries
+// through the global one.
+typedef double tw_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cd tw_uniform(const cd* tw2, int idx) {
+    const tw_d2 t = ((const tw_d2 __attribute__((address_space(4)))*)tw2)[idx];
+    return cd{t.x, t.y};
+}
+__device__ __forceinline__ cd tw_lane(const cd* tw2, int idx) {
+    const tw_d2 t = ((const tw_d2 __attribute__((address_space(1)))*)tw2)[idx];
+    return cd{t.x, t.y};
+}
+
 // First stage from the parked pair (read-only: pass B reads it again).
+// Twiddles W_2M^{u(2q+B)}, u = tid + m*NT, without table gathers: g = W^{2u} = W^{2 tid} *
+// W^{2 m NT} and h = W^{uB} = W^{tid B} * W^{m NT B} (per-lane factor loaded once per pass
+// while no gather is in flight, wave-uniform factor by scalar load), then the powers
+// h, h g, h g^2, ... by repeated multiplication (two interleaved chains; <= R0/2 steps each).
 template <class P, bool PASSB, class Hook>
 __device__ __forceinline__ void first_stage_from_agpr(cd* __restrict__ lds,
                                                       const cd* __restrict__ tw2, int T, int tid,
                                                       Hook&& after_task) {
     using SI = StageInfo<P, 0>;
+    const cd G = tw_lane(tw2, 2 * tid);                           // W_2M^{2 tid}
+    const cd H = PASSB ? tw_lane(tw2, tid) : cd{1.0, 0.0};        // W_2M^{tid}
     static_for<SI::K>([&](auto mm) {
         constexpr int m = decltype(mm)::value;
         const int u = tid + m * P::NT;
@@ -143,21 +164,35 @@ __device__ __forceinline__ void first_stage_from_agpr(cd* __restrict__ lds,
             if constexpr (PASSB) {
                 // lane-uniform part of the twist: W_{2 R0}^j = tw2[j * L]
 #pragma unroll
-                for (int j = 1; j < SI::R; ++j) w[j] = cmul(w[j], tw2[j * SI::L]);
+                for (int j = 1; j < SI::R; ++j) w[j] = cmul(w[j], tw_uniform(tw2, j * SI::L));
             }
             agpr_fence<P>();
             Dft<SI::R>::run(w);
             agpr_fence<P>();
-            // W_2M^{u(2q+B)} from the [q][u] first-stage table (coalesced)
-            const cd* __restrict__ tw0 = tw2 + (PASSB ? 3 : 2) * P::M;
+            constexpr int eg = (2 * m * P::NT) % (2 * P::M), eh = (m * P::NT) % (2 * P::M);
+            const cd g = m == 0 ? G : cmul(G, tw_uniform(tw2, eg));
+            cd h = H;
+            if constexpr (PASSB && m > 0) h = cmul(H, tw_uniform(tw2, eh));
+            const cd g2 = cmul(g, g);
+            cd te = h, to = cmul(h, g);  // h g^q for the current even / odd q
+            if constexpr (PASSB) w[0] = cmul(w[0], te);
+            if constexpr (SI::R > 1) w[1] = cmul(w[1], to);
 #pragma unroll
-            for (int q = PASSB ? 0 : 1; q < SI::R; ++q) w[q] = cmul(w[q], tw0[q * SI::L + u]);
+            for (int q = 2; q < SI::R; ++q) {
+                if (q & 1) {
+                    to = cmul(to, g2);
+                    w[q] = cmul(w[q], to);
+                } else {
+                    te = cmul(te, g2);
+                    w[q] = cmul(w[q], te);
+                }
+            }
             agpr_fence<P>();
 #pragma unroll
             for (int q = 0; q < SI::R; ++q) lds[sw(u + q * SI::L)] = w[q];
         }
         agpr_fence<P>();
-        __builtin_amdgcn_sched_barrier(0);  // one butterfly's twiddle loads at a time
+        __builtin_amdgcn_sched_barrier(0);
         after_task(m);  // butterfly m's slots of the parked pair are dead from here on (pass B)
         __builtin_amdgcn_sched_barrier(0);
     });
