@@ -193,6 +193,14 @@ struct Plan {
         return n;
     }
     static constexpr int lds_elems() { return (M + 15) / 16 * 16; }
+    static constexpr bool kLanding = false;  // see WithLanding
+};
+
+// The same plan run with the landing-zone software pipeline of k_fft_accum (fft_kernels.hpp):
+// a property of the kernel instantiation, not of the transform.
+template <class P>
+struct WithLanding : P {
+    static constexpr bool kLanding = true;
 };
 
 template <class P, int s>

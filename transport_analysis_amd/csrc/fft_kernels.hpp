@@ -64,8 +64,24 @@ __device__ __forceinline__ void static_for(F&& f) {
 // lowest free AGPRs and cannot be told that the manual slots are live.  The fences below
 // keep its live ranges out of the manual range and tools/check_agpr.py verifies that at
 // build time.
+//
+// "Landing" plans (one wave per SIMD, NT >= 256): the area after the pair is not an
+// accumulator set but a LANDING ZONE for the first-stage butterflies K0-KL..K0-1 of the NEXT
+// pair (KL = K0/2), filled by gather loads issued during pass A, when the pair area is still
+// needed and the vector-memory pipe would otherwise idle; pass B refills the pair slots of
+// butterflies 0..K0-KL-1 as it frees them and copies the landed half over once its own
+// butterflies K0-KL.. are done.  Half of the gather's pipe time thus moves out of pass B.
+// Both accumulator sets of these plans live in VGPRs while they are used (pass A's set is
+// loaded from / stored to the workgroup's global block around pass A's last stage).
+template <class P>
+constexpr bool landing() { return P::kLanding && P::NT >= 256 && StageInfo<P, 0>::K >= 2; }
+template <class P>
+constexpr int land_tasks() { return landing<P>() ? StageInfo<P, 0>::K / 2 : 0; }
+template <class P>
+constexpr int land_elems() { return land_tasks<P>() * StageInfo<P, 0>::R; }
 template <class P>
 constexpr int agpr_acc_dwords() {
+    if (landing<P>()) return 4 * land_elems<P>();
     return (StageInfo<P, P::S - 1>::K * StageInfo<P, P::S - 1>::R * 2 + 3) / 4 * 4;
 }
 template <class P>
@@ -85,13 +101,20 @@ __device__ __forceinline__ void ag_write_f64(double x) {
     AG<I + 1>::w((unsigned)__double2hiint(x));
 }
 
+template <int D, int S>
+__device__ __forceinline__ void ag_mov() {  // aD = aS
+    asm volatile("v_accvgpr_mov_b32 a[%0], a[%1]" ::"n"(D), "n"(S));
+}
+
 // Issue gather loads [LO, HI) (flat index f = m*R0 + j -> a[4f..4f+3]) of one column pair.
 // Rows past the end (t >= T, the zero padding) re-read row T-1 and are zeroed when the
 // registers are read, so the loads are branch-free.  Non-VEC (rows not 16-byte aligned or
 // an odd last column): two 8-byte loads, or one plus a zero imaginary part.
 // kind (wave-uniform, non-VEC kernels): 0 = one column (imaginary part zero), 1 = two columns,
 // two 8-byte loads, 2 = two columns at a 16-byte aligned address, one load.
-template <class P, bool VEC, int LO, int HI>
+// FMAX: only elements f < FMAX are loaded; DSTOFF: dword offset added to the destination slot
+// (the landing zone is the pair area shifted by 4*land_elems dwords).
+template <class P, bool VEC, int LO, int HI, int FMAX = 1 << 20, int DSTOFF = 0>
 __device__ __forceinline__ void gather_issue_range(const double* __restrict__ col, long ld_row,
                                                    int T, int kind, int tid) {
     using SI = StageInfo<P, 0>;
@@ -100,22 +123,23 @@ __device__ __forceinline__ void gather_issue_range(const double* __restrict__ co
     asm volatile("" : "+v"(tid), "+s"(ld_row));
     static_for<(HI > LO ? HI - LO : 0)>([&](auto i) {
         constexpr int f = LO + decltype(i)::value;
-        if constexpr (f < SI::K * SI::R) {
+        if constexpr (f < SI::K * SI::R && f < FMAX) {
             constexpr int m = f / SI::R, j = f % SI::R;
+            constexpr int dst = agpr_base<P>() + 4 * f + DSTOFF;
             const int t = tid + m * P::NT + j * SI::L;
             const int tc = t < T ? t : T - 1;
             const double* p = col + (long)tc * ld_row;
             if constexpr (VEC) {
-                ag_load4<agpr_base<P>() + 4 * f>(p);
+                ag_load4<dst>(p);
             } else if (kind == 2) {
-                ag_load4<agpr_base<P>() + 4 * f>(p);
+                ag_load4<dst>(p);
             } else {
-                ag_load2<agpr_base<P>() + 4 * f>(p);
+                ag_load2<dst>(p);
                 if (kind == 1) {
-                    ag_load2<agpr_base<P>() + 4 * f + 2>(p + 1);
+                    ag_load2<dst + 2>(p + 1);
                 } else {
-                    AG<agpr_base<P>() + 4 * f + 2>::w(0u);
-                    AG<agpr_base<P>() + 4 * f + 3>::w(0u);
+                    AG<dst + 2>::w(0u);
+                    AG<dst + 3>::w(0u);
                 }
             }
         }
@@ -244,6 +268,53 @@ __device__ __forceinline__ void last_stage_acc_regs(
 #pragma unroll
             for (int q = 0; q < SI::R; ++q) acc[m][q] += norm2(v[q]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        after_task(m);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// Same, accumulating into the workgroup's accumulator block in global memory (L2/MALL
+// resident, [quad][thread] x double2): a butterfly's R accumulators are loaded one butterfly
+// ahead and stored right after the update, so only 2*R of them are ever in registers.
+template <class P, class Hook>
+__device__ __forceinline__ void last_stage_acc_global(const cd* __restrict__ lds,
+                                                      double* __restrict__ blk, int tid,
+                                                      Hook&& after_task) {
+    using SI = StageInfo<P, P::S - 1>;
+    static_assert(SI::R % 2 == 0, "accumulators move as double2");
+    constexpr int Q = SI::R / 2;  // double2 per butterfly
+    double2 buf[2][Q];
+    auto row = [&](int quad) {
+        double2* r = reinterpret_cast<double2*>(blk) + (long)quad * P::NT;
+        asm volatile("" : "+s"(r));  // uniform row base: SGPR base + one shared VGPR offset
+        return r;
+    };
+#pragma unroll
+    for (int h = 0; h < Q; ++h) buf[0][h] = row(h)[tid];
+    static_for<SI::K>([&](auto mm) {
+        constexpr int m = decltype(mm)::value;
+        const int u = tid + m * P::NT;
+        if constexpr (m + 1 < SI::K) {
+#pragma unroll
+            for (int h = 0; h < Q; ++h) buf[(m + 1) & 1][h] = row((m + 1) * Q + h)[tid];
+        }
+        if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
+            cd v[SI::R];
+#pragma unroll
+            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(u * SI::R + j)];
+            agpr_fence<P>();
+            Dft<SI::R>::run(v);
+            agpr_fence<P>();
+#pragma unroll
+            for (int h = 0; h < Q; ++h) {
+                double2 a = buf[m & 1][h];
+                a.x += norm2(v[2 * h]);
+                a.y += norm2(v[2 * h + 1]);
+                row(m * Q + h)[tid] = a;
+            }
+        }
+        agpr_fence<P>();
         __builtin_amdgcn_sched_barrier(0);
         after_task(m);
         __builtin_amdgcn_sched_barrier(0);
@@ -389,7 +460,7 @@ __global__ void __launch_bounds__(P::NT)
     using SL = StageInfo<P, P::S - 1>;
     using S0 = StageInfo<P, 0>;
     static_assert(P::S <= 5, "seed array sized for S <= 5");
-    static_assert(agpr_acc_base<P>() + acc_quads<P>() * 4 <= 256, "manual AGPR slots exceed a255");
+    static_assert(agpr_acc_base<P>() + agpr_acc_dwords<P>() <= 256, "manual AGPR slots exceed a255");
     static_assert(agpr_base<P>() >= 16, "leave at least a0..a15 to the compiler");
     asm volatile("; TA_AGPR_MANUAL_RANGE %0 %1" ::"n"(agpr_base<P>()), "n"(256));  // tools/check_agpr.py
     constexpr long ACC_BLK = (long)acc_quads<P>() * 2 * P::NT;
@@ -421,8 +492,10 @@ __global__ void __launch_bounds__(P::NT)
     static_assert(UNIT <= S0::R, "a first-stage slot may only refill registers already consumed");
     static_assert(NSLOT <= 32, "extend the TA_PIECE list");
 
-    // pass A accumulators: manual AGPR slots; pass B accumulators: ordinary registers
-    static_for<SL::K * SL::R>([&](auto dd) { ag_write_f64<agpr_acc_base<P>() + 2 * decltype(dd)::value>(0.0); });
+    // pass A accumulators: manual AGPR slots (landing plans: the workgroup's global block,
+    // in VGPRs only around pass A's last stage); pass B accumulators: ordinary registers
+    if constexpr (!landing<P>())
+        static_for<SL::K * SL::R>([&](auto dd) { ag_write_f64<agpr_acc_base<P>() + 2 * decltype(dd)::value>(0.0); });
     double accB[SL::K][SL::R];
 #pragma unroll
     for (int m = 0; m < SL::K; ++m)
@@ -467,6 +540,80 @@ __global__ void __launch_bounds__(P::NT)
         // hoisting (and spilling) them out of the pair loop
         asm volatile("" : "+s"(tw2), "+s"(ld_row), "+v"(tid));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the gathered pair has landed
+        const long next = unit + 1;
+        const bool more = next < n_mine;
+        const double* ncol = unit_col(more ? next : unit);
+        const int nkind = unit_kind(more ? next : unit);
+        if constexpr (landing<P>()) {
+            // ================= landing plans =================
+            constexpr int KL = land_tasks<P>(), NL = land_elems<P>(), NB = NLOAD - NL;
+            constexpr int WSLOTS = S0::K + 2 * MIDSLOTS + SL::K;  // mid rounds count twice
+            constexpr int UA = (NL + WSLOTS - 1) / WSLOTS, UB = (NB + WSLOTS - 1) / WSLOTS;
+            static_assert(UB <= S0::R, "a first-stage slot may only refill registers already consumed");
+#define TA_W(S) ((S) <= S0::K ? (S) : (S) <= S0::K + MIDSLOTS ? S0::K + 2 * ((S)-S0::K) \
+                                                             : S0::K + 2 * MIDSLOTS + ((S)-S0::K - MIDSLOTS))
+            // pass A: elements NB.. of the next unit -> landing zone
+            auto hookA = [&](int slot_) {
+                if (more) {
+#define TA_PIECE(S)                                                                            \
+    if (slot_ == S)                                                                            \
+        gather_issue_range<P, VEC, NB + TA_W(S) * UA, NB + TA_W((S) + 1) * UA, NLOAD, 4 * NL>( \
+            ncol, ld_row, T, nkind, tid);
+                    TA_PIECE(0) TA_PIECE(1) TA_PIECE(2) TA_PIECE(3) TA_PIECE(4) TA_PIECE(5)
+                    TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
+                    TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)
+                    TA_PIECE(18) TA_PIECE(19) TA_PIECE(20) TA_PIECE(21) TA_PIECE(22) TA_PIECE(23)
+                    TA_PIECE(24) TA_PIECE(25) TA_PIECE(26) TA_PIECE(27) TA_PIECE(28) TA_PIECE(29)
+                    TA_PIECE(30) TA_PIECE(31)
+#undef TA_PIECE
+                }
+            };
+            // pass B: elements 0..NB-1 of the next unit -> pair slots of the butterflies already
+            // done; after butterfly m >= K0-KL the landed elements of that butterfly move over
+            auto hookB = [&](int slot_) {
+                if (more) {
+#define TA_PIECE(S)                                                                          \
+    if (slot_ == S) {                                                                        \
+        gather_issue_range<P, VEC, TA_W(S) * UB, TA_W((S) + 1) * UB, NB>(ncol, ld_row, T,    \
+                                                                        nkind, tid);        \
+        if constexpr ((S) >= S0::K - KL && (S) < S0::K) {                                    \
+            static_for<4 * S0::R>([&](auto dd) {                                             \
+                constexpr int a = agpr_base<P>() + 4 * (S)*S0::R + decltype(dd)::value;      \
+                ag_mov<a, a + 4 * NL>();                                                     \
+            });                                                                              \
+        }                                                                                    \
+    }
+                    TA_PIECE(0) TA_PIECE(1) TA_PIECE(2) TA_PIECE(3) TA_PIECE(4) TA_PIECE(5)
+                    TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
+                    TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)
+                    TA_PIECE(18) TA_PIECE(19) TA_PIECE(20) TA_PIECE(21) TA_PIECE(22) TA_PIECE(23)
+                    TA_PIECE(24) TA_PIECE(25) TA_PIECE(26) TA_PIECE(27) TA_PIECE(28) TA_PIECE(29)
+                    TA_PIECE(30) TA_PIECE(31)
+#undef TA_PIECE
+                }
+            };
+#undef TA_W
+            // ---- pass A: even bins
+            first_stage_from_agpr<P, false>(lds, tw2, T, tid, hookA);
+            TA_STAMP(0)
+            __syncthreads();
+            mid_stages_seeded<P, 1, S0::K>(lds, tw2, seed, tid, hookA);
+            TA_STAMP(1)
+            last_stage_acc_global<P>(lds, blkA, tid, [&](int m) { hookA(S0::K + MIDSLOTS + m); });
+            TA_STAMP(2)
+            __syncthreads();
+            // ---- pass B: odd bins.  Everything issued so far (the landing loads, the
+            // accumulator block) must be complete before landed data is moved.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            first_stage_from_agpr<P, true>(lds, tw2, T, tid, hookB);
+            TA_STAMP(3)
+            __syncthreads();
+            mid_stages_seeded<P, 1, S0::K>(lds, tw2, seed, tid, hookB);
+            TA_STAMP(4)
+            last_stage_acc_regs<P>(lds, accB, tid, [&](int m) { hookB(S0::K + MIDSLOTS + m); });
+            TA_STAMP(5)
+            __syncthreads();
+        } else {
         // ---- pass A: even bins
         first_stage_from_agpr<P, false>(lds, tw2, T, tid, no_hook);
         TA_STAMP(0)
@@ -482,10 +629,6 @@ __global__ void __launch_bounds__(P::NT)
         __syncthreads();
         // ---- pass B: odd bins; after its first stage the parked pair is dead and is
         // refilled with the next pair while pass B's butterflies run
-        const long next = unit + 1;
-        const bool more = next < n_mine;
-        const double* ncol = unit_col(more ? next : unit);
-        const int nkind = unit_kind(more ? next : unit);
         auto hook = [&](int slot_) {
             if (more) {
 #define TA_LO(S) ((S) <= S0::K ? (S)*UNIT                                                   \
@@ -549,12 +692,32 @@ __global__ void __launch_bounds__(P::NT)
         }
         TA_STAMP(5)
         __syncthreads();
+        }  // !landing
         if constexpr (STAMP) st_acc[7] += 1;
         if constexpr (BYP) {
             if ((int)(unit % ppa) == ppa - 1) {
                 const long atom = slot + (unit / ppa) * nwg;
                 // ---- this atom's spectrum -> LDS (digit-reversed order), accumulators reset
-                if constexpr (acc_b_in_regs<P>()) {
+                if constexpr (landing<P>()) {
+                    // pass A's set is in the workgroup's block, pass B's in registers
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    double2* ba = reinterpret_cast<double2*>(blkA);
+#pragma unroll
+                    for (int m = 0; m < SL::K; ++m) {
+                        const int u = tid + m * P::NT;
+#pragma unroll
+                        for (int q = 0; q < SL::R; q += 2) {
+                            const long at = (long)((m * SL::R + q) / 2) * P::NT + tid;
+                            const double2 va = ba[at];
+                            ba[at] = make_double2(0.0, 0.0);
+                            if (SL::TASKS % P::NT == 0 || u < SL::TASKS) {
+                                lds[sw(u * SL::R + q)] = cd{va.x, accB[m][q]};
+                                lds[sw(u * SL::R + q + 1)] = cd{va.y, accB[m][q + 1]};
+                            }
+                            accB[m][q] = accB[m][q + 1] = 0.0;
+                        }
+                    }
+                } else if constexpr (acc_b_in_regs<P>()) {
                     static_for<SL::K>([&](auto mm) {
                         constexpr int m = decltype(mm)::value;
                         const int u = tid + m * P::NT;
@@ -624,7 +787,7 @@ __global__ void __launch_bounds__(P::NT)
     // write both accumulator sets to this workgroup's block ([quad][thread] layout)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (acc_b_in_regs<P>()) {
-        acc_swap_out<P>(blkA, tid);
+        if constexpr (!landing<P>()) acc_swap_out<P>(blkA, tid);
         double2* b = reinterpret_cast<double2*>(blkB);
 #pragma unroll
         for (int m = 0; m < SL::K; ++m)

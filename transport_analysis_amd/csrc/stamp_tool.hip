@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(partial, 0, sizeof(double) * accn));
     unsigned long long* st; CK(hipMalloc(&st, 8 * sizeof(unsigned long long) * nwg));
     const size_t lds = (size_t)P::lds_elems() * sizeof(cd);
-    auto kern = k_fft_accum<P, true, true>;
+    auto kern = k_fft_accum<WithLanding<P>, true, true>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
