@@ -266,6 +266,21 @@ __device__ __forceinline__ void inv_stage_lds(cd* __restrict__ lds, const cd* __
     }
 }
 
+// Table reads that must not become flat loads: after the pointer laundering in the pair loop
+// the compiler no longer knows the address space of tw2 and would emit flat_load + a wait for
+// vmcnt(0) AND lgkmcnt(0), i.e. for every gather load in flight.  Wave-uniform entries go
+// through the constant address space (s_load, counted by lgkmcnt only), per-lane entries
+// through the global one.
+typedef double tw_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cd tw_uniform(const cd* tw2, int idx) {
+    const tw_d2 t = ((const tw_d2 __attribute__((address_space(4)))*)tw2)[idx];
+    return cd{t.x, t.y};
+}
+__device__ __forceinline__ cd tw_lane(const cd* tw2, int idx) {
+    const tw_d2 t = ((const tw_d2 __attribute__((address_space(1)))*)tw2)[idx];
+    return cd{t.x, t.y};
+}
+
 template <class P, int s>
 constexpr bool stage_seedable() {
     return StageInfo<P, s>::L > 1 && (P::NT % StageInfo<P, s>::L == 0);
@@ -290,7 +305,7 @@ __device__ __forceinline__ void inv_stage_lds_fast(cd* __restrict__ lds,
 #pragma unroll
                 for (int q = 0; q < SI::R; ++q) v[q] = lds[sw(u + q * SI::L)];
 #pragma unroll
-                for (int q = 1; q < SI::R; ++q) v[q] = cmulc(v[q], tbl[q * SI::L + u]);
+                for (int q = 1; q < SI::R; ++q) v[q] = cmulc(v[q], tw_lane(tbl, q * SI::L + u));
                 TA_AGPR_FENCE_HOOK();
                 idft<SI::R>(v);
                 TA_AGPR_FENCE_HOOK();
@@ -299,7 +314,7 @@ __device__ __forceinline__ void inv_stage_lds_fast(cd* __restrict__ lds,
             }
         }
     } else if constexpr (stage_seedable<P, s>()) {
-        const cd seed = tw2[(tid % SI::L) * SI::TWSTEP];
+        const cd seed = tw_lane(tw2, (tid % SI::L) * SI::TWSTEP);
         const cd seed2 = cmul(seed, seed);
 #pragma unroll 1
         for (int m = 0; m < SI::K; ++m) {

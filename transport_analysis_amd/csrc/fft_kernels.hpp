@@ -146,21 +146,6 @@ __device__ __forceinline__ void gather_issue_range(const double* __restrict__ co
     });
 }
 
-// Table reads that must not become flat loads: after the pointer laundering in the pair loop
-// the compiler no longer knows the address space of tw2 and would emit flat_load + a wait for
-// vmcnt(0) AND lgkmcnt(0), i.e. for every gather load in flight.  Wave-uniform entries go
-// through the constant address space (s_load, counted by lgkmcnt only), per-lane entries
-// through the global one.
-typedef double tw_d2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ cd tw_uniform(const cd* tw2, int idx) {
-    const tw_d2 t = ((const tw_d2 __attribute__((address_space(4)))*)tw2)[idx];
-    return cd{t.x, t.y};
-}
-__device__ __forceinline__ cd tw_lane(const cd* tw2, int idx) {
-    const tw_d2 t = ((const tw_d2 __attribute__((address_space(1)))*)tw2)[idx];
-    return cd{t.x, t.y};
-}
-
 // First stage from the parked pair (read-only: pass B reads it again).
 // Twiddles W_2M^{u(2q+B)}, u = tid + m*NT, without table gathers: g = W^{2u} = W^{2 tid} *
 // W^{2 m NT} and h = W^{uB} = W^{tid B} * W^{m NT B} (per-lane factor loaded once per pass
@@ -284,11 +269,14 @@ __device__ __forceinline__ void last_stage_acc_global(const cd* __restrict__ lds
     using SI = StageInfo<P, P::S - 1>;
     static_assert(SI::R % 2 == 0, "accumulators move as double2");
     constexpr int Q = SI::R / 2;  // double2 per butterfly
-    double2 buf[2][Q];
+    // global address space kept explicit: a laundered generic pointer would turn these into
+    // flat loads/stores, whose waits drain every load in flight
+    typedef tw_d2 __attribute__((address_space(1)))* gptr;
+    tw_d2 buf[2][Q];
     auto row = [&](int quad) {
-        double2* r = reinterpret_cast<double2*>(blk) + (long)quad * P::NT;
+        double* r = blk + (long)quad * 2 * P::NT;
         asm volatile("" : "+s"(r));  // uniform row base: SGPR base + one shared VGPR offset
-        return r;
+        return (gptr)r;
     };
 #pragma unroll
     for (int h = 0; h < Q; ++h) buf[0][h] = row(h)[tid];
@@ -308,7 +296,7 @@ __device__ __forceinline__ void last_stage_acc_global(const cd* __restrict__ lds
             agpr_fence<P>();
 #pragma unroll
             for (int h = 0; h < Q; ++h) {
-                double2 a = buf[m & 1][h];
+                tw_d2 a = buf[m & 1][h];
                 a.x += norm2(v[2 * h]);
                 a.y += norm2(v[2 * h + 1]);
                 row(m * Q + h)[tid] = a;
@@ -359,7 +347,7 @@ __device__ __forceinline__ void acc_swap_out(double* __restrict__ blk, int tid) 
 template <class P, int s>
 __device__ __forceinline__ cd stage_seed(const cd* __restrict__ tw2, int tid) {
     using SI = StageInfo<P, s>;
-    if constexpr (stage_seedable<P, s>()) return tw2[(tid % SI::L) * SI::TWSTEP];
+    if constexpr (stage_seedable<P, s>()) return tw_lane(tw2, (tid % SI::L) * SI::TWSTEP);
     else return cd{1.0, 0.0};
 }
 
@@ -411,7 +399,7 @@ __device__ __forceinline__ double lag_value(const cd* __restrict__ lds,
     const cd a = {0.5 * (qn.x + qm.x), 0.5 * (qn.y - qm.y)};
     // (qn - conj(qm)) / (2i) = ( (qn.y + qm.y) - i (qn.x - qm.x) ) / 2
     const cd b = {0.5 * (qn.y + qm.y), -0.5 * (qn.x - qm.x)};
-    const cd w = tw2[n];  // exp(-i pi n / M); need its conjugate
+    const cd w = tw_lane(tw2, n);  // exp(-i pi n / M); need its conjugate
     const double re = a.x + (b.x * w.x + b.y * w.y);
     return re / (2.0 * (double)P::M * (double)(T - n));  // 2M(T-n) < 2^53: exact product
 }
