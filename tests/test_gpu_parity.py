@@ -232,6 +232,32 @@ def test_device_entry_points_on_a_column_block(ctx):
         assert scale_rel_err(lag2.cpu().numpy(), want.sum(axis=1)) < TOL
 
 
+@pytest.mark.parametrize("T,A_all,D,lo,hi", [(13, 18, 1, 0, 1), (300, 8, 3, 1, 4), (5200, 6, 3, 2, 5),
+                                           (9000, 4, 1, 1, 4), (640, 10, 2, 3, 8)])
+def test_fft_shard_with_odd_column_count_in_an_even_slab(ctx, T, A_all, D, lo, hi):
+    """A column block whose column count is odd while the slab's row length is even (found by
+    tests/stress_gpu.py): the last column has no partner and must not pick up the neighbouring
+    atom's data through a 16-byte load."""
+    import torch
+
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(T, A_all, D, seed=9000 + T)
+    dv = torch.from_numpy(v).cuda()
+    A = hi - lo
+    want_bp, _ = orc.vacf_fft_batched(v[:, lo:hi])
+    st = torch.cuda.current_stream().cuda_stream
+    for with_bp in (False, True):
+        lag = torch.zeros(T, dtype=torch.float64, device="cuda")
+        bp = torch.zeros((T, A), dtype=torch.float64, device="cuda")
+        ctx.vacf_fft_dev(dv.data_ptr() + lo * D * 8, T, A, D, A_all * D, lag.data_ptr(),
+                         bp.data_ptr() if with_bp else 0, A, st)
+        torch.cuda.synchronize()
+        assert scale_rel_err(lag.cpu().numpy(), want_bp.sum(axis=1)) < TOL
+        if with_bp:
+            assert scale_rel_err(bp.cpu().numpy(), want_bp) < TOL
+
+
 def test_cabi_error_behaviour(ctx):
     """Negative status + message instead of a crash (include/ta_hip.h conventions)."""
     import torch

@@ -391,7 +391,10 @@ int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int 
     a.D = D;
     a.tw2 = tb.tw2;
     if (!d_bp) {
-        const bool vec = (ld_row % 2 == 0) && ((uintptr_t)d_vel % 16 == 0);
+        // the all-16-byte-loads instantiation needs every pair complete: an odd column count
+        // (possible with an even ld_row when the shard is a column block of a wider slab) takes
+        // the general one, which still uses 16-byte loads wherever a pair is aligned
+        const bool vec = (ld_row % 2 == 0) && ((uintptr_t)d_vel % 16 == 0) && ((A * D) % 2 == 0);
         const int64_t n_pairs = (A * D + 1) / 2;
         int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg
                                            : (int64_t)ctx->n_cu * plan->max_wg_per_cu(vec ? 0 : 1);

@@ -517,7 +517,9 @@ __global__ void __launch_bounds__(P::NT)
             if (D == 2) return slab16 ? 2 : 1;
             return 0;
         } else {
-            return 2 * (slot + i * nwg) + 1 < n_cols ? 1 : 0;
+            // a pair of a 16-byte aligned slab is one 16-byte load (pair_stride = 2: every
+            // pair starts at an even column); an odd last column has no partner
+            return 2 * (slot + i * nwg) + 1 < n_cols ? (slab16 && pair_stride % 2 == 0 ? 2 : 1) : 0;
         }
     };
     long unit = 0;
