@@ -18,6 +18,58 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
+def host_cases(n_cases, seed):
+    """Host-facing boundary: pinned slabs in float32 or float64, committed in random chunks."""
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for case in range(n_cases):
+        ctx = _lib.Context(0)
+        T = int(rng.integers(1, 4000)) if rng.random() < 0.8 else int(rng.integers(4000, 18000))
+        A = int(rng.integers(1, 30 if T < 4000 else 6))
+        D = int(rng.integers(1, 4))
+        dtype = np.float32 if rng.random() < 0.5 else np.float64
+        kind = rng.choice(["fft", "direct", "helfand"])
+        v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=int(rng.integers(1 << 30)))
+        v, x = v.astype(dtype), x.astype(dtype)
+        slabs = ctx.stage_alloc(T, A, D, n_slabs=2 if kind == "helfand" else 1, dtype=dtype)
+        cuts = sorted(set([0, T] + [int(c) for c in rng.integers(0, T + 1, size=int(rng.integers(0, 4)))]))
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            slabs[0][lo:hi] = v[lo:hi]
+            if kind == "helfand":
+                slabs[1][lo:hi] = x[lo:hi]
+            ctx.stage_commit(lo, hi)
+        v64, x64 = v.astype(np.float64), x.astype(np.float64)
+        by_particle = bool(rng.random() < 0.5)
+        if kind == "helfand":
+            scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+            ts, bp = ctx.helfand_msd(m, scale, by_particle=by_particle)
+            if T <= 2500:
+                want_bp, want_ts = orc.helfand(v64, x64, m, vol, 300.0)
+            else:  # O(T^2) oracle: a few lags only
+                P = m[None, :, None] * v64 * x64
+                ks = [1, 2, T // 2, T - 1]
+                sub = np.array([np.mean(np.square(P[:-k] - P[k:]).mean(axis=-1), axis=0) * scale for k in ks])
+                e = float(np.max(np.abs(ts[ks] - sub.mean(axis=1)))) / max(float(np.max(np.abs(sub))), 1e-300)
+                worst = max(worst, e / 1e-10)
+                assert e < 1e-10, ("helfand long", T, A, D, e)
+                ctx.close()
+                continue
+        else:
+            ts, bp = (ctx.vacf_fft if kind == "fft" else ctx.vacf_direct)(by_particle=by_particle)
+            want_bp, want_ts = orc.vacf_fft_batched(v64)
+        sc = max(float(np.max(np.abs(want_bp))), 1e-300)
+        e = float(np.max(np.abs(ts - want_ts))) / sc
+        if by_particle:
+            e = max(e, float(np.max(np.abs(bp - want_bp))) / sc)
+        worst = max(worst, e / 1e-10)
+        if e > 1e-10:
+            print("FAIL host", case, kind, T, A, D, dtype, by_particle, e, flush=True)
+            return 1
+        ctx.close()
+    print("host stress ok:", n_cases, "cases, worst err/tol %.3g" % worst)
+    return 0
+
+
 def main(n_cases, seed=1234):
     rng = np.random.default_rng(seed)
     ctx = _lib.Context(0)
@@ -83,5 +135,6 @@ def main(n_cases, seed=1234):
 
 
 if __name__ == "__main__":
-    sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 200,
-                  int(sys.argv[2]) if len(sys.argv) > 2 else 1234))
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    sd = int(sys.argv[2]) if len(sys.argv) > 2 else 1234
+    sys.exit(main(n, sd) or host_cases(max(1, n // 5), sd + 1))
