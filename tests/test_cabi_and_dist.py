@@ -92,3 +92,65 @@ def test_sharded_reduce_gloo_world2(tmp_path, A):
     for r in range(world):
         got = np.load(tmp_path / f"ts_{r}.npy")
         assert scale_rel_err(got, want) < 1e-13
+
+
+def _class_worker(rank, world, port, T, A, out_dir):
+    """The drop-in classes under torch.distributed (gloo here; nccl = RCCL on GPUs): every
+    rank runs the same script, the library context is the oracle-backed stand-in."""
+    import sys
+
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fake_backend import OracleContext
+    from oracle import numpy_oracle as orc
+    from transport_analysis_amd import VelocityAutocorr, ViscosityHelfand, _lib
+    from transport_analysis_amd._mini_mda import ArrayUniverse
+
+    _lib.Context = OracleContext
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                            world_size=world)
+    v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=123)
+    u = ArrayUniverse(positions=x, velocities=v, masses=m, dimensions=[60, 60, 60, 90, 90, 90])
+    out = {}
+    for fft in (True, False):
+        a = VelocityAutocorr(u.atoms, dim_type="xz", fft=fft, distributed=True).run()
+        out[f"vacf_ts_{int(fft)}"] = a.results.timeseries
+        out[f"vacf_bp_{int(fft)}"] = a.results.vacf_by_particle
+        out["range"] = np.array(a.results.particle_range)
+    h = ViscosityHelfand(u.atoms, distributed=True, linear_fit_window=(2, T - 2)).run()
+    out["visc_ts"] = h.results.timeseries
+    out["visc_bp"] = h.results.visc_by_particle
+    out["visc"] = np.array(h.results.viscosity)
+    np.savez(os.path.join(out_dir, f"cls_{rank}.npz"), **out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("A", [7, 1])
+def test_classes_distributed_gloo_world2(tmp_path, A):
+    import torch.multiprocessing as mp
+
+    from oracle import numpy_oracle as orc
+
+    T, world = 40, 2
+    port = 31500 + (os.getpid() % 2000) + A
+    mp.spawn(_class_worker, args=(world, port, T, A, str(tmp_path)), nprocs=world, join=True)
+    v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=123)
+    v32 = v.astype(np.float32).astype(np.float64)  # ArrayUniverse hands out float32 like MDAnalysis
+    x32 = x.astype(np.float32).astype(np.float64)
+    want_bp, want_ts = orc.vacf_fft_batched(v32[:, :, [0, 2]])
+    hbp, hts = orc.helfand(v32, x32, m, np.full(T, 60.0**3), 300.0)
+    for r in range(world):
+        z = np.load(tmp_path / f"cls_{r}.npz", allow_pickle=True)
+        lo, hi = z["range"]
+        assert (lo, hi) == ((A * r) // world, (A * (r + 1)) // world)
+        for fft in (0, 1):
+            assert scale_rel_err(z[f"vacf_ts_{fft}"], want_ts) < 1e-12
+            if hi > lo:
+                assert scale_rel_err(z[f"vacf_bp_{fft}"], want_bp[:, lo:hi]) < 1e-12
+            else:
+                assert z[f"vacf_bp_{fft}"].shape == (T, 0)
+        assert scale_rel_err(z["visc_ts"], hts) < 1e-12
+        if hi > lo:
+            assert scale_rel_err(z["visc_bp"], hbp[:, lo:hi]) < 1e-12
+        np.testing.assert_allclose(z["visc"], orc.helfand_fit(hts, (2, T - 2)), rtol=1e-9)

@@ -45,3 +45,29 @@ def sharded_timeseries(compute_lagsum, n_atoms_total, rank, world_size, group=No
     lo, hi = atom_shard(n_atoms_total, rank, world_size)
     part = compute_lagsum(lo, hi)
     return reduce_lagsum(part, n_atoms_total, group)
+
+
+def shard_of_this_rank(n_atoms):
+    """(rank, world, lo, hi) of the calling process under torch.distributed (must be
+    initialised): the contiguous block of atoms this process stages and correlates."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("distributed=True needs an initialised torch.distributed process group "
+                           "(one process per GPU, e.g. under torchrun)")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = atom_shard(n_atoms, rank, world)
+    return rank, world, lo, hi
+
+
+def allreduce_mean_over_atoms(ts_local, n_local, n_atoms_total, device=None):
+    """Turn this rank's mean over ITS atoms into the mean over ALL atoms: one all-reduce of the
+    (n_frames,) float64 lag sums (RCCL when the group's backend is nccl, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+
+    lagsum = torch.from_numpy(np.ascontiguousarray(ts_local, dtype=np.float64) * float(n_local))
+    if dist.get_backend() == "nccl":
+        lagsum = lagsum.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+    out = reduce_lagsum(lagsum, n_atoms_total)
+    return out.cpu().numpy()

@@ -40,6 +40,12 @@ class VelocityAutocorr(AnalysisBase):
         ``results.vacf_by_particle`` is ``None``.
     device : int, keyword-only
         GPU index (default: ``$TA_AMD_DEVICE`` or 0).
+    distributed : bool, keyword-only, default False
+        One process per GPU under ``torch.distributed`` (e.g. ``torchrun``): every rank runs
+        the same script on the same AtomGroup, stages and correlates only its contiguous block
+        of atoms and ONE all-reduce of the lag sums gives ``results.timeseries`` (the mean over
+        ALL atoms) on every rank.  ``results.vacf_by_particle`` then holds this rank's atoms
+        only, ``results.particle_range = (lo, hi)``.
 
     Attributes
     ----------
@@ -52,6 +58,7 @@ class VelocityAutocorr(AnalysisBase):
     def __init__(self, atomgroup, dim_type="xyz", fft=True, **kwargs):
         self._want_by_particle = bool(kwargs.pop("by_particle", True))
         self._device = int(kwargs.pop("device", os.environ.get("TA_AMD_DEVICE", 0)))
+        self._distributed = bool(kwargs.pop("distributed", False))
         super().__init__(atomgroup.universe.trajectory, **kwargs)
 
         if isinstance(atomgroup, UpdatingAtomGroup):
@@ -73,9 +80,16 @@ class VelocityAutocorr(AnalysisBase):
         """Pinned host slab + device slab instead of ``np.zeros`` (:142-153)."""
         if self._ctx is None:
             self._ctx = _lib.Context(self._device)
+        self._lo, self._hi = 0, self.n_particles
+        if self._distributed:
+            from .dist import shard_of_this_rank
+
+            _, _, self._lo, self._hi = shard_of_this_rank(self.n_particles)
+            self.results.particle_range = (self._lo, self._hi)
+        self._n_local = self._hi - self._lo
         (self._velocities,) = self._ctx.stage_alloc(
-            self.n_frames, self.n_particles, self.dim_fac, n_slabs=1)
-        frame_bytes = max(1, self.n_particles * self.dim_fac * 8)
+            self.n_frames, max(self._n_local, 1), self.dim_fac, n_slabs=1)
+        frame_bytes = max(1, self._n_local * self.dim_fac * 8)
         self._commit_every = max(1, _COMMIT_BYTES // frame_bytes)
         self._committed = 0
         self.results.vacf_by_particle = None
@@ -86,7 +100,9 @@ class VelocityAutocorr(AnalysisBase):
         if not self._ts.has_velocities:
             raise NoDataError("VACF computation requires velocities in the trajectory")
         i = self._frame_index
-        self._velocities[i] = self.atomgroup.velocities[:, self._dim]
+        vel = self.atomgroup.velocities
+        if self._n_local:
+            self._velocities[i, : self._n_local] = vel[self._lo:self._hi][:, self._dim]
         if i + 1 - self._committed >= self._commit_every:
             self._ctx.stage_commit(self._committed, i + 1)
             self._committed = i + 1
@@ -109,6 +125,12 @@ class VelocityAutocorr(AnalysisBase):
         self._store(ts, bp)
 
     def _store(self, ts, bp):
+        if self._distributed:
+            from .dist import allreduce_mean_over_atoms
+
+            if self._n_local == 0:  # more ranks than atoms: this rank contributes nothing
+                ts, bp = np.zeros(self.n_frames), (None if bp is None else bp[:, :0])
+            ts = allreduce_mean_over_atoms(ts, self._n_local, self.n_particles, self._device)
         self.results.vacf_by_particle = bp
         self.results.timeseries = ts
         self._run_called = True

@@ -28,6 +28,10 @@ class ViscosityHelfand(AnalysisBase):
     by_particle : bool, keyword-only, default True — materialise
         ``results.visc_by_particle``; ``False`` computes the timeseries only.
     device : int, keyword-only — GPU index (default ``$TA_AMD_DEVICE`` or 0).
+    distributed : bool, keyword-only, default False — one process per GPU under
+        ``torch.distributed``: each rank handles its contiguous block of atoms, one all-reduce of
+        the lag sums gives ``results.timeseries`` on every rank; ``results.visc_by_particle``
+        holds this rank's atoms only (``results.particle_range``).
     float32 : bool, keyword-only, default False — form the mass-weighted
         velocity-position products in float64, then evaluate the squared differences and
         their block sums in float32 (accumulated into float64): ~1e-6 relative accuracy
@@ -45,6 +49,7 @@ class ViscosityHelfand(AnalysisBase):
                  **kwargs):
         self._want_by_particle = bool(kwargs.pop("by_particle", True))
         self._device = int(kwargs.pop("device", os.environ.get("TA_AMD_DEVICE", 0)))
+        self._distributed = bool(kwargs.pop("distributed", False))
         self._float32 = bool(kwargs.pop("float32", False))
         super().__init__(atomgroup.universe.trajectory, **kwargs)
 
@@ -67,12 +72,21 @@ class ViscosityHelfand(AnalysisBase):
         if self._ctx is None:
             self._ctx = _lib.Context(self._device)
         self._ctx.set_option("direct_f32", int(self._float32))
+        self._lo, self._hi = 0, self.n_particles
+        if self._distributed:
+            from .dist import shard_of_this_rank
+
+            _, _, self._lo, self._hi = shard_of_this_rank(self.n_particles)
+            self.results.particle_range = (self._lo, self._hi)
+        self._n_local = self._hi - self._lo
         self._velocities, self._positions = self._ctx.stage_alloc(
-            self.n_frames, self.n_particles, self.dim_fac, n_slabs=2)
+            self.n_frames, max(self._n_local, 1), self.dim_fac, n_slabs=2)
         self._volumes = np.zeros(self.n_frames)
-        self._masses = np.asarray(self.atomgroup.masses, dtype=np.float64)
+        self._masses = np.asarray(self.atomgroup.masses, dtype=np.float64)[self._lo:self._hi]
+        if self._n_local == 0:
+            self._masses = np.ones(1)
         self.boltzmann = BOLTZMANN
-        frame_bytes = max(1, 2 * self.n_particles * self.dim_fac * 8)
+        frame_bytes = max(1, 2 * self._n_local * self.dim_fac * 8)
         self._commit_every = max(1, _COMMIT_BYTES // frame_bytes)
         self._committed = 0
         self.results.visc_by_particle = None
@@ -87,8 +101,9 @@ class ViscosityHelfand(AnalysisBase):
             )
         i = self._frame_index
         self._volumes[i] = ts.volume
-        self._velocities[i] = self.atomgroup.velocities[:, self._dim]
-        self._positions[i] = self.atomgroup.positions[:, self._dim]
+        if self._n_local:
+            self._velocities[i, : self._n_local] = self.atomgroup.velocities[self._lo:self._hi][:, self._dim]
+            self._positions[i, : self._n_local] = self.atomgroup.positions[self._lo:self._hi][:, self._dim]
         if i + 1 - self._committed >= self._commit_every:
             self._ctx.stage_commit(self._committed, i + 1)
             self._committed = i + 1
@@ -101,6 +116,12 @@ class ViscosityHelfand(AnalysisBase):
         # everything is divided by 2 kB <V> T (:229-231)
         scale = 1.0 / (2 * self.boltzmann * self._vol_avg * self.temp_avg)
         ts, bp = self._ctx.helfand_msd(self._masses, scale, by_particle=self._want_by_particle)
+        if self._distributed:
+            from .dist import allreduce_mean_over_atoms
+
+            if self._n_local == 0:
+                ts, bp = np.zeros(self.n_frames), (None if bp is None else bp[:, :0])
+            ts = allreduce_mean_over_atoms(ts, self._n_local, self.n_particles, self._device)
         self.results.visc_by_particle = bp
         self.results.timeseries = ts
 
