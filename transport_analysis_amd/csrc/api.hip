@@ -403,7 +403,8 @@ int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int 
         const size_t acc_blk = (size_t)((plan->K_last * plan->R_last + 1) / 2) * 2 * plan->NT;
         const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * acc_blk;
         if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
-        if ((rc = ensure(ctx, ctx->spec, sizeof(double) * 2 * plan->M))) return rc;
+        const int n_slices = (int)std::min<int64_t>(8, nwg);
+        if ((rc = ensure(ctx, ctx->spec, sizeof(double) * 2 * plan->M * n_slices))) return rc;
         a.partial = (double*)ctx->partial.p;
         TA_HIP_TRY(ctx, hipMemsetAsync(a.partial, 0, acc_bytes, st));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
@@ -411,8 +412,9 @@ int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int 
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
         TA_HIP_TRY(ctx, launch_sum_partials_perm(a.partial, (int)nwg, plan->M, plan->NT, plan->R_last,
                                                  plan->K_last, plan->TASKS_last,
-                                                 (double*)ctx->spec.p, st));
+                                                 (double*)ctx->spec.p, n_slices, st));
         a.spec = (const double*)ctx->spec.p;
+        a.n_slices = n_slices;
         a.lagsum = d_lagsum;
         TA_HIP_TRY(ctx, plan->finalize(st, a));
     } else {

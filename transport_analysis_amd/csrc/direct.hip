@@ -36,17 +36,19 @@ __global__ void k_sum_partials_perm(const double* __restrict__ partial, int n_pa
     const int m = d / R, q = d % R;
     const int u = tid + m * NT;
     if (u >= TASKS) return;
+    // grid.y slices of the workgroup blocks: slice y sums blocks y, y + gridDim.y, ... into its
+    // own copy of the spectrum (k_fft_finalize adds the copies): fixed order, more parallelism
     double s = 0.0;
-    for (int w = 0; w < n_parts; ++w) s += partial[(long)w * 2 * blk + i];
-    spec[(long)pass * M + (long)u * R + q] = s;
+    for (int w = blockIdx.y; w < n_parts; w += gridDim.y) s += partial[(long)w * 2 * blk + i];
+    spec[(long)blockIdx.y * 2 * M + (long)pass * M + (long)u * R + q] = s;
 }
 
 hipError_t launch_sum_partials_perm(const double* partial, int n_parts, int M, int NT, int R, int K,
-                                    int TASKS, double* out, hipStream_t st) {
+                                    int TASKS, double* out, int n_slices, hipStream_t st) {
     const int nt = 256;
     const long n = 2L * ((K * R + 1) / 2) * 2 * NT;
-    hipLaunchKernelGGL(k_sum_partials_perm, dim3((unsigned)((n + nt - 1) / nt)), dim3(nt), 0, st,
-                       partial, n_parts, M, NT, R, K, TASKS, out);
+    hipLaunchKernelGGL(k_sum_partials_perm, dim3((unsigned)((n + nt - 1) / nt), n_slices), dim3(nt),
+                       0, st, partial, n_parts, M, NT, R, K, TASKS, out);
     return hipGetLastError();
 }
 

@@ -792,15 +792,23 @@ __global__ void __launch_bounds__(P::NT)
 }
 
 // ---- K3 (timeseries path): one inverse transform of the summed spectrum --------
-// spec: [2][M] (pass A bins, pass B bins), digit-reversed order.
+// spec: [n_slices][2][M] (pass A bins, pass B bins; the slices are partial sums over disjoint
+// sets of workgroups), digit-reversed order.
 template <class P>
 __global__ void __launch_bounds__(P::NT)
     k_fft_finalize(const double* __restrict__ spec, const cd* __restrict__ tw2, int T,
-                   double* __restrict__ lagsum) {
+                   double* __restrict__ lagsum, int n_slices) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
     const int tid = threadIdx.x;
-    for (int i = tid; i < P::M; i += P::NT) lds[sw(i)] = cd{spec[i], spec[P::M + i]};
+    for (int i = tid; i < P::M; i += P::NT) {
+        double a = 0.0, b = 0.0;
+        for (int y = 0; y < n_slices; ++y) {
+            a += spec[(long)y * 2 * P::M + i];
+            b += spec[(long)y * 2 * P::M + P::M + i];
+        }
+        lds[sw(i)] = cd{a, b};
+    }
     __syncthreads();
     inv_all_stages<P, P::S - 1>(lds, tw2, tid);
     for (int n = tid; n < T; n += P::NT) lagsum[n] = lag_value<P>(lds, tw2, n, T);

@@ -21,7 +21,8 @@ struct FftArgs {
     int D;
     const cd* tw2;        // [0,2M): W_{2M}^n; [2M,3M): first-stage table pass A; [3M,4M): pass B
     double* partial;      // accum: [nwg][2][quads*2*NT] float64, zeroed by the caller
-    const double* spec;   // finalize: [2][M]
+    const double* spec;   // finalize: [n_slices][2][M]
+    int n_slices;
     double* lagsum;       // finalize: [T]
     double* by_particle;  // by_particle: (T, ld_bp)
     long ld_bp;
@@ -57,7 +58,7 @@ hipError_t launch_sum_partials(const double* partial, int n_parts, long n, doubl
                                hipStream_t st);
 // spec[pass*M + u*R + q] = sum over workgroups of their accumulator (m, q), u = tid + m*NT
 hipError_t launch_sum_partials_perm(const double* partial, int n_parts, int M, int NT, int R, int K,
-                                    int TASKS, double* out, hipStream_t st);
+                                    int TASKS, double* out, int n_slices, hipStream_t st);
 hipError_t launch_widen_f32(const float* in, double* out, long n, hipStream_t st);
 
 }  // namespace ta
