@@ -74,7 +74,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Both accumulator sets of these plans live in VGPRs while they are used (pass A's set is
 // loaded from / stored to the workgroup's global block around pass A's last stage).
 template <class P>
-constexpr bool landing() { return P::kLanding && P::NT >= 256 && StageInfo<P, 0>::K >= 2; }
+constexpr bool landing() {
+    // measured per plan: the 128-thread 5*2^a plan spills with the landing zone and is faster without
+    return P::kLanding && StageInfo<P, 0>::K >= 2 && (P::NT >= 256 || (P::NT >= 128 && P::radix(0) != 5));
+}
 template <class P>
 constexpr int land_tasks() { return landing<P>() ? StageInfo<P, 0>::K / 2 : 0; }
 template <class P>
@@ -320,7 +323,7 @@ constexpr int acc_quads() {
 // room); the smaller plans swap the single AGPR set through the workgroup's global block at
 // the pass boundaries instead (their extra register pressure would spill).
 template <class P>
-constexpr bool acc_b_in_regs() { return P::NT >= 256; }
+constexpr bool acc_b_in_regs() { return P::NT >= 128; }
 
 template <class P>
 __device__ __forceinline__ void agpr_fence() {
