@@ -76,7 +76,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <class P>
 constexpr bool landing() {
     // measured per plan: the 128-thread 5*2^a plan spills with the landing zone and is faster without
-    return P::kLanding && StageInfo<P, 0>::K >= 2 && (P::NT >= 256 || (P::NT >= 128 && P::radix(0) != 5));
+    return P::kLanding && StageInfo<P, 0>::K >= 2 && (P::NT >= 256 || P::radix(0) != 5);
 }
 template <class P>
 constexpr int land_tasks() { return landing<P>() ? StageInfo<P, 0>::K / 2 : 0; }
@@ -312,32 +312,21 @@ __device__ __forceinline__ void last_stage_acc_global(const cd* __restrict__ lds
     });
 }
 
-// Accumulator swap between the AGPRs and this workgroup's private block in global
-// memory (L2/MALL resident), laid out [quad][thread] so a wave's accesses are contiguous;
-// a thread only ever touches its own slots, so program order is the only ordering needed.
+// The workgroup's accumulator blocks in global memory (one per pass; what the launch hands to
+// k_sum_partials_perm, and where the landing pipeline streams pass A's set) are laid out
+// [quad][thread] x 2 doubles, so a wave's accesses are contiguous; a thread only ever touches
+// its own slots, so program order is the only ordering needed.
 template <class P>
 constexpr int acc_quads() {
     return (StageInfo<P, P::S - 1>::K * StageInfo<P, P::S - 1>::R * 2 + 3) / 4;
 }
-// Second accumulator set: ordinary registers for the big plans (one wave per SIMD has the
-// room); the smaller plans swap the single AGPR set through the workgroup's global block at
-// the pass boundaries instead (their extra register pressure would spill).
-template <class P>
-constexpr bool acc_b_in_regs() { return P::NT >= 128; }
-
 template <class P>
 __device__ __forceinline__ void agpr_fence() {
     static_assert(agpr_base<P>() >= 0, "manual AGPR slots exceed the AGPR file");
     agpr_fence_from<agpr_base<P>()>();
 }
 
-template <class P>
-__device__ __forceinline__ void acc_swap_in(const double* __restrict__ blk, int tid) {
-    static_for<acc_quads<P>()>([&](auto qq) {
-        constexpr int q = decltype(qq)::value;
-        ag_load4<agpr_acc_base<P>() + 4 * q>(blk + 2 * ((long)q * P::NT + tid));
-    });
-}
+// Store the AGPR-resident accumulator set to a block (end of the kernel).
 template <class P>
 __device__ __forceinline__ void acc_swap_out(double* __restrict__ blk, int tid) {
     asm volatile("s_nop 4" ::: "memory");  // VALU AGPR writes -> VMEM store data (no auto padding in asm)
@@ -424,12 +413,15 @@ __device__ __forceinline__ double lag_value(const cd* __restrict__ lds,
 // multiple of 8, blocks b and b+8 share an XCD and an XCD's workgroups take consecutive
 // pairs, so the 8 pairs of a 128-byte line go through one L2 and the line leaves HBM once.
 //
-// Per pair:  wait gather -> first stage A -> [swap in acc A] mid A -> last A [swap out]
-//            -> first stage B -> [swap in acc B] mid B -> last B [swap out], with the NEXT
-//            pair's gather loads spread between pass B's butterfly rounds.
-// The 16-byte strided gather is L2-request-bound (a pure gather of this shape peaks at
-// ~2.3 TB/s on MI355X, ~0.27 lane-requests/clk/CU); issued as one burst its 40 loads per
-// thread would stall the wave for longer than a whole pass takes.
+// Plain pipeline (by-particle mode, the 5*2^a plans below 256 threads):
+//   wait gather -> first stage A -> mid A -> last A (accumulators in AGPRs)
+//   -> first stage B -> mid B -> last B (accumulators in VGPRs), with the NEXT pair's gather
+//   loads spread between pass B's butterfly rounds (its first stage frees the pair slots).
+// Landing pipeline (landing<P>(), see above): the gather is split over both passes.
+// The 16-byte strided gather is request-bound (a pure gather of this shape peaks at
+// ~1.9-2.3 TB/s on MI355X, ~0.25 lane-requests/clk/CU) and every load costs the issuing wave
+// ~400-500 cycles of issue back-pressure; issued as one burst the 40 loads per thread would
+// stall the wave for longer than a whole pass takes.
 //
 // accg: [gridDim.x][2][acc_quads*2*NT] float64 (pass A block, pass B block), zeroed by
 // the caller; k_sum_partials_perm restores the transform's digit-reversed bin order.
@@ -611,13 +603,9 @@ __global__ void __launch_bounds__(P::NT)
         first_stage_from_agpr<P, false>(lds, tw2, T, tid, no_hook);
         TA_STAMP(0)
         __syncthreads();
-        if constexpr (!acc_b_in_regs<P>()) acc_swap_in<P>(blkA, tid);
         mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, no_hook);
         TA_STAMP(1)
-        if constexpr (!acc_b_in_regs<P>())
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // accumulators A are in
         last_stage_acc_agpr<P>(lds, tid, no_hook);
-        if constexpr (!acc_b_in_regs<P>()) acc_swap_out<P>(blkA, tid);
         TA_STAMP(2)
         __syncthreads();
         // ---- pass B: odd bins; after its first stage the parked pair is dead and is
@@ -640,49 +628,12 @@ __global__ void __launch_bounds__(P::NT)
 #undef TA_LO
             }
         };
-        if constexpr (acc_b_in_regs<P>()) {
-            first_stage_from_agpr<P, true>(lds, tw2, T, tid, hook);
-            TA_STAMP(3)
-            __syncthreads();
-            mid_stages_seeded<P, 1, S0::K>(lds, tw2, seed, tid, hook);
-            TA_STAMP(4)
-            last_stage_acc_regs<P>(lds, accB, tid, [&](int m) { hook(S0::K + MIDSLOTS + m); });
-        } else {
-            // accumulators B are requested before any gather piece, the gather starts after
-            // the first stage, and the wait before the last stage leaves exactly the gather
-            // loads issued in the mid stages outstanding (inline asm: the compiler's waitcnt
-            // pass deletes builtin waits it considers redundant and cannot see asm loads)
-            first_stage_from_agpr<P, true>(lds, tw2, T, tid, no_hook);
-            TA_STAMP(3)
-            __syncthreads();
-            acc_swap_in<P>(blkB, tid);
-            constexpr int PER2 = (NLOAD + MIDSLOTS + SL::K - 1) / (MIDSLOTS + SL::K);
-            constexpr int MID_VMEM1 = MIDSLOTS * PER2;      // one load per element
-            constexpr int MID_VMEM2 = 2 * MIDSLOTS * PER2;  // two 8-byte loads per element
-            auto hook2 = [&](int slot_) {
-                if (more) {
-#define TA_PIECE(S)                                                                          \
-    if (slot_ == S)                                                                          \
-        gather_issue_range<P, VEC, (S)*PER2, ((S) + 1) * PER2>(ncol, ld_row, T, nkind, tid);
-                    TA_PIECE(0) TA_PIECE(1) TA_PIECE(2) TA_PIECE(3) TA_PIECE(4) TA_PIECE(5)
-                    TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
-                    TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)
-                    TA_PIECE(18) TA_PIECE(19) TA_PIECE(20) TA_PIECE(21) TA_PIECE(22) TA_PIECE(23)
-#undef TA_PIECE
-                }
-            };
-            mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, hook2);
-            TA_STAMP(4)
-            const bool two_loads = !VEC && nkind == 1;
-            if (more && MIDSLOTS * PER2 <= NLOAD && !two_loads && MID_VMEM1 < 64)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MID_VMEM1 < 64 ? MID_VMEM1 : 0) : "memory");
-            else if (more && MIDSLOTS * PER2 <= NLOAD && two_loads && MID_VMEM2 < 64)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MID_VMEM2 < 64 ? MID_VMEM2 : 0) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            last_stage_acc_agpr<P>(lds, tid, [&](int m) { hook2(MIDSLOTS + m); });
-            acc_swap_out<P>(blkB, tid);
-        }
+        first_stage_from_agpr<P, true>(lds, tw2, T, tid, hook);
+        TA_STAMP(3)
+        __syncthreads();
+        mid_stages_seeded<P, 1, S0::K>(lds, tw2, seed, tid, hook);
+        TA_STAMP(4)
+        last_stage_acc_regs<P>(lds, accB, tid, [&](int m) { hook(S0::K + MIDSLOTS + m); });
         TA_STAMP(5)
         __syncthreads();
         }  // !landing
@@ -710,7 +661,7 @@ __global__ void __launch_bounds__(P::NT)
                             accB[m][q] = accB[m][q + 1] = 0.0;
                         }
                     }
-                } else if constexpr (acc_b_in_regs<P>()) {
+                } else {
                     static_for<SL::K>([&](auto mm) {
                         constexpr int m = decltype(mm)::value;
                         const int u = tid + m * P::NT;
@@ -724,32 +675,6 @@ __global__ void __launch_bounds__(P::NT)
                             });
                         }
                     });
-                } else {
-                    // both sets were swapped out to the workgroup's blocks: [quad][thread] x 2
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const double2* ba = reinterpret_cast<const double2*>(blkA);
-                    const double2* bb = reinterpret_cast<const double2*>(blkB);
-#pragma unroll
-                    for (int m = 0; m < SL::K; ++m) {
-                        const int u = tid + m * P::NT;
-                        if (SL::TASKS % P::NT == 0 || u < SL::TASKS) {
-#pragma unroll
-                            for (int q = 0; q < SL::R; q += 2) {
-                                const int e = m * SL::R + q;  // even: SL::R is even or K == 1
-                                const double2 va = ba[(long)(e / 2) * P::NT + tid];
-                                const double2 vb = bb[(long)(e / 2) * P::NT + tid];
-                                lds[sw(u * SL::R + q)] = cd{va.x, vb.x};
-                                if (q + 1 < SL::R) lds[sw(u * SL::R + q + 1)] = cd{va.y, vb.y};
-                            }
-                        }
-                    }
-                    double2* za = reinterpret_cast<double2*>(blkA);
-                    double2* zb = reinterpret_cast<double2*>(blkB);
-#pragma unroll
-                    for (int q = 0; q < acc_quads<P>(); ++q) {
-                        za[(long)q * P::NT + tid] = make_double2(0.0, 0.0);
-                        zb[(long)q * P::NT + tid] = make_double2(0.0, 0.0);
-                    }
                 }
                 agpr_fence<P>();
                 __syncthreads();
@@ -779,7 +704,7 @@ __global__ void __launch_bounds__(P::NT)
     if constexpr (BYP) return;
     // write both accumulator sets to this workgroup's block ([quad][thread] layout)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (acc_b_in_regs<P>()) {
+    {
         if constexpr (!landing<P>()) acc_swap_out<P>(blkA, tid);
         double2* b = reinterpret_cast<double2*>(blkB);
 #pragma unroll
