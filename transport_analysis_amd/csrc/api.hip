@@ -403,7 +403,7 @@ int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int 
         const size_t acc_blk = (size_t)((plan->K_last * plan->R_last + 1) / 2) * 2 * plan->NT;
         const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * acc_blk;
         if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
-        const int n_slices = (int)std::min<int64_t>(8, nwg);
+        const int n_slices = (int)std::min<int64_t>(4, nwg);
         if ((rc = ensure(ctx, ctx->spec, sizeof(double) * 2 * plan->M * n_slices))) return rc;
         a.partial = (double*)ctx->partial.p;
         TA_HIP_TRY(ctx, hipMemsetAsync(a.partial, 0, acc_bytes, st));

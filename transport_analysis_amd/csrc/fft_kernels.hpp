@@ -729,13 +729,24 @@ __global__ void __launch_bounds__(P::NT)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
     const int tid = threadIdx.x;
-    for (int i = tid; i < P::M; i += P::NT) {
-        double a = 0.0, b = 0.0;
+    // 4 elements x n_slices x 2 independent loads in flight per thread
+    for (int i0 = tid; i0 < P::M; i0 += 4 * P::NT) {
+        double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
         for (int y = 0; y < n_slices; ++y) {
-            a += spec[(long)y * 2 * P::M + i];
-            b += spec[(long)y * 2 * P::M + P::M + i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * P::NT;
+                if (i < P::M) {
+                    a[k] += spec[(long)y * 2 * P::M + i];
+                    b[k] += spec[(long)y * 2 * P::M + P::M + i];
+                }
+            }
         }
-        lds[sw(i)] = cd{a, b};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * P::NT;
+            if (i < P::M) lds[sw(i)] = cd{a[k], b[k]};
+        }
     }
     __syncthreads();
     inv_all_stages<P, P::S - 1>(lds, tw2, tid);
