@@ -100,8 +100,8 @@ int get_tables(ta_ctx* ctx, int M, int R0, Tables* out) {
     // [0,2M): W_2M^n.  [2M,3M) and [3M,4M): the first-stage twiddles of pass A and pass B,
     // W_2M^{u(2q+B)} stored [q][u] (u < M/R0) so that a wave's 64 consecutive butterflies read
     // 1 KB contiguous (from the main table the same values sit 2q+B elements apart: one L2
-    // request per lane).
-    std::vector<cd> a(4 * (size_t)M);
+    // request per lane).  [4M,4M+2): zeros.
+    std::vector<cd> a(4 * (size_t)M + 2, cd{0.0, 0.0});  // + 32 zero bytes: the gather's padding rows
     const long double pi = 3.141592653589793238462643383279502884L;
     auto w2m = [&](long n) {
         n %= 2L * M;
@@ -118,8 +118,8 @@ int get_tables(ta_ctx* ctx, int M, int R0, Tables* out) {
         for (long q = 0; q < R0; ++q)
             for (long u = 0; u < L0; ++u) a[(2 + B) * (size_t)M + q * L0 + u] = w2m(u * (2 * q + B));
     Tables t;
-    TA_HIP_TRY(ctx, hipMalloc((void**)&t.tw2, sizeof(cd) * 4 * M));
-    TA_HIP_TRY(ctx, hipMemcpy(t.tw2, a.data(), sizeof(cd) * 4 * M, hipMemcpyHostToDevice));
+    TA_HIP_TRY(ctx, hipMalloc((void**)&t.tw2, sizeof(cd) * (4 * (size_t)M + 2)));
+    TA_HIP_TRY(ctx, hipMemcpy(t.tw2, a.data(), sizeof(cd) * (4 * (size_t)M + 2), hipMemcpyHostToDevice));
     ctx->tables[M] = t;
     *out = t;
     return TA_OK;

@@ -42,6 +42,16 @@ __device__ __forceinline__ double norm2(cd a) { return a.x * a.x + a.y * a.y; }
 // LDS element swizzle: keeps strided (power-of-two) element access conflict-free
 // for 16-byte accesses; a permutation inside every aligned 16-element block.
 __device__ __forceinline__ int sw(int i) { return i ^ ((i >> 4) & 15); }
+// sw(base + c) from sb = sw(base), for a constant c whose one-bits are zero in base (every
+// butterfly: base = blk*N + b with b < L, c = j*L, N = R*L).  sw is linear over disjoint bit
+// fields: sw(base + c) = sw(base) ^ sw(c); the bits of sw(c) above the low nibble are c's own
+// and cannot meet a one-bit of sb, so they are an ADD and fold into the DS instruction's
+// immediate offset.  A butterfly's R addresses then cost one v_xor per distinct low nibble of
+// sw(j*L) instead of a shift, a bit-op and an add each.
+__device__ __forceinline__ int sw_off(int sb, int c) {
+    const int s = c ^ ((c >> 4) & 15);
+    return (sb ^ (s & 15)) + (s & ~15);
+}
 
 constexpr double kR2 = 0.70710678118654752440084436210485;   // sqrt(1/2)
 constexpr double kC8 = 0.92387953251128675612818318939679;   // cos(pi/8)
@@ -224,16 +234,17 @@ __device__ __forceinline__ void fwd_stage_lds(cd* __restrict__ lds, const cd* __
         if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
             const int blk = u / SI::L, b = u - blk * SI::L;
             const int base = blk * SI::N + b;
+            const int sb = sw(base);
             cd v[SI::R];
 #pragma unroll
-            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(base + j * SI::L)];
+            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw_off(sb, j * SI::L)];
             Dft<SI::R>::run(v);
             if (SI::L > 1) {
 #pragma unroll
                 for (int q = 1; q < SI::R; ++q) v[q] = cmul(v[q], tw2[q * b * SI::TWSTEP]);
             }
 #pragma unroll
-            for (int q = 0; q < SI::R; ++q) lds[sw(base + q * SI::L)] = v[q];
+            for (int q = 0; q < SI::R; ++q) lds[sw_off(sb, q * SI::L)] = v[q];
         }
     }
 }
@@ -249,10 +260,11 @@ __device__ __forceinline__ void inv_stage_lds(cd* __restrict__ lds, const cd* __
         if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
             const int blk = u / SI::L, b = u - blk * SI::L;
             const int base = blk * SI::N + b;
+            const int sb = sw(base);
             cd v[SI::R];
             TA_AGPR_FENCE_HOOK();
 #pragma unroll
-            for (int q = 0; q < SI::R; ++q) v[q] = lds[sw(base + q * SI::L)];
+            for (int q = 0; q < SI::R; ++q) v[q] = lds[sw_off(sb, q * SI::L)];
             if (SI::L > 1) {
 #pragma unroll
                 for (int q = 1; q < SI::R; ++q) v[q] = cmulc(v[q], tw2[q * b * SI::TWSTEP]);
@@ -261,7 +273,7 @@ __device__ __forceinline__ void inv_stage_lds(cd* __restrict__ lds, const cd* __
             idft<SI::R>(v);
             TA_AGPR_FENCE_HOOK();
 #pragma unroll
-            for (int j = 0; j < SI::R; ++j) lds[sw(base + j * SI::L)] = v[j];
+            for (int j = 0; j < SI::R; ++j) lds[sw_off(sb, j * SI::L)] = v[j];
         }
     }
 }
@@ -300,17 +312,18 @@ __device__ __forceinline__ void inv_stage_lds_fast(cd* __restrict__ lds,
         for (int m = 0; m < SI::K; ++m) {
             const int u = tid + m * P::NT;
             if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
+                const int sb = sw(u);
                 cd v[SI::R];
                 TA_AGPR_FENCE_HOOK();
 #pragma unroll
-                for (int q = 0; q < SI::R; ++q) v[q] = lds[sw(u + q * SI::L)];
+                for (int q = 0; q < SI::R; ++q) v[q] = lds[sw_off(sb, q * SI::L)];
 #pragma unroll
                 for (int q = 1; q < SI::R; ++q) v[q] = cmulc(v[q], tw_lane(tbl, q * SI::L + u));
                 TA_AGPR_FENCE_HOOK();
                 idft<SI::R>(v);
                 TA_AGPR_FENCE_HOOK();
 #pragma unroll
-                for (int j = 0; j < SI::R; ++j) lds[sw(u + j * SI::L)] = v[j];
+                for (int j = 0; j < SI::R; ++j) lds[sw_off(sb, j * SI::L)] = v[j];
             }
         }
     } else if constexpr (stage_seedable<P, s>()) {
@@ -322,10 +335,11 @@ __device__ __forceinline__ void inv_stage_lds_fast(cd* __restrict__ lds,
             if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
                 const int blk = u / SI::L, b = u - blk * SI::L;
                 const int base = blk * SI::N + b;
+                const int sb = sw(base);
                 cd v[SI::R];
                 TA_AGPR_FENCE_HOOK();
 #pragma unroll
-                for (int q = 0; q < SI::R; ++q) v[q] = lds[sw(base + q * SI::L)];
+                for (int q = 0; q < SI::R; ++q) v[q] = lds[sw_off(sb, q * SI::L)];
                 cd wo = seed, we = seed2;  // seed^q for the current odd / even q
                 v[1] = cmulc(v[1], wo);
                 if constexpr (SI::R > 2) v[2] = cmulc(v[2], we);
@@ -343,7 +357,7 @@ __device__ __forceinline__ void inv_stage_lds_fast(cd* __restrict__ lds,
                 idft<SI::R>(v);
                 TA_AGPR_FENCE_HOOK();
 #pragma unroll
-                for (int j = 0; j < SI::R; ++j) lds[sw(base + j * SI::L)] = v[j];
+                for (int j = 0; j < SI::R; ++j) lds[sw_off(sb, j * SI::L)] = v[j];
             }
         }
     } else {
@@ -379,9 +393,10 @@ __device__ __forceinline__ void fwd_stage_lds_seeded(cd* __restrict__ lds, cd se
         if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
             const int blk = u / SI::L, b = u - blk * SI::L;
             const int base = blk * SI::N + b;
+            const int sb = sw(base);
             cd v[SI::R];
 #pragma unroll
-            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(base + j * SI::L)];
+            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw_off(sb, j * SI::L)];
             TA_AGPR_FENCE_HOOK();
             Dft<SI::R>::run(v);
             TA_AGPR_FENCE_HOOK();
@@ -400,7 +415,7 @@ __device__ __forceinline__ void fwd_stage_lds_seeded(cd* __restrict__ lds, cd se
             }
             TA_AGPR_FENCE_HOOK();
 #pragma unroll
-            for (int q = 0; q < SI::R; ++q) lds[sw(base + q * SI::L)] = v[q];
+            for (int q = 0; q < SI::R; ++q) lds[sw_off(sb, q * SI::L)] = v[q];
         }
         TA_AGPR_FENCE_HOOK();
         // all lanes (also those without a butterfly in this round) run the hook

@@ -110,28 +110,41 @@ __device__ __forceinline__ void ag_mov() {  // aD = aS
 }
 
 // Issue gather loads [LO, HI) (flat index f = m*R0 + j -> a[4f..4f+3]) of one column pair.
-// Rows past the end (t >= T, the zero padding) re-read row T-1 and are zeroed when the
-// registers are read, so the loads are branch-free.  Non-VEC (rows not 16-byte aligned or
-// an odd last column): two 8-byte loads, or one plus a zero imaginary part.
+// Addressing: a lane's row tid sits lane_off = tid*ld_row*8 bytes into the column (computed once
+// per kernel), element f adds the wave-uniform (m*NT + j*L)*ld_row*8 (scalar multiply), so a
+// load costs one 64-bit vector add.  Rows past the end (t >= T, the zero padding) read the
+// 32 zero bytes behind the twiddle tables instead (compare + select on the address): the
+// parked registers then hold the padded series itself and nothing is masked when they are
+// read (twice per pair).  Non-VEC (rows not 16-byte aligned or an odd last column): two
+// 8-byte loads, or one plus a zero imaginary part.
 // kind (wave-uniform, non-VEC kernels): 0 = one column (imaginary part zero), 1 = two columns,
 // two 8-byte loads, 2 = two columns at a 16-byte aligned address, one load.
 // FMAX: only elements f < FMAX are loaded; DSTOFF: dword offset added to the destination slot
 // (the landing zone is the pair area shifted by 4*land_elems dwords).
 template <class P, bool VEC, int LO, int HI, int FMAX = 1 << 20, int DSTOFF = 0>
 __device__ __forceinline__ void gather_issue_range(const double* __restrict__ col, long ld_row,
-                                                   int T, int kind, int tid) {
+                                                   int T, int kind, int tid,
+                                                   unsigned long lane_off,
+                                                   const cd* __restrict__ zeros) {
     using SI = StageInfo<P, 0>;
-    // compute this piece's addresses here and now (hoisted out, the 40 row addresses of a
-    // pair would occupy 80 VGPRs for the whole pass)
-    asm volatile("" : "+v"(tid), "+s"(ld_row));
+    // form this piece's addresses here and now (hoisted out, the 40 row addresses of a
+    // pair would occupy 80 VGPRs for the whole pass, their uniform parts 80 SGPRs)
+    asm volatile("" : "+s"(ld_row), "+s"(T));
     static_for<(HI > LO ? HI - LO : 0)>([&](auto i) {
         constexpr int f = LO + decltype(i)::value;
         if constexpr (f < SI::K * SI::R && f < FMAX) {
             constexpr int m = f / SI::R, j = f % SI::R;
             constexpr int dst = agpr_base<P>() + 4 * f + DSTOFF;
-            const int t = tid + m * P::NT + j * SI::L;
-            const int tc = t < T ? t : T - 1;
-            const double* p = col + (long)tc * ld_row;
+            constexpr int r0 = m * P::NT + j * SI::L;  // row of lane 0
+            // uniform part on the scalar unit (left alone the compiler folds it into a
+            // quarter-rate v_mad_u64_u32 per load)
+            unsigned long base = reinterpret_cast<unsigned long>(col) + (unsigned long)r0 * ((unsigned long)ld_row * 8ul);
+            asm volatile("" : "+s"(base));
+            const double* p = reinterpret_cast<const double*>(base + lane_off);
+            if (T - r0 < P::NT) {  // wave-uniform: this element reaches into the padding
+                asm volatile("");  // keep it a scalar branch (two selects per load otherwise)
+                if (!(tid < T - r0)) p = reinterpret_cast<const double*>(zeros);
+            }
             if constexpr (VEC) {
                 ag_load4<dst>(p);
             } else if (kind == 2) {
@@ -169,9 +182,7 @@ __device__ __forceinline__ void first_stage_from_agpr(cd* __restrict__ lds,
             static_for<SI::R>([&](auto jj) {
                 constexpr int j = decltype(jj)::value;
                 constexpr int a = agpr_base<P>() + 4 * (m * SI::R + j);
-                const bool live = u + j * SI::L < T;  // rows past the end are zero padding
-                const double x = ag_read_f64<a>(), y = ag_read_f64<a + 2>();
-                w[j] = cd{live ? x : 0.0, live ? y : 0.0};
+                w[j] = cd{ag_read_f64<a>(), ag_read_f64<a + 2>()};  // zero-padded by the gather
             });
             if constexpr (PASSB) {
                 // lane-uniform part of the twist: W_{2 R0}^j = tw2[j * L]
@@ -200,8 +211,9 @@ __device__ __forceinline__ void first_stage_from_agpr(cd* __restrict__ lds,
                 }
             }
             agpr_fence<P>();
+            const int sb = sw(u);
 #pragma unroll
-            for (int q = 0; q < SI::R; ++q) lds[sw(u + q * SI::L)] = w[q];
+            for (int q = 0; q < SI::R; ++q) lds[sw_off(sb, q * SI::L)] = w[q];
         }
         agpr_fence<P>();
         __builtin_amdgcn_sched_barrier(0);
@@ -219,9 +231,10 @@ __device__ __forceinline__ void last_stage_acc_agpr(const cd* __restrict__ lds, 
         constexpr int m = decltype(mm)::value;
         const int u = tid + m * P::NT;
         if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
+            const int sb = sw(u * SI::R);
             cd v[SI::R];
 #pragma unroll
-            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(u * SI::R + j)];
+            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw_off(sb, j)];
             agpr_fence<P>();
             Dft<SI::R>::run(v);
             agpr_fence<P>();
@@ -247,9 +260,10 @@ __device__ __forceinline__ void last_stage_acc_regs(
         constexpr int m = decltype(mm)::value;
         const int u = tid + m * P::NT;
         if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
+            const int sb = sw(u * SI::R);
             cd v[SI::R];
 #pragma unroll
-            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(u * SI::R + j)];
+            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw_off(sb, j)];
             agpr_fence<P>();
             Dft<SI::R>::run(v);
             agpr_fence<P>();
@@ -291,9 +305,10 @@ __device__ __forceinline__ void last_stage_acc_global(const cd* __restrict__ lds
             for (int h = 0; h < Q; ++h) buf[(m + 1) & 1][h] = row((m + 1) * Q + h)[tid];
         }
         if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
+            const int sb = sw(u * SI::R);
             cd v[SI::R];
 #pragma unroll
-            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw(u * SI::R + j)];
+            for (int j = 0; j < SI::R; ++j) v[j] = lds[sw_off(sb, j)];
             agpr_fence<P>();
             Dft<SI::R>::run(v);
             agpr_fence<P>();
@@ -518,7 +533,11 @@ __global__ void __launch_bounds__(P::NT)
         }
     };
     long unit = 0;
-    if (unit < n_mine) gather_issue_range<P, VEC, 0, NLOAD>(unit_col(0), ld_row, T, unit_kind(0), tid);
+    // byte offset of this lane's row tid inside any column; 32 zero bytes behind the tables
+    const unsigned long lane_off = (unsigned long)(unsigned)tid * ((unsigned long)ld_row * 8ul);
+    const cd* zeros = tw2 + 4 * P::M;
+    if (unit < n_mine)
+        gather_issue_range<P, VEC, 0, NLOAD>(unit_col(0), ld_row, T, unit_kind(0), tid, lane_off, zeros);
     auto no_hook = [](int) {};
     while (unit < n_mine) {
         // per-lane addresses and table offsets depend on tid/ld_row only: keep LICM from
@@ -543,7 +562,7 @@ __global__ void __launch_bounds__(P::NT)
 #define TA_PIECE(S)                                                                            \
     if (slot_ == S)                                                                            \
         gather_issue_range<P, VEC, NB + TA_W(S) * UA, NB + TA_W((S) + 1) * UA, NLOAD, 4 * NL>( \
-            ncol, ld_row, T, nkind, tid);
+            ncol, ld_row, T, nkind, tid, lane_off, zeros);
                     TA_PIECE(0) TA_PIECE(1) TA_PIECE(2) TA_PIECE(3) TA_PIECE(4) TA_PIECE(5)
                     TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
                     TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)
@@ -560,7 +579,7 @@ __global__ void __launch_bounds__(P::NT)
 #define TA_PIECE(S)                                                                          \
     if (slot_ == S) {                                                                        \
         gather_issue_range<P, VEC, TA_W(S) * UB, TA_W((S) + 1) * UB, NB>(ncol, ld_row, T,    \
-                                                                        nkind, tid);        \
+                                                     nkind, tid, lane_off, zeros);          \
         if constexpr ((S) >= S0::K - KL && (S) < S0::K) {                                    \
             static_for<4 * S0::R>([&](auto dd) {                                             \
                 constexpr int a = agpr_base<P>() + 4 * (S)*S0::R + decltype(dd)::value;      \
@@ -617,7 +636,7 @@ __global__ void __launch_bounds__(P::NT)
                                            : S0::K * UNIT + MIDSLOTS * 2 * UNIT + ((S)-S0::K - MIDSLOTS) * UNIT)
 #define TA_PIECE(S)                                                                         \
     if (slot_ == S)                                                                         \
-        gather_issue_range<P, VEC, TA_LO(S), TA_LO((S) + 1)>(ncol, ld_row, T, nkind, tid);
+        gather_issue_range<P, VEC, TA_LO(S), TA_LO((S) + 1)>(ncol, ld_row, T, nkind, tid, lane_off, zeros);
                 TA_PIECE(0) TA_PIECE(1) TA_PIECE(2) TA_PIECE(3) TA_PIECE(4) TA_PIECE(5)
                 TA_PIECE(6) TA_PIECE(7) TA_PIECE(8) TA_PIECE(9) TA_PIECE(10) TA_PIECE(11)
                 TA_PIECE(12) TA_PIECE(13) TA_PIECE(14) TA_PIECE(15) TA_PIECE(16) TA_PIECE(17)

@@ -19,7 +19,7 @@ struct FftArgs {
     long n_cols;   // accum: columns of the shard (n_atoms * D)
     long n_atoms;  // by_particle
     int D;
-    const cd* tw2;        // [0,2M): W_{2M}^n; [2M,3M): first-stage table pass A; [3M,4M): pass B
+    const cd* tw2;        // [0,2M): W_{2M}^n; [2M,3M): first-stage table pass A; [3M,4M): pass B; [4M,4M+2): zeros
     double* partial;      // accum: [nwg][2][quads*2*NT] float64, zeroed by the caller
     const double* spec;   // finalize: [n_slices][2][M]
     int n_slices;
