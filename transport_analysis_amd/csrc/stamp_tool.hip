@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     std::vector<double> h((size_t)T * C);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (double)((i * 2654435761u) % 1000) / 500.0 - 1.0;
     CK(hipMemcpy(vel, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
-    std::vector<cd> tw(4 * P::M);
+    std::vector<cd> tw(4 * P::M + 2, cd{0.0, 0.0});
     for (int n = 0; n < 2 * P::M; ++n) tw[n] = cd{cos(M_PI * n / P::M), -sin(M_PI * n / P::M)};
     { const int R0 = StageInfo<P, 0>::R; const long L0 = P::M / R0;
       for (int B = 0; B < 2; ++B) for (long q = 0; q < R0; ++q) for (long u = 0; u < L0; ++u) {
