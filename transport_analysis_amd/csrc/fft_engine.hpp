@@ -367,6 +367,9 @@ __device__ __forceinline__ void inv_stage_lds_fast(cd* __restrict__ lds,
 
 template <class P, int s>
 __device__ __forceinline__ void inv_all_stages(cd* lds, const cd* tw2, int tid) {
+    // per-thread twiddle seeds and addresses depend on tid only: inside a loop over atoms LICM
+    // would hoist them out and keep (spill) them across the whole forward pipeline
+    asm volatile("" : "+v"(tid));
     inv_stage_lds_fast<P, s>(lds, tw2, tid);
     __syncthreads();
     if constexpr (s > 0) inv_all_stages<P, s - 1>(lds, tw2, tid);
@@ -386,6 +389,9 @@ __device__ __forceinline__ void fwd_stage_lds_seeded(cd* __restrict__ lds, cd se
     // chain (R-1 complex values per stage) out of the pair loop and spill it; laundering
     // the seed keeps the chain where it is used.
     asm volatile("" : "+v"(seed.x), "+v"(seed.y));
+    // likewise the LDS addresses in the by-particle kernels (register file full: CSE across the
+    // passes spills them; measured -2 % there, +1 % on the landing kernels, which keep the CSE)
+    if constexpr (!P::kLanding) asm volatile("" : "+v"(tid));
     const cd seed2 = cmul(seed, seed);
     const double c2 = 2.0 * seed2.x;
 #pragma unroll

@@ -227,6 +227,7 @@ template <class P, class Hook>
 __device__ __forceinline__ void last_stage_acc_agpr(const cd* __restrict__ lds, int tid,
                                                     Hook&& after_task) {
     using SI = StageInfo<P, P::S - 1>;
+    asm volatile("" : "+v"(tid));  // LDS addresses re-formed here, not carried (and spilled) across stages
     static_for<SI::K>([&](auto mm) {
         constexpr int m = decltype(mm)::value;
         const int u = tid + m * P::NT;
@@ -256,6 +257,7 @@ __device__ __forceinline__ void last_stage_acc_regs(
     const cd* __restrict__ lds,
     double (&acc)[StageInfo<P, P::S - 1>::K][StageInfo<P, P::S - 1>::R], int tid, Hook&& after_task) {
     using SI = StageInfo<P, P::S - 1>;
+    if constexpr (!P::kLanding) asm volatile("" : "+v"(tid));  // see fwd_stage_lds_seeded
     static_for<SI::K>([&](auto mm) {
         constexpr int m = decltype(mm)::value;
         const int u = tid + m * P::NT;
