@@ -122,7 +122,12 @@ int ta_helfand_msd_dev(ta_ctx *ctx, const double *d_vel, const double *d_pos,
  * have completed.                                                            */
 int ta_last_timing(ta_ctx *ctx, float *total_ms, float *main_kernel_ms);
 /* FFT length bookkeeping for a given n_frames: *m_out = padded half-length M
- * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1).        */
+ * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1).  Up to
+ * M = 10240 the transform runs on chip; up to 16 x 10240 the lag sums (no
+ * by-particle output) use an outer radix step around the on-chip transform
+ * (n_stages counts it); beyond that, and for by-particle output past 10240
+ * frames, ta_vacf_fft* compute the same quantity with the direct correlator
+ * and this call returns TA_E_UNSUPPORTED.                                     */
 int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_stages);
 /* options (key, value):
  *   "direct_f32" 0|1 : direct correlators (ta_vacf_direct*, ta_helfand_msd*) evaluate

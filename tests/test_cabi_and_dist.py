@@ -43,7 +43,11 @@ def test_plan_info():
     for T, M in ((1, 16), (16, 16), (17, 20), (1000, 1024), (1025, 1280), (5001, 5120),
                  (10000, 10240), (10240, 10240)):
         assert _lib.fft_plan_info(T)["M"] == M
-    assert _lib.fft_plan_info(10241) is None  # handled by the direct correlator
+    # beyond the on-chip plans: outer radix R x on-chip M (lag sums; csrc/fft_long.hip)
+    for T, M in ((10241, 16384), (16385, 20480), (20481, 32768), (40961, 65536), (163840, 163840)):
+        info = _lib.fft_plan_info(T)
+        assert info["M"] == M and info["n_threads"] == 256
+    assert _lib.fft_plan_info(163841) is None  # handled by the direct correlator
 
 
 def test_atom_shard_partition():

@@ -296,6 +296,42 @@ def test_vacf_long_trajectory(ctx, fft):
     assert scale_rel_err(ts, want_ts) < TOL
 
 
+@pytest.mark.parametrize("T,A,D", [(10241, 3, 3), (12000, 5, 3), (16385, 2, 2), (20000, 4, 3),
+                                   (20481, 3, 1), (33000, 2, 3), (50000, 1, 3), (70000, 1, 2)])
+def test_vacf_fft_long_trajectory_timeseries(ctx, T, A, D):
+    """fft=True, lag sums only, n_frames beyond the largest on-chip transform: outer radix
+    2/4/8 step on the fly + on-chip 8192/10240-point transforms (csrc/fft_long.hip); covers
+    both on-chip plans, an odd column count (unpaired last column) and rows past the end."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(T, A, D, seed=T % 1000 + A)
+    _, want_ts = orc.vacf_fft_batched(v)
+    ts, bp = run_vacf(ctx, v, True, False)
+    assert bp is None
+    assert ts.shape == want_ts.shape
+    assert scale_rel_err(ts, want_ts) < TOL
+
+
+def test_vacf_fft_long_trajectory_many_pairs_and_step_kat(ctx):
+    """More column pairs than workgroups (several pairs per workgroup, accumulator blocks
+    carried across pairs), and the reference's closed-form step trajectory at N = 12001."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(10500, 400, 3, seed=5)
+    _, want_ts = orc.vacf_fft_batched(v)
+    ts, _ = run_vacf(ctx, v, True, False)
+    assert scale_rel_err(ts, want_ts) < TOL
+    # the reference's step trajectory v[t] = t (test_velocityautocorr.py:59-93), N = 12001:
+    # lag k is 3 * sum_i i (i + k) / (N - k), exact in integers
+    n = 12001
+    vs, _ = step(n)
+    ts, _ = run_vacf(ctx, vs, True, False)
+    lags = (0, 1, 7, 6000, 12000)
+    exact = np.array([3.0 * sum(i * (i + kk) for i in range(n - kk)) / (n - kk) for kk in lags])
+    got = ts[list(lags)]
+    assert np.max(np.abs(got - exact) / np.max(np.abs(exact))) < TOL
+
+
 def test_helfand_long_trajectory(ctx):
     from oracle import numpy_oracle as orc
 

@@ -23,6 +23,11 @@ struct Tables {
     cd* tw2 = nullptr;  // W_{2M}^n = exp(-i pi n / M), n < 2M
 };
 
+struct LongTables {     // fft_long.hip
+    cd* twL = nullptr;  // W_{2M'}^n, n < 2M'
+    int* perm = nullptr;  // plan M's output position -> frequency
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -36,6 +41,7 @@ struct ta_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     std::map<int, Tables> tables;
+    std::map<long, LongTables> long_tables;  // keyed by M'
     DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, f32_stage, stage_buf;
     // staging
     int64_t st_T = 0, st_A = 0;
@@ -122,6 +128,72 @@ int get_tables(ta_ctx* ctx, int M, int R0, Tables* out) {
     TA_HIP_TRY(ctx, hipMemcpy(t.tw2, a.data(), sizeof(cd) * (4 * (size_t)M + 2), hipMemcpyHostToDevice));
     ctx->tables[M] = t;
     *out = t;
+    return TA_OK;
+}
+
+int get_long_tables(ta_ctx* ctx, int M, int Rout, LongTables* out) {
+    const long Mp = (long)M * Rout;
+    auto it = ctx->long_tables.find(Mp);
+    if (it != ctx->long_tables.end()) {
+        *out = it->second;
+        return TA_OK;
+    }
+    std::vector<cd> a(2 * (size_t)Mp);
+    const long double pi = 3.141592653589793238462643383279502884L;
+    for (long n = 0; n < 2 * Mp; ++n) {
+        if (n == 0) a[n] = cd{1.0, 0.0};
+        else if (n == Mp) a[n] = cd{-1.0, 0.0};
+        else if (2 * n == Mp) a[n] = cd{0.0, -1.0};
+        else if (2 * n == 3 * Mp) a[n] = cd{0.0, 1.0};
+        else {
+            const long double h = pi * (long double)n / (long double)Mp;
+            a[n] = cd{(double)cosl(h), (double)-sinl(h)};
+        }
+    }
+    std::vector<int> perm;
+    fft_long_perm(M, perm);
+    LongTables t;
+    TA_HIP_TRY(ctx, hipMalloc((void**)&t.twL, sizeof(cd) * a.size()));
+    TA_HIP_TRY(ctx, hipMemcpy(t.twL, a.data(), sizeof(cd) * a.size(), hipMemcpyHostToDevice));
+    TA_HIP_TRY(ctx, hipMalloc((void**)&t.perm, sizeof(int) * perm.size()));
+    TA_HIP_TRY(ctx, hipMemcpy(t.perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice));
+    ctx->long_tables[Mp] = t;
+    *out = t;
+    return TA_OK;
+}
+
+const PlanEntry* plan_of_length(int M) {
+    for (const auto* tab : {&plans_pow2(), &plans_five()})
+        for (const auto& p : *tab)
+            if (p.M == M) return &p;
+    return nullptr;
+}
+
+// FFT lag sums for n_frames beyond the largest on-chip plan (fft_long.hip); timeseries only.
+int fft_long_impl(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int D, int64_t ld_row,
+                  double* d_lagsum, hipStream_t st, int M, int Rout) {
+    const PlanEntry* plan = plan_of_length(M);
+    if (!plan) return fail(ctx, TA_E_INVALID, "no on-chip plan for the long transform");
+    int rc;
+    Tables tb;
+    LongTables lt;
+    if ((rc = get_tables(ctx, M, plan->R_first, &tb))) return rc;
+    if ((rc = get_long_tables(ctx, M, Rout, &lt))) return rc;
+    const int64_t n_pairs = (A * D + 1) / 2;
+    int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu;
+    nwg = std::max<int64_t>(1, std::min(nwg, n_pairs));
+    if (nwg >= 8) nwg -= nwg % 8;  // XCD-aware walk
+    const size_t blk = fft_long_acc_block(M);
+    const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * Rout * blk;
+    if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->spec, sizeof(double) * 2 * (size_t)Rout * M))) return rc;
+    TA_HIP_TRY(ctx, hipMemsetAsync(ctx->partial.p, 0, acc_bytes, st));
+    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+    TA_HIP_TRY(ctx, launch_fft_long_accum(M, (int)nwg, st, d_vel, ld_row, (int)T, A * D, Rout, tb.tw2,
+                                          lt.twL, (double*)ctx->partial.p));
+    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+    TA_HIP_TRY(ctx, launch_fft_long_finish(M, Rout, (const double*)ctx->partial.p, (int)nwg, lt.perm,
+                                           lt.twL, (int)T, (double*)ctx->spec.p, d_lagsum, st));
     return TA_OK;
 }
 
@@ -253,6 +325,10 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     for (auto& kv : ctx->tables) {
         hipFree(kv.second.tw2);
     }
+    for (auto& kv : ctx->long_tables) {
+        hipFree(kv.second.twL);
+        hipFree(kv.second.perm);
+    }
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
                       &ctx->masses, &ctx->f32_stage, &ctx->stage_buf})
         if (b->p) hipFree(b->p);
@@ -277,7 +353,16 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
 
 int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_stages) {
     const PlanEntry* p = find_plan(n_frames);
-    if (!p) return fail(nullptr, TA_E_UNSUPPORTED, "n_frames exceeds the largest on-chip FFT plan");
+    int long_M = 0, long_R = 0;
+    if (!p && fft_long_choose((long)n_frames, &long_M, &long_R)) {
+        // outer radix step + on-chip transform (lag sums only; fft_long.hip)
+        const PlanEntry* q = plan_of_length(long_M);
+        if (m_out) *m_out = (int64_t)long_M * long_R;
+        if (n_threads) *n_threads = q ? q->NT : 0;
+        if (n_stages) *n_stages = q ? q->S + 1 : 0;
+        return TA_OK;
+    }
+    if (!p) return fail(nullptr, TA_E_UNSUPPORTED, "n_frames exceeds the largest FFT plan");
     if (m_out) *m_out = p->M;
     if (n_threads) *n_threads = p->NT;
     if (n_stages) *n_stages = p->S;
@@ -368,8 +453,18 @@ int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int 
     ctx->timing_valid = false;
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     const PlanEntry* plan = find_plan(T);
+    int long_M = 0, long_R = 0;
+    if (!plan && !d_bp && fft_long_choose((long)T, &long_M, &long_R)) {
+        // longer than the largest on-chip transform, lag sums only: outer radix step while
+        // the column is read, on-chip transforms of the derived series (fft_long.hip)
+        rc = fft_long_impl(ctx, d_vel, T, A, D, ld_row, d_lagsum, st, long_M, long_R);
+        if (rc) return rc;
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+        ctx->timing_valid = true;
+        return TA_OK;
+    }
     if (!plan) {
-        // longer than the largest on-chip transform: the direct correlator computes
+        // by-particle output (or longer than 16 x 10240 frames): the direct correlator computes
         // the same quantity (velocityautocorr.py:217-238 == :208-215 mathematically)
         rc = direct_impl(ctx, MODE_VACF, d_vel, nullptr, nullptr, T, A, D, ld_row, 1.0, d_lagsum,
                          d_bp, ld_bp, st);

@@ -1,0 +1,246 @@
+// fft_long.hip — FFT VACF lag sums for trajectories longer than the largest on-chip
+// transform (n_frames > 10240), timeseries path.
+//
+// Replaces the same reference code as fft_kernels.hpp (VelocityAutocorr._conclude_fft +
+// tidynamics.acf, /root/reference/transport_analysis/velocityautocorr.py:208-215) where a
+// column no longer fits one workgroup's LDS.
+//
+// Maths.  Pad to 2M' with M' = R*M >= n_frames, M an on-chip plan length (8192 or 10240) and R
+// the outer radix (2, 4, 8, 16).  Bin k = 2R*s + c (c < 2R, s < M) of the 2M'-point transform of
+// the zero-padded pair series z is one output of an M-point transform:
+//     Z[2R s + c] = FFT_M(u_c)[s],
+//     u_c[t] = W_{2M'}^{c t} * sum_{j<R} z[t + M j] * W_{2R}^{c j},     t < M
+// (a radix-2R decimation-in-frequency step done while the column is read).  So a workgroup
+// runs 2R passes per column pair, each the on-chip M-point transform of a series it forms
+// from R strided rows per element, and adds |.|^2 into that pass's accumulator block in
+// global memory.  The lag sums are linear in the summed spectrum; with P[k] summed over pairs
+//     lagsum[n] = (1 / (2M' (T - n))) * sum_k P[k] cos(pi k n / M'),     n < T,
+// evaluated directly (k_long_lags): one launch per analysis, O(T * M') table look-ups, where
+// an inverse transform of length 2M' would not fit on chip either.
+//
+// Cost: every pass re-reads the column (2R gathers per pair instead of one) and nothing is
+// software-pipelined: this path is O(T log T) with a large constant, meant to replace the
+// O(T^2) direct correlator beyond the on-chip limit, not to run at the headline rate.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "fft_kernels.hpp"
+#include "plans.hpp"
+#include "ta_internal.hpp"
+
+namespace ta {
+namespace {
+
+__device__ __forceinline__ cd cfma(cd acc, cd a, cd b) {  // acc + a*b
+    return {acc.x + (a.x * b.x - a.y * b.y), acc.y + (a.x * b.y + a.y * b.x)};
+}
+
+// accg: [gridDim.x][2*Rout][ACC_BLK] float64, zeroed by the caller; block layout as in
+// k_fft_accum ([quad][thread] x 2 doubles).  twL: W_{2M'}^n = exp(-i pi n / M'), n < 2M'.
+template <class P>
+__global__ void __launch_bounds__(P::NT)
+    k_fft_accum_long(const double* __restrict__ vel, long ld_row, int T, long n_cols, int Rout,
+                     const cd* __restrict__ tw2, const cd* __restrict__ twL,
+                     double* __restrict__ accg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd* lds = reinterpret_cast<cd*>(smem_raw);
+    using S0 = StageInfo<P, 0>;
+    constexpr long ACC_BLK = (long)acc_quads<P>() * 2 * P::NT;
+    const int nwg = gridDim.x, wg = blockIdx.x;
+    int slot = wg;
+    if (nwg % 8 == 0) slot = (wg % 8) * (nwg / 8) + wg / 8;  // XCD-aware walk, as k_fft_accum
+    const int tid = threadIdx.x;
+    const int L2 = 2 * Rout * P::M;  // table length 2M'
+    double* blk0 = accg + (long)wg * 2 * Rout * ACC_BLK;
+
+    cd seed[4];
+    seed[0] = cd{1.0, 0.0};
+    seed[1] = stage_seed<P, (P::S > 2 ? 1 : 0)>(tw2, tid);
+    seed[2] = stage_seed<P, (P::S > 3 ? 2 : 0)>(tw2, tid);
+    seed[3] = stage_seed<P, (P::S > 4 ? 3 : 0)>(tw2, tid);
+
+    const bool slab16 = ((reinterpret_cast<unsigned long long>(vel) | ((unsigned long long)ld_row * 8)) & 15) == 0;
+    const long n_pairs = (n_cols + 1) / 2;
+    auto no_hook = [](int) {};
+    for (long pair = slot; pair < n_pairs; pair += nwg) {
+        const double* col = vel + 2 * pair;
+        const bool two = 2 * pair + 1 < n_cols;  // an odd last column has no partner
+        for (int c = 0; c < 2 * Rout; ++c) {
+            // ---- first stage: the derived series u_c formed from R rows per element
+            static_for<S0::K>([&](auto mm) {
+                constexpr int m = decltype(mm)::value;
+                const int u = tid + m * P::NT;
+                if (S0::TASKS % P::NT == 0 || u < S0::TASKS) {
+                    cd w[S0::R];
+#pragma unroll
+                    for (int j0 = 0; j0 < S0::R; ++j0) {
+                        const int t1 = u + j0 * S0::L;
+                        cd a = {0.0, 0.0};
+                        for (int j = 0; j < Rout; ++j) {
+                            const int t = t1 + P::M * j;
+                            if (t < T) {
+                                const double* p = col + (long)t * ld_row;
+                                cd z;
+                                if (two && slab16) {
+                                    const double2 v = *reinterpret_cast<const double2*>(p);
+                                    z = cd{v.x, v.y};
+                                } else {
+                                    z = cd{p[0], two ? p[1] : 0.0};
+                                }
+                                a = cfma(a, z, twL[(c * j * P::M) % L2]);  // W_{2R}^{c j}
+                            }
+                        }
+                        w[j0] = cmul(a, twL[(c * j0 * S0::L) % L2]);  // W_{2M'}^{c j0 L}
+                    }
+                    Dft<S0::R>::run(w);
+                    // W_{2M'}^{c u} (common to the butterfly's inputs) merged with the stage
+                    // twiddle W_M^{u q} = W_{2M'}^{2R u q}
+                    const int sb = sw(u);
+#pragma unroll
+                    for (int q = 0; q < S0::R; ++q) {
+                        const int idx = (int)(((long)u * (c + 2 * Rout * q)) % L2);
+                        lds[sw_off(sb, q * S0::L)] = cmul(w[q], twL[idx]);
+                    }
+                }
+            });
+            __syncthreads();
+            mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, no_hook);
+            last_stage_acc_global<P>(lds, blk0 + (long)c * ACC_BLK, tid, no_hook);
+            __syncthreads();
+        }
+    }
+}
+
+// Sum the workgroups' blocks (fixed order) and put the spectrum into natural bin order:
+// P[2R*perm[p] + c] = sum_w block[w][c][(m, q)], p = u*R_last + q, u = tid + m*NT.
+__global__ void k_long_spectrum(const double* __restrict__ partial, int n_parts, int n_pass, int NT,
+                                int R, int K, int TASKS, const int* __restrict__ perm,
+                                double* __restrict__ spec) {
+    const int quads = (K * R + 1) / 2;
+    const long blk = (long)quads * 2 * NT;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // index within [n_pass][blk]
+    if (i >= (long)n_pass * blk) return;
+    const int c = (int)(i / blk);
+    const long r = i - c * blk;
+    const int comp = (int)(r & 1);
+    const long qt = r >> 1;  // quad*NT + tid
+    const int tid = (int)(qt % NT);
+    const int d = 2 * (int)(qt / NT) + comp;
+    if (d >= K * R) return;
+    const int m = d / R, q = d % R;
+    const int u = tid + m * NT;
+    if (u >= TASKS) return;
+    double s = 0.0;
+    for (int w = 0; w < n_parts; ++w) s += partial[(long)w * n_pass * blk + i];
+    spec[(long)n_pass * perm[u * R + q] + c] = s;
+}
+
+// lagsum[n] = sum_k P[k] cos(2 pi k n / L2) / (L2 (T - n)): one workgroup per lag, the table
+// index (k n) mod L2 advanced by a fixed step per thread, tree reduction in fixed order.
+__global__ void __launch_bounds__(256)
+    k_long_lags(const double* __restrict__ spec, const cd* __restrict__ twL, int L2, int T,
+                double* __restrict__ lagsum) {
+    __shared__ double red[256];
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x;
+    int idx = (int)(((long)tid * n) % L2);
+    const int step = (int)((256L * n) % L2);
+    double s = 0.0;
+    for (int k = tid; k < L2; k += 256) {
+        s += spec[k] * twL[idx].x;
+        idx += step;
+        if (idx >= L2) idx -= L2;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) red[tid] += red[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) lagsum[n] = red[0] / ((double)L2 * (double)(T - n));  // L2 (T-n) < 2^53: exact
+}
+
+template <class P>
+hipError_t launch_accum(int nwg, hipStream_t st, const double* vel, long ld_row, int T, long n_cols,
+                        int Rout, const cd* tw2, const cd* twL, double* accg) {
+    const size_t lds = (size_t)P::lds_elems() * sizeof(cd);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_accum_long<P>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_fft_accum_long<P>), dim3(nwg), dim3(P::NT), lds, st, vel, ld_row, T, n_cols,
+                       Rout, tw2, twL, accg);
+    return hipGetLastError();
+}
+
+using PlanA = Plan<256, 16, 8, 8, 8>;      // M = 8192
+using PlanB = Plan<256, 5, 16, 16, 8>;     // M = 10240
+
+template <class P>
+void digit_perm(std::vector<int>& perm) {
+    // position p = q0*(M/r0) + q1*(M/(r0 r1)) + ... holds frequency s = q0 + r0*(q1 + r1*(...))
+    perm.assign(P::M, 0);
+    for (int s = 0; s < P::M; ++s) {
+        int rest = s, p = 0, block = P::M;
+        for (int st = 0; st < P::S; ++st) {
+            const int r = P::radix(st);
+            block /= r;
+            p += (rest % r) * block;
+            rest /= r;
+        }
+        perm[p] = s;
+    }
+}
+
+}  // namespace
+
+bool fft_long_choose(long n_frames, int* M, int* Rout) {
+    long best = 0;
+    for (int R = 2; R <= 16; R *= 2)
+        for (int m : {PlanA::M, PlanB::M}) {
+            const long mp = (long)R * m;
+            if (mp >= n_frames && (best == 0 || mp < best)) {
+                best = mp;
+                *M = m;
+                *Rout = R;
+            }
+        }
+    return best != 0;
+}
+
+void fft_long_perm(int M, std::vector<int>& perm) {
+    if (M == PlanA::M) digit_perm<PlanA>(perm);
+    else digit_perm<PlanB>(perm);
+}
+
+size_t fft_long_acc_block(int M) {  // doubles per workgroup and pass
+    return (size_t)(M == PlanA::M ? acc_quads<PlanA>() * 2 * PlanA::NT : acc_quads<PlanB>() * 2 * PlanB::NT);
+}
+
+hipError_t launch_fft_long_accum(int M, int nwg, hipStream_t st, const double* vel, long ld_row, int T,
+                                 long n_cols, int Rout, const cd* tw2, const cd* twL, double* accg) {
+    if (M == PlanA::M) return launch_accum<PlanA>(nwg, st, vel, ld_row, T, n_cols, Rout, tw2, twL, accg);
+    return launch_accum<PlanB>(nwg, st, vel, ld_row, T, n_cols, Rout, tw2, twL, accg);
+}
+
+hipError_t launch_fft_long_finish(int M, int Rout, const double* partial, int n_parts, const int* perm,
+                                  const cd* twL, int T, double* spec, double* lagsum, hipStream_t st) {
+    int NT, R, K, TASKS;
+    if (M == PlanA::M) {
+        using SL = StageInfo<PlanA, PlanA::S - 1>;
+        NT = PlanA::NT, R = SL::R, K = SL::K, TASKS = SL::TASKS;
+    } else {
+        using SL = StageInfo<PlanB, PlanB::S - 1>;
+        NT = PlanB::NT, R = SL::R, K = SL::K, TASKS = SL::TASKS;
+    }
+    const int n_pass = 2 * Rout;
+    const long n = (long)n_pass * ((K * R + 1) / 2) * 2 * NT;
+    hipLaunchKernelGGL(k_long_spectrum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial,
+                       n_parts, n_pass, NT, R, K, TASKS, perm, spec);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_long_lags, dim3(T), dim3(256), 0, st, spec, twL, n_pass * M, T, lagsum);
+    return hipGetLastError();
+}
+
+}  // namespace ta

@@ -59,6 +59,15 @@ hipError_t launch_sum_partials(const double* partial, int n_parts, long n, doubl
 // spec[pass*M + u*R + q] = sum over workgroups of their accumulator (m, q), u = tid + m*NT
 hipError_t launch_sum_partials_perm(const double* partial, int n_parts, int M, int NT, int R, int K,
                                     int TASKS, double* out, int n_slices, hipStream_t st);
+// fft_long.hip: FFT lag sums beyond the on-chip transform length (timeseries path)
+bool fft_long_choose(long n_frames, int* M, int* Rout);  // smallest M' = Rout*M >= n_frames
+void fft_long_perm(int M, std::vector<int>& perm);       // position -> frequency of plan M's output
+size_t fft_long_acc_block(int M);                        // doubles per workgroup and pass
+hipError_t launch_fft_long_accum(int M, int nwg, hipStream_t st, const double* vel, long ld_row, int T,
+                                 long n_cols, int Rout, const cd* tw2, const cd* twL, double* accg);
+hipError_t launch_fft_long_finish(int M, int Rout, const double* partial, int n_parts, const int* perm,
+                                  const cd* twL, int T, double* spec, double* lagsum, hipStream_t st);
+
 hipError_t launch_widen_f32(const float* in, double* out, long n, hipStream_t st);
 
 }  // namespace ta
