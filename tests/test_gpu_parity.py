@@ -297,10 +297,11 @@ def test_vacf_long_trajectory(ctx, fft):
 
 
 @pytest.mark.parametrize("T,A,D", [(10241, 3, 3), (12000, 5, 3), (16385, 2, 2), (20000, 4, 3),
-                                   (20481, 3, 1), (33000, 2, 3), (50000, 1, 3), (70000, 1, 2)])
+                                   (20481, 3, 1), (33000, 2, 3), (50000, 1, 3), (70000, 1, 2),
+                                   (90000, 1, 1), (140000, 1, 2), (163840, 1, 1)])
 def test_vacf_fft_long_trajectory_timeseries(ctx, T, A, D):
     """fft=True, lag sums only, n_frames beyond the largest on-chip transform: outer radix
-    2/4/8 step on the fly + on-chip 8192/10240-point transforms (csrc/fft_long.hip); covers
+    2/4/8/16 step on the fly + on-chip 8192/10240-point transforms (csrc/fft_long.hip); covers
     both on-chip plans, an odd column count (unpaired last column) and rows past the end."""
     from oracle import numpy_oracle as orc
 
