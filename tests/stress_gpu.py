@@ -39,7 +39,7 @@ def host_cases(n_cases, seed):
                 slabs[1][lo:hi] = x[lo:hi]
             ctx.stage_commit(lo, hi)
         v64, x64 = v.astype(np.float64), x.astype(np.float64)
-        by_particle = bool(rng.random() < 0.5)
+        by_particle = bool(rng.random() < 0.5) and kind != "fftlong"
         if kind == "helfand":
             scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
             ts, bp = ctx.helfand_msd(m, scale, by_particle=by_particle)
@@ -78,8 +78,12 @@ def main(n_cases, seed=1234):
     edges = [16, 20, 32, 40, 64, 80, 128, 160, 256, 320, 512, 640, 1024, 1280, 2048, 2560, 4096,
              5120, 8192, 10240]
     for case in range(n_cases):
-        kind = rng.choice(["fft", "fft", "fft", "direct", "helfand"])
-        if kind == "fft":
+        kind = rng.choice(["fft", "fft", "fft", "direct", "helfand", "fftlong"])
+        if kind == "fftlong":  # beyond the on-chip transform: lag sums through csrc/fft_long.hip
+            T = int(rng.choice([10241, 16384, 16385, 20480, 20481, 32769, 40961])) if rng.random() < 0.4 \
+                else int(rng.integers(10241, 60000))
+            A_all = int(rng.integers(1, 7))
+        elif kind == "fft":
             e = int(rng.choice(edges))
             T = int(np.clip(e + rng.integers(-3, 2), 1, 10240)) if rng.random() < 0.6 else int(rng.integers(1, 10241))
             A_all = int(rng.integers(1, 24 if T > 3000 else 60))
@@ -94,17 +98,17 @@ def main(n_cases, seed=1234):
         dv, dx = torch.from_numpy(v).cuda(), torch.from_numpy(x).cuda()
         dm = torch.from_numpy(m[lo:hi].copy()).cuda()
         ld_row, off = A_all * D, lo * D * 8
-        by_particle = bool(rng.random() < 0.5)
+        by_particle = bool(rng.random() < 0.5) and kind != "fftlong"
         ld_bp = A + int(rng.integers(0, 3))
         ctx.set_option("fft_nwg", int(rng.choice([0, 0, 1, 2, 3, 8, 16])))
         ctx.set_option("direct_nwg", int(rng.choice([0, 0, 1, 2, 5])))
-        f32 = int(kind != "fft" and rng.random() < 0.3)
+        f32 = int(kind in ("direct", "helfand") and rng.random() < 0.3)
         ctx.set_option("direct_f32", f32)
         lag = torch.full((T,), -3.0, dtype=torch.float64, device="cuda")
         bp = torch.full((T, ld_bp), -7.0, dtype=torch.float64, device="cuda")
         d_bp = bp.data_ptr() if by_particle else 0
         vs, xs = v[:, lo:hi], x[:, lo:hi]
-        if kind == "fft":
+        if kind in ("fft", "fftlong"):
             ctx.vacf_fft_dev(dv.data_ptr() + off, T, A, D, ld_row, lag.data_ptr(), d_bp, ld_bp, st)
             want_bp, _ = orc.vacf_fft_batched(vs)
         elif kind == "direct":
