@@ -210,7 +210,7 @@ def main():
         try:
             rec = json.load(open(tfile))
             key = f"{args.mode}_{T}x{A}x{D}"
-            if key in rec:
+            if key in rec and not args.by_particle:
                 traffic = rec[key]["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -228,7 +228,9 @@ def main():
         "dtype": "f32 (f64 inputs and accumulators)" if args.float32 else "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"{'FFT' if args.mode == 'fft' else args.mode} VACF timeseries, {T} frames x {A} atoms x {D} float64 per GPU"
+            "workload": {"fft": "FFT VACF", "direct": "windowed (direct) VACF", "helfand": "Helfand MSD"}[args.mode]
+                        + (" with the by-particle array" if args.by_particle else " timeseries")
+                        + f", {T} frames x {A} atoms x {D} float64 per GPU"
                         + (" (BASELINE configs[2] shape)" if (T, A, D, args.mode) == (10000, 100000, 3, "fft") else ""),
             "n_frames": T, "n_atoms_per_gpu": A, "dim": D, "mode": args.mode,
             "by_particle": bool(args.by_particle), "sharding": f"atoms x{world}",
@@ -237,11 +239,22 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-            "kernel": "k_fft_accum" if args.mode == "fft" else "k_direct",
+            "kernel": ("k_fft_accum" if T <= 10240 or args.by_particle else "k_fft_accum_long")
+                      if args.mode == "fft" else "k_direct",
             "kernel_ms": main_ms, "algorithmic_bytes_per_launch": bytes_algo,
         },
         "check": {"max_scale_rel_err_vs_torch_lags": max(errs) if errs else None},
     }
+    if args.mode != "fft":
+        # the direct correlators are bound by the vector FP issue rate:
+        # windowed VACF 2*D*A*T(T+1)/2 flop, Helfand 3*D*A*T(T-1)/2; HBM is touched once
+        flops = (2.0 * D * A * T * (T + 1) / 2) if args.mode == "direct" else (3.0 * D * A * T * (T - 1) / 2)
+        peak = 157.3 if args.float32 else 78.6
+        tf = flops / (main_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                           "frac": tf / peak, "traffic": None, "kernel": "k_direct", "kernel_ms": main_ms,
+                           "algorithmic_flops_per_launch": flops,
+                           "hbm_GBps_for_reference": achieved}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, T, D)
     print(json.dumps(out), flush=True)
