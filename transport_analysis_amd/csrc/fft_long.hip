@@ -15,8 +15,9 @@
 // from R strided rows per element, and adds |.|^2 into that pass's accumulator block in
 // global memory.  The lag sums are linear in the summed spectrum; with P[k] summed over pairs
 //     lagsum[n] = (1 / (2M' (T - n))) * sum_k P[k] cos(pi k n / M'),     n < T,
-// evaluated directly (k_long_lags): one launch per analysis, O(T * M') table look-ups, where
-// an inverse transform of length 2M' would not fit on chip either.
+// evaluated directly (k_long_lags, over the spectrum folded about k = M'): one launch per
+// analysis, O(T * M') table look-ups, where an inverse transform of length 2M' would not fit on
+// chip either.
 //
 // Cost: every pass re-reads the column (2R gathers per pair instead of one) and nothing is
 // software-pipelined: this path is O(T log T) with a large constant, meant to replace the
@@ -136,8 +137,16 @@ __global__ void k_long_spectrum(const double* __restrict__ partial, int n_parts,
     spec[(long)n_pass * perm[u * R + q] + c] = s;
 }
 
-// lagsum[n] = sum_k P[k] cos(2 pi k n / L2) / (L2 (T - n)): one workgroup per lag, the table
-// index (k n) mod L2 advanced by a fixed step per thread, tree reduction in fixed order.
+// The cosine is even in k about L2/2: fold P[k] + P[L2-k] once (in place, k <= L2/2), which
+// halves the table look-ups of every lag.
+__global__ void k_long_fold(double* __restrict__ spec, int L2) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > 0 && k < L2 / 2) spec[k] += spec[L2 - k];
+}
+
+// lagsum[n] = sum_k P[k] cos(2 pi k n / L2) / (L2 (T - n)) over the folded spectrum (k <= L2/2):
+// one workgroup per lag, the table index (k n) mod L2 advanced by a fixed step per thread,
+// tree reduction in fixed order.
 __global__ void __launch_bounds__(256)
     k_long_lags(const double* __restrict__ spec, const cd* __restrict__ twL, int L2, int T,
                 double* __restrict__ lagsum) {
@@ -147,7 +156,7 @@ __global__ void __launch_bounds__(256)
     int idx = (int)(((long)tid * n) % L2);
     const int step = (int)((256L * n) % L2);
     double s = 0.0;
-    for (int k = tid; k < L2; k += 256) {
+    for (int k = tid; k <= L2 / 2; k += 256) {
         s += spec[k] * twL[idx].x;
         idx += step;
         if (idx >= L2) idx -= L2;
@@ -238,6 +247,10 @@ hipError_t launch_fft_long_finish(int M, int Rout, const double* partial, int n_
     hipLaunchKernelGGL(k_long_spectrum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial,
                        n_parts, n_pass, NT, R, K, TASKS, perm, spec);
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_long_fold, dim3((unsigned)((n_pass * M / 2 + 255) / 256)), dim3(256), 0, st, spec,
+                       n_pass * M);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_long_lags, dim3(T), dim3(256), 0, st, spec, twL, n_pass * M, T, lagsum);
     return hipGetLastError();
