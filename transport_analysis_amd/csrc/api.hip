@@ -42,7 +42,7 @@ struct ta_ctx {
     std::string err;
     std::map<int, Tables> tables;
     std::map<long, LongTables> long_tables;  // keyed by M'
-    DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, f32_stage, stage_buf;
+    DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, f32_stage, stage_buf, long_scratch;
     // staging
     int64_t st_T = 0, st_A = 0;
     int st_D = 0, st_dtype = TA_F64, st_nslabs = 0;
@@ -187,10 +187,11 @@ int fft_long_impl(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int D,
     const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * Rout * blk;
     if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->spec, sizeof(double) * 2 * (size_t)Rout * M))) return rc;
+    if ((rc = ensure(ctx, ctx->long_scratch, sizeof(cd) * (size_t)nwg * 2 * Rout * M))) return rc;
     TA_HIP_TRY(ctx, hipMemsetAsync(ctx->partial.p, 0, acc_bytes, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     TA_HIP_TRY(ctx, launch_fft_long_accum(M, (int)nwg, st, d_vel, ld_row, (int)T, A * D, Rout, tb.tw2,
-                                          lt.twL, (double*)ctx->partial.p));
+                                          lt.twL, (double*)ctx->partial.p, (cd*)ctx->long_scratch.p));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     TA_HIP_TRY(ctx, launch_fft_long_finish(M, Rout, (const double*)ctx->partial.p, (int)nwg, lt.perm,
                                            lt.twL, (int)T, (double*)ctx->spec.p, d_lagsum, st));
@@ -330,7 +331,7 @@ int ta_ctx_destroy(ta_ctx* ctx) {
         hipFree(kv.second.perm);
     }
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
-                      &ctx->masses, &ctx->f32_stage, &ctx->stage_buf})
+                      &ctx->masses, &ctx->f32_stage, &ctx->stage_buf, &ctx->long_scratch})
         if (b->p) hipFree(b->p);
     for (auto& ev : ctx->ev)
         if (ev) hipEventDestroy(ev);

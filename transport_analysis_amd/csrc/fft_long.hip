@@ -19,9 +19,10 @@
 // analysis, O(T * M') table look-ups, where an inverse transform of length 2M' would not fit on
 // chip either.
 //
-// Cost: every pass re-reads the column (2R gathers per pair instead of one) and nothing is
-// software-pipelined: this path is O(T log T) with a large constant, meant to replace the
-// O(T^2) direct correlator beyond the on-chip limit, not to run at the headline rate.
+// Cost: the column is gathered once per pair; the 2R derived series cross L2 twice (2R*M*16
+// bytes written and read back per pair) and nothing is software-pipelined: O(T log T) with a
+// larger constant than the on-chip path, meant to replace the O(T^2) direct correlator beyond
+// the on-chip limit.
 #include <hip/hip_runtime.h>
 
 #include <vector>
@@ -39,11 +40,18 @@ __device__ __forceinline__ cd cfma(cd acc, cd a, cd b) {  // acc + a*b
 
 // accg: [gridDim.x][2*Rout][ACC_BLK] float64, zeroed by the caller; block layout as in
 // k_fft_accum ([quad][thread] x 2 doubles).  twL: W_{2M'}^n = exp(-i pi n / M'), n < 2M'.
+// scratch: [gridDim.x][2*Rout][M] complex: the column is gathered ONCE per pair (phase 0: R
+// strided rows per element, all in flight together) and the 2R partial sums
+// a_c[t] = sum_j z[t + M j] W_{2R}^{c j} go to the workgroup's scratch (lane = row: contiguous
+// 1 KB stores), from which pass c reads its series back contiguously -- a thread reads exactly
+// the elements it wrote.  Per pair: R*M scattered 16-byte requests instead of 2R*R*M.
+constexpr int kMaxRout = 16;
+
 template <class P>
 __global__ void __launch_bounds__(P::NT)
     k_fft_accum_long(const double* __restrict__ vel, long ld_row, int T, long n_cols, int Rout,
                      const cd* __restrict__ tw2, const cd* __restrict__ twL,
-                     double* __restrict__ accg) {
+                     double* __restrict__ accg, cd* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
     using S0 = StageInfo<P, 0>;
@@ -54,6 +62,8 @@ __global__ void __launch_bounds__(P::NT)
     const int tid = threadIdx.x;
     const int L2 = 2 * Rout * P::M;  // table length 2M'
     double* blk0 = accg + (long)wg * 2 * Rout * ACC_BLK;
+    cd* scr = scratch + (long)wg * 2 * Rout * P::M;
+    const double* zeros = reinterpret_cast<const double*>(tw2 + 4 * P::M);  // 32 zero bytes
 
     cd seed[4];
     seed[0] = cd{1.0, 0.0};
@@ -67,43 +77,87 @@ __global__ void __launch_bounds__(P::NT)
     for (long pair = slot; pair < n_pairs; pair += nwg) {
         const double* col = vel + 2 * pair;
         const bool two = 2 * pair + 1 < n_cols;  // an odd last column has no partner
-        for (int c = 0; c < 2 * Rout; ++c) {
-            // ---- first stage: the derived series u_c formed from R rows per element
-            static_for<S0::K>([&](auto mm) {
-                constexpr int m = decltype(mm)::value;
-                const int u = tid + m * P::NT;
-                if (S0::TASKS % P::NT == 0 || u < S0::TASKS) {
-                    cd w[S0::R];
+        const bool wide = two && slab16;         // one 16-byte load per row
+        // ---- phase 0: gather once, partial sums of all 2R passes -> scratch
+        for (int m = 0; m < S0::K; ++m) {
+            const int u = tid + m * P::NT;
+            if (!(S0::TASKS % P::NT == 0 || u < S0::TASKS)) continue;
+            for (int j0 = 0; j0 < S0::R; ++j0) {
+                const int t1 = u + j0 * S0::L;
+                cd z[kMaxRout];
 #pragma unroll
-                    for (int j0 = 0; j0 < S0::R; ++j0) {
-                        const int t1 = u + j0 * S0::L;
-                        cd a = {0.0, 0.0};
-                        for (int j = 0; j < Rout; ++j) {
-                            const int t = t1 + P::M * j;
-                            if (t < T) {
-                                const double* p = col + (long)t * ld_row;
-                                cd z;
-                                if (two && slab16) {
-                                    const double2 v = *reinterpret_cast<const double2*>(p);
-                                    z = cd{v.x, v.y};
-                                } else {
-                                    z = cd{p[0], two ? p[1] : 0.0};
-                                }
-                                a = cfma(a, z, twL[(c * j * P::M) % L2]);  // W_{2R}^{c j}
-                            }
+                for (int j = 0; j < kMaxRout; ++j) {
+                    if (j < Rout) {  // wave-uniform
+                        const int t = t1 + P::M * j;
+                        // rows past the end are the zero padding: read the zero block instead
+                        const double* p = t < T ? col + (long)t * ld_row : zeros;
+                        if (wide) {
+                            const double2 v = *reinterpret_cast<const double2*>(p);
+                            z[j] = cd{v.x, v.y};
+                        } else {
+                            z[j] = cd{p[0], two ? p[1] : 0.0};
                         }
-                        w[j0] = cmul(a, twL[(c * j0 * S0::L) % L2]);  // W_{2M'}^{c j0 L}
-                    }
-                    Dft<S0::R>::run(w);
-                    // W_{2M'}^{c u} (common to the butterfly's inputs) merged with the stage
-                    // twiddle W_M^{u q} = W_{2M'}^{2R u q}
-                    const int sb = sw(u);
-#pragma unroll
-                    for (int q = 0; q < S0::R; ++q) {
-                        const int idx = (int)(((long)u * (c + 2 * Rout * q)) % L2);
-                        lds[sw_off(sb, q * S0::L)] = cmul(w[q], twL[idx]);
                     }
                 }
+                for (int c = 0; c < 2 * Rout; ++c) {
+                    cd a = z[0];
+#pragma unroll
+                    for (int j = 1; j < kMaxRout; ++j)
+                        if (j < Rout) a = cfma(a, z[j], twL[(c * j * P::M) % L2]);  // W_{2R}^{c j}
+                    scr[(long)c * P::M + t1] = a;
+                }
+            }
+        }
+        __threadfence();
+        for (int c = 0; c < 2 * Rout; ++c) {
+            // ---- first stage of pass c: u_c[t] = W_{2M'}^{c t} a_c[t].  Per butterfly u the inputs
+            // are scaled by the wave-uniform W_{2M'}^{c j0 L} (hoisted: tj), the outputs by
+            // W_{2M'}^{c u} * W_M^{u q} = h g^q (one table entry each per butterfly, powers by
+            // repeated multiplication); the next butterfly's operands are loaded while the
+            // current one is computed.
+            const cd* __restrict__ ac = scr + (long)c * P::M;
+            // per-butterfly offsets depend on tid only: formed here, per pass, or LICM hoists the
+            // lot out of both loops and spills it
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            cd tj[S0::R];
+#pragma unroll
+            for (int j0 = 0; j0 < S0::R; ++j0) tj[j0] = twL[(c * j0 * S0::L) % L2];
+            cd wbuf[2][S0::R], hb[2], gb[2];
+            auto fetch = [&](auto mc, int which) {
+                constexpr int m = decltype(mc)::value;
+                const int u = tl + m * P::NT;
+                if (S0::TASKS % P::NT == 0 || u < S0::TASKS) {
+#pragma unroll
+                    for (int j0 = 0; j0 < S0::R; ++j0) wbuf[which][j0] = ac[u + j0 * S0::L];
+                    hb[which] = twL[(unsigned)(u * c) % (unsigned)L2];  // W_{2M'}^{c u}
+                    gb[which] = tw2[2 * u];                              // W_M^u
+                }
+            };
+            fetch(std::integral_constant<int, 0>{}, 0);
+            static_for<S0::K>([&](auto mm) {
+                constexpr int m = decltype(mm)::value;
+                const int u = tl + m * P::NT;
+                if constexpr (m + 1 < S0::K) fetch(std::integral_constant<int, m + 1>{}, (m + 1) & 1);
+                // one butterfly ahead, not all of them (the scheduler would cluster every load
+                // of the unrolled stage at its top and spill)
+                __builtin_amdgcn_sched_barrier(0);
+                if (S0::TASKS % P::NT == 0 || u < S0::TASKS) {
+                    cd w[S0::R];
+                    w[0] = wbuf[m & 1][0];
+#pragma unroll
+                    for (int j0 = 1; j0 < S0::R; ++j0) w[j0] = cmul(wbuf[m & 1][j0], tj[j0]);
+                    Dft<S0::R>::run(w);
+                    const int sb = sw(u);
+                    cd te = hb[m & 1];
+                    const cd g = gb[m & 1];
+#pragma unroll
+                    for (int q = 0; q < S0::R; ++q) {
+                        lds[sw_off(sb, q * S0::L)] = cmul(w[q], te);
+                        te = cmul(te, g);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             });
             __syncthreads();
             mid_stages_seeded<P, 1, 0>(lds, tw2, seed, tid, no_hook);
@@ -172,13 +226,13 @@ __global__ void __launch_bounds__(256)
 
 template <class P>
 hipError_t launch_accum(int nwg, hipStream_t st, const double* vel, long ld_row, int T, long n_cols,
-                        int Rout, const cd* tw2, const cd* twL, double* accg) {
+                        int Rout, const cd* tw2, const cd* twL, double* accg, cd* scratch) {
     const size_t lds = (size_t)P::lds_elems() * sizeof(cd);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_accum_long<P>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_fft_accum_long<P>), dim3(nwg), dim3(P::NT), lds, st, vel, ld_row, T, n_cols,
-                       Rout, tw2, twL, accg);
+                       Rout, tw2, twL, accg, scratch);
     return hipGetLastError();
 }
 
@@ -227,9 +281,12 @@ size_t fft_long_acc_block(int M) {  // doubles per workgroup and pass
 }
 
 hipError_t launch_fft_long_accum(int M, int nwg, hipStream_t st, const double* vel, long ld_row, int T,
-                                 long n_cols, int Rout, const cd* tw2, const cd* twL, double* accg) {
-    if (M == PlanA::M) return launch_accum<PlanA>(nwg, st, vel, ld_row, T, n_cols, Rout, tw2, twL, accg);
-    return launch_accum<PlanB>(nwg, st, vel, ld_row, T, n_cols, Rout, tw2, twL, accg);
+                                 long n_cols, int Rout, const cd* tw2, const cd* twL, double* accg,
+                                 cd* scratch) {
+    if (Rout < 1 || Rout > kMaxRout) return hipErrorInvalidValue;
+    if (M == PlanA::M)
+        return launch_accum<PlanA>(nwg, st, vel, ld_row, T, n_cols, Rout, tw2, twL, accg, scratch);
+    return launch_accum<PlanB>(nwg, st, vel, ld_row, T, n_cols, Rout, tw2, twL, accg, scratch);
 }
 
 hipError_t launch_fft_long_finish(int M, int Rout, const double* partial, int n_parts, const int* perm,

@@ -64,7 +64,8 @@ bool fft_long_choose(long n_frames, int* M, int* Rout);  // smallest M' = Rout*M
 void fft_long_perm(int M, std::vector<int>& perm);       // position -> frequency of plan M's output
 size_t fft_long_acc_block(int M);                        // doubles per workgroup and pass
 hipError_t launch_fft_long_accum(int M, int nwg, hipStream_t st, const double* vel, long ld_row, int T,
-                                 long n_cols, int Rout, const cd* tw2, const cd* twL, double* accg);
+                                 long n_cols, int Rout, const cd* tw2, const cd* twL, double* accg,
+                                 cd* scratch /* [nwg][2*Rout][M] */);
 hipError_t launch_fft_long_finish(int M, int Rout, const double* partial, int n_parts, const int* perm,
                                   const cd* twL, int T, double* spec, double* lagsum, hipStream_t st);
 
