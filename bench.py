@@ -44,6 +44,8 @@ def parse():
                     help="also materialise vacf_by_particle (secondary number)")
     ap.add_argument("--float32", action="store_true",
                     help="direct / helfand modes: float32 products and block sums (configs[4])")
+    ap.add_argument("--helfand-fft", action="store_true",
+                    help="--mode helfand: the O(T log T) option (lag sums as S1 - 2 S2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-atoms", type=int, default=0)
     return ap.parse_args()
@@ -137,6 +139,10 @@ def main():
         if args.mode == "fft":
             raise SystemExit("--float32 applies to --mode direct / helfand")
         ctx.set_option("direct_f32", 1)
+    if args.helfand_fft:
+        if args.mode != "helfand" or args.by_particle or args.float32:
+            raise SystemExit("--helfand-fft applies to --mode helfand without --by-particle/--float32")
+        ctx.set_option("helfand_fft", 1)
     gen = torch.Generator(device=dev)
     gen.manual_seed(20250824 + 3 + 1000 * rank)
     vel = torch.randn((T, A, D), dtype=torch.float64, device=dev, generator=gen)
@@ -228,7 +234,8 @@ def main():
         "dtype": "f32 (f64 inputs and accumulators)" if args.float32 else "f64",
         "data": "synthetic",
         "config": {
-            "workload": {"fft": "FFT VACF", "direct": "windowed (direct) VACF", "helfand": "Helfand MSD"}[args.mode]
+            "workload": {"fft": "FFT VACF", "direct": "windowed (direct) VACF",
+                         "helfand": "Helfand MSD (FFT option)" if args.helfand_fft else "Helfand MSD"}[args.mode]
                         + (" with the by-particle array" if args.by_particle else " timeseries")
                         + f", {T} frames x {A} atoms x {D} float64 per GPU"
                         + (" (BASELINE configs[2] shape)" if (T, A, D, args.mode) == (10000, 100000, 3, "fft") else ""),
@@ -245,7 +252,7 @@ def main():
         },
         "check": {"max_scale_rel_err_vs_torch_lags": max(errs) if errs else None},
     }
-    if args.mode != "fft":
+    if args.mode != "fft" and not args.helfand_fft:
         # the direct correlators are bound by the vector FP issue rate:
         # windowed VACF 2*D*A*T(T+1)/2 flop, Helfand 3*D*A*T(T-1)/2; HBM is touched once
         flops = (2.0 * D * A * T * (T + 1) / 2) if args.mode == "direct" else (3.0 * D * A * T * (T - 1) / 2)

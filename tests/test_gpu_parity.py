@@ -527,6 +527,55 @@ def test_float32_direct_paths_vs_oracle(ctx, T, A, D):
     assert scale_rel_err(ts, orc.helfand(v, x, m, vol, 300.0)[1]) < TOL  # switch is off again
 
 
+@pytest.mark.parametrize("T,A,D", [(2, 3, 1), (9, 1, 1), (50, 6, 2), (300, 21, 3), (1001, 7, 3),
+                                   (5000, 5, 3), (10240, 2, 2), (12000, 3, 3), (25000, 2, 3)])
+def test_helfand_fft_option_vs_oracle(ctx, T, A, D):
+    """Option "helfand_fft" (extension, csrc/helfand_fft.hip): lag sums as S1 - 2 S2 with S2 from
+    the FFT path (on-chip and long-trajectory plans) -- same series as the reference's O(T^2)
+    loop to the north-star tolerance in the scale-relative metric; lag 0 exactly 0."""
+    from oracle import numpy_oracle as orc
+
+    v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=T + A)
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+    want_bp, want_ts = orc.helfand(v, x, m, vol, 300.0)
+    ctx.set_option("helfand_fft", 1)
+    try:
+        ts, bp = run_helfand(ctx, v, x, m, scale, False)
+    finally:
+        ctx.set_option("helfand_fft", 0)
+    assert bp is None and ts.shape == want_ts.shape
+    assert ts[0] == 0.0
+    assert scale_rel_err(ts, want_ts) < TOL
+
+
+def test_helfand_fft_option_step_kat_and_class(ctx):
+    """The reference's step trajectory (test_viscosity.py:115-132 / :180-208, N = 5001, m = 16,
+    V = 8, T = 300): a smooth P, where short lags are far below P^2 -- the FFT option stays inside
+    1e-10 of the series' scale (not of each value: see include/ta_hip.h).  The class takes
+    fft=True with by_particle=False only."""
+    from transport_analysis_amd import ViscosityHelfand
+    from transport_analysis_amd._base import BOLTZMANN
+    from transport_analysis_amd._mini_mda import ArrayUniverse
+
+    want = g("kat_helfand_poly_N5001_D3.npy")
+    v, x = step(5001)
+    ctx.set_option("helfand_fft", 1)
+    try:
+        ts, _ = run_helfand(ctx, v, x, np.array([16.0]), 1.0 / (2 * BOLTZMANN * 8.0 * 300.0), False)
+    finally:
+        ctx.set_option("helfand_fft", 0)
+    assert ts[0] == 0.0
+    assert scale_rel_err(ts, want) < TOL
+    u = ArrayUniverse(positions=x[:300].astype(np.float32), velocities=v[:300].astype(np.float32),
+                      masses=np.full(1, 16.0), dimensions=[2, 2, 2, 90, 90, 90])
+    ref = ViscosityHelfand(u.atoms, by_particle=False).run()
+    got = ViscosityHelfand(u.atoms, fft=True, by_particle=False).run()
+    assert got.results.visc_by_particle is None
+    assert scale_rel_err(got.results.timeseries, ref.results.timeseries) < TOL
+    with pytest.raises(ValueError):
+        ViscosityHelfand(u.atoms, fft=True)
+
+
 @pytest.mark.parametrize("T", [20000, 28000])
 def test_float32_helfand_long_trajectory(ctx, T):
     """20000 frames (configs[4]) fits LDS as float32; 28000 takes the L2-staged variant."""

@@ -42,7 +42,7 @@ struct ta_ctx {
     std::string err;
     std::map<int, Tables> tables;
     std::map<long, LongTables> long_tables;  // keyed by M'
-    DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, f32_stage, stage_buf, long_scratch;
+    DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, f32_stage, stage_buf, long_scratch, helf_p, helf_small;
     // staging
     int64_t st_T = 0, st_A = 0;
     int st_D = 0, st_dtype = TA_F64, st_nslabs = 0;
@@ -58,6 +58,7 @@ struct ta_ctx {
     int64_t opt_direct_f32 = 0;
     int64_t opt_direct_groups = 0;
     int64_t opt_direct_chunk = 0;
+    int64_t opt_helfand_fft = 0;
 };
 
 namespace {
@@ -331,7 +332,8 @@ int ta_ctx_destroy(ta_ctx* ctx) {
         hipFree(kv.second.perm);
     }
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
-                      &ctx->masses, &ctx->f32_stage, &ctx->stage_buf, &ctx->long_scratch})
+                      &ctx->masses, &ctx->f32_stage, &ctx->stage_buf, &ctx->long_scratch, &ctx->helf_p,
+                      &ctx->helf_small})
         if (b->p) hipFree(b->p);
     for (auto& ev : ctx->ev)
         if (ev) hipEventDestroy(ev);
@@ -348,6 +350,7 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "direct_f32")) ctx->opt_direct_f32 = value;
     else if (!strcmp(key, "direct_groups")) ctx->opt_direct_groups = value;
     else if (!strcmp(key, "direct_chunk")) ctx->opt_direct_chunk = value;
+    else if (!strcmp(key, "helfand_fft")) ctx->opt_helfand_fft = value;
     else return fail(ctx, TA_E_INVALID, std::string("unknown option ") + key);
     return TA_OK;
 }
@@ -566,6 +569,22 @@ int ta_helfand_msd_dev(ta_ctx* ctx, const double* d_vel, const double* d_pos, co
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as for any HIP call
     ctx->timing_valid = false;
+    if (ctx->opt_helfand_fft && !d_bp && T >= 2) {
+        // option "helfand_fft" (lag sums only): S1 from prefix sums, S2 = FFT lag sums of the
+        // product slab P = (m v) x (helfand_fft.hip)
+        const size_t n = (size_t)T * A * D;
+        if ((rc = ensure(ctx, ctx->helf_p, sizeof(double) * n))) return rc;
+        if ((rc = ensure(ctx, ctx->helf_small, sizeof(double) * (3 * (size_t)T + 1)))) return rc;
+        double* P = (double*)ctx->helf_p.p;
+        double* Q = (double*)ctx->helf_small.p;
+        double* S2 = Q + T;
+        double* C = S2 + T;
+        TA_HIP_TRY(ctx, launch_helfand_product(d_vel, d_pos, d_masses, ld_row, T, A * D, D, P, Q, st));
+        if ((rc = ta_vacf_fft_dev(ctx, P, T, A, D, A * D, S2, nullptr, 0, stream))) return rc;
+        TA_HIP_TRY(ctx, launch_helfand_combine(Q, S2, C, (int)T, scale / (double)D, d_lagsum, st));
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+        return TA_OK;  // timing: ev[0..2] set by the FFT call, ev[3] after the combine
+    }
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     rc = direct_impl(ctx, MODE_HELFAND, d_vel, d_pos, d_masses, T, A, D, ld_row, scale, d_lagsum,
                      d_bp, ld_bp, st);

@@ -1,0 +1,107 @@
+// helfand_fft.hip — optional O(T log T) evaluation of the Einstein-Helfand lag sums
+// (option "helfand_fft", timeseries path; SURVEY.md section 8(f) row f4: the reference has
+// no such path, /root/reference/transport_analysis/viscosity.py:201-233 always runs the
+// O(T^2) double loop, which k_direct<MODE_HELFAND> restates and which stays the default).
+//
+// With P[i] = (m v[i]) x[i] per column (the reference's evaluation order),
+//   sum_{i<T-k} (P[i] - P[i+k])^2 = S1(k) - 2 S2(k),
+//   S2(k) = sum_i P[i] P[i+k]                       -> the FFT VACF lag sums of the P slab
+//   S1(k) = sum_{i<T-k} P[i]^2 + sum_{i>=k} P[i]^2  -> prefix sums of Q[i] = sum_cols P[i]^2
+// so the sum over atoms of the windowed mean squared difference is
+//   (C[T-k] + C[T] - C[k]) / (T-k) - 2 * lagsum_fft[k],   C = exclusive prefix sums of Q.
+// Accuracy: the two terms are each ~2 sum P^2 / (T-k) and their difference is formed in
+// float64: absolute error ~1e-16 * sum P^2 / (T-k), i.e. ~1e-15 of the series' scale, but the
+// RELATIVE error of a lag whose mean squared difference is far below P^2 (short lags of a
+// smooth P) grows by that ratio -- which is why this is an option and not the default.
+#include <hip/hip_runtime.h>
+
+#include "ta_internal.hpp"
+
+namespace ta {
+namespace {
+
+// One workgroup per frame: P[t, col] = (m * v) * x, Q[t] = sum_col P^2 (fixed-order tree sum).
+__global__ void __launch_bounds__(256)
+    k_helfand_product(const double* __restrict__ vel, const double* __restrict__ pos,
+                      const double* __restrict__ masses, long ld_row, long n_cols, int D,
+                      double* __restrict__ P, double* __restrict__ Q) {
+    __shared__ double red[256];
+    const long t = blockIdx.x;
+    const int tid = threadIdx.x;
+    const double* v = vel + t * ld_row;
+    const double* x = pos + t * ld_row;
+    double* p = P + t * n_cols;
+    double s = 0.0;
+    for (long c = tid; c < n_cols; c += 256) {
+        const double val = (masses[c / D] * v[c]) * x[c];
+        p[c] = val;
+        s += val * val;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) red[tid] += red[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) Q[t] = red[0];
+}
+
+// Single workgroup: C = exclusive prefix sums of Q (C[0] = 0 ... C[T]), then
+// out[k] = factor * ((C[T-k] + C[T] - C[k]) / (T-k) - 2 s2n[k]), out[0] = 0 exactly
+// (viscosity.py:205-233 leaves row 0 at 0).
+__global__ void __launch_bounds__(256)
+    k_helfand_combine(const double* __restrict__ Q, const double* __restrict__ s2n, double* __restrict__ C,
+                      int T, double factor, double* __restrict__ out) {
+    __shared__ double part[256];
+    const int tid = threadIdx.x;
+    const int chunk = (T + 255) / 256;
+    const int lo = tid * chunk < T ? tid * chunk : T, hi = lo + chunk < T ? lo + chunk : T;
+    double s = 0.0;
+    for (int i = lo; i < hi; ++i) s += Q[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double run = 0.0;
+        for (int i = 0; i < 256; ++i) {
+            const double v = part[i];
+            part[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    double run = part[tid];
+    for (int i = lo; i < hi; ++i) {
+        C[i] = run;
+        run += Q[i];
+    }
+    if (lo < T && hi == T) C[T] = run;  // the thread that owns the last non-empty range
+    __threadfence_block();
+    __syncthreads();
+    const double total = C[T];
+    for (int k = tid; k < T; k += 256) {
+        if (k == 0) {
+            out[0] = 0.0;
+        } else {
+            const double s1 = C[T - k] + (total - C[k]);
+            out[k] = factor * (s1 / (double)(T - k) - 2.0 * s2n[k]);
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_helfand_product(const double* vel, const double* pos, const double* masses,
+                                  long ld_row, long T, long n_cols, int D, double* P, double* Q,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL(k_helfand_product, dim3((unsigned)T), dim3(256), 0, st, vel, pos, masses, ld_row,
+                       n_cols, D, P, Q);
+    return hipGetLastError();
+}
+
+hipError_t launch_helfand_combine(const double* Q, const double* s2n, double* C, int T, double factor,
+                                  double* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_helfand_combine, dim3(1), dim3(256), 0, st, Q, s2n, C, T, factor, out);
+    return hipGetLastError();
+}
+
+}  // namespace ta

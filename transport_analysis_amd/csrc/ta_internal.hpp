@@ -69,6 +69,13 @@ hipError_t launch_fft_long_accum(int M, int nwg, hipStream_t st, const double* v
 hipError_t launch_fft_long_finish(int M, int Rout, const double* partial, int n_parts, const int* perm,
                                   const cd* twL, int T, double* spec, double* lagsum, hipStream_t st);
 
+// helfand_fft.hip: optional FFT evaluation of the Helfand lag sums
+hipError_t launch_helfand_product(const double* vel, const double* pos, const double* masses,
+                                  long ld_row, long T, long n_cols, int D, double* P, double* Q,
+                                  hipStream_t st);
+hipError_t launch_helfand_combine(const double* Q, const double* s2n, double* C, int T, double factor,
+                                  double* out, hipStream_t st);
+
 hipError_t launch_widen_f32(const float* in, double* out, long n, hipStream_t st);
 
 }  // namespace ta
