@@ -140,8 +140,8 @@ def main():
             raise SystemExit("--float32 applies to --mode direct / helfand")
         ctx.set_option("direct_f32", 1)
     if args.helfand_fft:
-        if args.mode != "helfand" or args.by_particle or args.float32:
-            raise SystemExit("--helfand-fft applies to --mode helfand without --by-particle/--float32")
+        if args.mode != "helfand" or args.float32:
+            raise SystemExit("--helfand-fft applies to --mode helfand without --float32")
         ctx.set_option("helfand_fft", 1)
     gen = torch.Generator(device=dev)
     gen.manual_seed(20250824 + 3 + 1000 * rank)

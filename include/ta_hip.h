@@ -134,8 +134,8 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *                      products / squared differences and 32-term block sums in float32
  *                      and add them into float64 accumulators (BASELINE configs[4]'s
  *                      float32 path; ~1e-6 relative accuracy).  Default 0 = float64.
- *   "helfand_fft" 0|1: ta_helfand_msd* without a by-particle array evaluate the lag sums
- *                      in O(T log T): sum (P[i]-P[i+k])^2 = S1(k) - 2 S2(k), S2 by the FFT
+ *   "helfand_fft" 0|1: ta_helfand_msd* evaluate the mean squared differences in O(T log T)
+ *                      (with a by-particle array: for n_frames <= 10240, else as default): sum (P[i]-P[i+k])^2 = S1(k) - 2 S2(k), S2 by the FFT
  *                      lag sums of the product slab P = (m v) x, S1 by prefix sums.  An
  *                      extension (the reference has only the O(T^2) loop,
  *                      viscosity.py:201-233, which stays the default): ~1e-15 of the series'

@@ -217,15 +217,16 @@ def test_helfand_float32_switch(backend, step_vtraj):
 
 def test_helfand_fft_switch(backend, step_vtraj):
     """fft=True (an extension: the reference has only the O(T^2) loop) selects the library's
-    S1 - 2 S2 evaluation of the lag sums; it needs by_particle=False and excludes float32."""
+    S1 - 2 S2 evaluation of the mean squared differences; it excludes float32."""
     vh = VH(step_vtraj.atoms, dim_type="xy", fft=True, by_particle=False).run(start=10, stop=1000, step=10)
     want = g("kat_helfand_poly_10_1000_10_D2.npy")
     assert np.max(np.abs(vh.results.timeseries - want)) < 1e-10 * np.max(np.abs(want))
     assert vh.results.timeseries[0] == 0.0 and vh.results.visc_by_particle is None
     if backend == "oracle-backed":
         assert vh._ctx.options["helfand_fft"] == 1
-    with pytest.raises(ValueError):
-        VH(step_vtraj.atoms, fft=True)
+    vh = VH(step_vtraj.atoms, dim_type="xy", fft=True).run(start=10, stop=1000, step=10)
+    assert vh.results.visc_by_particle.shape == (99, 1)
+    assert np.max(np.abs(vh.results.visc_by_particle[:, 0] - want)) < 1e-10 * np.max(np.abs(want))
     with pytest.raises(ValueError):
         VH(step_vtraj.atoms, fft=True, by_particle=False, float32=True)
     vh = VH(step_vtraj.atoms, dim_type="xy", by_particle=False).run(start=10, stop=1000, step=10)

@@ -546,13 +546,21 @@ def test_helfand_fft_option_vs_oracle(ctx, T, A, D):
     assert bp is None and ts.shape == want_ts.shape
     assert ts[0] == 0.0
     assert scale_rel_err(ts, want_ts) < TOL
+    ctx.set_option("helfand_fft", 1)
+    try:
+        ts, bp = run_helfand(ctx, v, x, m, scale, True)  # per atom (direct fallback past 10240)
+    finally:
+        ctx.set_option("helfand_fft", 0)
+    assert np.all(bp[0] == 0.0)
+    assert scale_rel_err(bp, want_bp) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL
 
 
 def test_helfand_fft_option_step_kat_and_class(ctx):
     """The reference's step trajectory (test_viscosity.py:115-132 / :180-208, N = 5001, m = 16,
     V = 8, T = 300): a smooth P, where short lags are far below P^2 -- the FFT option stays inside
     1e-10 of the series' scale (not of each value: see include/ta_hip.h).  The class takes
-    fft=True with by_particle=False only."""
+    fft=True with and without the per-particle array."""
     from transport_analysis_amd import ViscosityHelfand
     from transport_analysis_amd._base import BOLTZMANN
     from transport_analysis_amd._mini_mda import ArrayUniverse
@@ -572,8 +580,8 @@ def test_helfand_fft_option_step_kat_and_class(ctx):
     got = ViscosityHelfand(u.atoms, fft=True, by_particle=False).run()
     assert got.results.visc_by_particle is None
     assert scale_rel_err(got.results.timeseries, ref.results.timeseries) < TOL
-    with pytest.raises(ValueError):
-        ViscosityHelfand(u.atoms, fft=True)
+    got = ViscosityHelfand(u.atoms, fft=True).run()
+    assert scale_rel_err(got.results.visc_by_particle[:, 0], ref.results.timeseries) < TOL
 
 
 @pytest.mark.parametrize("T", [20000, 28000])

@@ -585,6 +585,21 @@ int ta_helfand_msd_dev(ta_ctx* ctx, const double* d_vel, const double* d_pos, co
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
         return TA_OK;  // timing: ev[0..2] set by the FFT call, ev[3] after the combine
     }
+    if (ctx->opt_helfand_fft && d_bp && T >= 2 && find_plan(T)) {
+        // the same per atom (on-chip FFT lengths only; longer trajectories take the direct
+        // correlator below): bp <- FFT by-particle autocorrelation of P, then S1 - 2 S2 in place
+        const size_t n = (size_t)T * A * D;
+        if ((rc = ensure(ctx, ctx->helf_p, sizeof(double) * n))) return rc;
+        if ((rc = ensure(ctx, ctx->helf_small, sizeof(double) * ((size_t)T + 1) * A))) return rc;
+        double* P = (double*)ctx->helf_p.p;
+        double* Ca = (double*)ctx->helf_small.p;
+        TA_HIP_TRY(ctx, launch_helfand_product_bp(d_vel, d_pos, d_masses, ld_row, T, A, D, P, Ca, st));
+        if ((rc = ta_vacf_fft_dev(ctx, P, T, A, D, A * D, d_lagsum, d_bp, ld_bp, stream))) return rc;
+        TA_HIP_TRY(ctx, launch_helfand_combine_bp(Ca, A, (int)T, scale / (double)D, d_bp, ld_bp, st));
+        TA_HIP_TRY(ctx, launch_row_sums(d_bp, T, A, ld_bp, d_lagsum, st));
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+        return TA_OK;
+    }
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     rc = direct_impl(ctx, MODE_HELFAND, d_vel, d_pos, d_masses, T, A, D, ld_row, scale, d_lagsum,
                      d_bp, ld_bp, st);

@@ -88,7 +88,66 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// By-particle variant.  k_helfand_product_bp: P slab and Qa[t, n] = sum_d P[t, n, d]^2 (into the
+// (T+1, n_atoms) prefix array's rows 1..T).  k_helfand_combine_bp: one thread per atom
+// (coalesced over atoms): in-place prefix sums over time, then
+// bp[k, n] = factor * ((C[T-k] + C[T] - C[k]) / (T-k) - 2 bp[k, n]) with bp holding the FFT
+// by-particle autocorrelation of P on entry; row 0 is set to exactly 0.
+__global__ void __launch_bounds__(256)
+    k_helfand_product_bp(const double* __restrict__ vel, const double* __restrict__ pos,
+                         const double* __restrict__ masses, long ld_row, long n_atoms, int D,
+                         double* __restrict__ P, double* __restrict__ Ca) {
+    const long t = blockIdx.y;
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_atoms) return;
+    const double* v = vel + t * ld_row + n * D;
+    const double* x = pos + t * ld_row + n * D;
+    double* p = P + (t * n_atoms + n) * D;
+    const double m = masses[n];
+    double s = 0.0;
+    for (int d = 0; d < D; ++d) {
+        const double val = (m * v[d]) * x[d];
+        p[d] = val;
+        s += val * val;
+    }
+    Ca[(t + 1) * n_atoms + n] = s;
+}
+
+__global__ void __launch_bounds__(256)
+    k_helfand_combine_bp(double* __restrict__ Ca, long n_atoms, int T, double factor,
+                         double* __restrict__ bp, long ld_bp) {
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_atoms) return;
+    double run = 0.0;
+    Ca[n] = 0.0;
+    for (int t = 1; t <= T; ++t) {
+        run += Ca[(long)t * n_atoms + n];
+        Ca[(long)t * n_atoms + n] = run;
+    }
+    const double total = run;
+    bp[n] = 0.0;
+    for (int k = 1; k < T; ++k) {
+        const double s1 = Ca[(long)(T - k) * n_atoms + n] + (total - Ca[(long)k * n_atoms + n]);
+        bp[(long)k * ld_bp + n] = factor * (s1 / (double)(T - k) - 2.0 * bp[(long)k * ld_bp + n]);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_helfand_product_bp(const double* vel, const double* pos, const double* masses,
+                                     long ld_row, long T, long n_atoms, int D, double* P, double* Ca,
+                                     hipStream_t st) {
+    hipLaunchKernelGGL(k_helfand_product_bp, dim3((unsigned)((n_atoms + 255) / 256), (unsigned)T), dim3(256),
+                       0, st, vel, pos, masses, ld_row, n_atoms, D, P, Ca);
+    return hipGetLastError();
+}
+
+hipError_t launch_helfand_combine_bp(double* Ca, long n_atoms, int T, double factor, double* bp,
+                                     long ld_bp, hipStream_t st) {
+    hipLaunchKernelGGL(k_helfand_combine_bp, dim3((unsigned)((n_atoms + 255) / 256)), dim3(256), 0, st, Ca,
+                       n_atoms, T, factor, bp, ld_bp);
+    return hipGetLastError();
+}
 
 hipError_t launch_helfand_product(const double* vel, const double* pos, const double* masses,
                                   long ld_row, long T, long n_cols, int D, double* P, double* Q,

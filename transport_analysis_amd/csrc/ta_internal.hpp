@@ -75,6 +75,11 @@ hipError_t launch_helfand_product(const double* vel, const double* pos, const do
                                   hipStream_t st);
 hipError_t launch_helfand_combine(const double* Q, const double* s2n, double* C, int T, double factor,
                                   double* out, hipStream_t st);
+hipError_t launch_helfand_product_bp(const double* vel, const double* pos, const double* masses,
+                                     long ld_row, long T, long n_atoms, int D, double* P, double* Ca,
+                                     hipStream_t st);  // Ca: (T+1, n_atoms)
+hipError_t launch_helfand_combine_bp(double* Ca, long n_atoms, int T, double factor, double* bp,
+                                     long ld_bp, hipStream_t st);
 
 hipError_t launch_widen_f32(const float* in, double* out, long n, hipStream_t st);
 

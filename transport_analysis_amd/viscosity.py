@@ -38,9 +38,10 @@ class ViscosityHelfand(AnalysisBase):
         instead of 1e-10, about twice the throughput.
 
     fft : bool, keyword-only, default False — an extension (the reference has only the
-        O(n_frames^2) loop): with ``by_particle=False`` evaluate the lag sums in
+        O(n_frames^2) loop): evaluate the mean squared differences in
         O(n_frames log n_frames) as ``S1(k) - 2 S2(k)`` (``S2`` = FFT autocorrelation of the
-        products ``m v x``, ``S1`` from prefix sums).  Accurate to ~1e-15 of the series' scale;
+        products ``m v x``, ``S1`` from prefix sums).  With the per-particle array this covers
+        n_frames <= 10240 (longer trajectories fall back to the direct correlator).  Accurate to ~1e-15 of the series' scale;
         lags whose mean squared difference is far below the squared products themselves lose
         relative accuracy by that ratio.
 
@@ -59,8 +60,6 @@ class ViscosityHelfand(AnalysisBase):
         self._distributed = bool(kwargs.pop("distributed", False))
         self._float32 = bool(kwargs.pop("float32", False))
         self._fft = bool(kwargs.pop("fft", False))
-        if self._fft and self._want_by_particle:
-            raise ValueError("fft=True evaluates the lag sums only: pass by_particle=False")
         if self._fft and self._float32:
             raise ValueError("fft=True and float32=True are exclusive")
         super().__init__(atomgroup.universe.trajectory, **kwargs)
