@@ -89,8 +89,8 @@ __global__ void __launch_bounds__(256)
 }
 
 // By-particle variant.  k_helfand_product_bp: P slab and Qa[t, n] = sum_d P[t, n, d]^2 (into the
-// (T+1, n_atoms) prefix array's rows 1..T).  k_helfand_combine_bp: one thread per atom
-// (coalesced over atoms): in-place prefix sums over time, then
+// (T+1, n_atoms) prefix array's rows 1..T).  k_helfand_combine_bp: in-place prefix sums over
+// time per atom (coalesced over atoms), then
 // bp[k, n] = factor * ((C[T-k] + C[T] - C[k]) / (T-k) - 2 bp[k, n]) with bp holding the FFT
 // by-particle autocorrelation of P on entry; row 0 is set to exactly 0.
 __global__ void __launch_bounds__(256)
@@ -113,22 +113,48 @@ __global__ void __launch_bounds__(256)
     Ca[(t + 1) * n_atoms + n] = s;
 }
 
+// 64 atoms x 4 time quarters per workgroup: every thread scans its quarter of its atom's
+// column (local prefix sums in place), the quarters' totals meet in LDS, and the combine
+// pass adds the quarter offsets on the fly.  Lanes of a wave are consecutive atoms: 512-byte
+// contiguous accesses.
 __global__ void __launch_bounds__(256)
     k_helfand_combine_bp(double* __restrict__ Ca, long n_atoms, int T, double factor,
                          double* __restrict__ bp, long ld_bp) {
-    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_atoms) return;
+    __shared__ double tot[4][64];
+    const int a = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const long n = (long)blockIdx.x * 64 + a;
+    const bool live = n < n_atoms;
+    const int Tc = (T + 3) / 4;  // rows 1..T of Ca in four quarters of Tc rows
+    const int lo = 1 + c * Tc, hi = (lo + Tc - 1 < T) ? lo + Tc - 1 : T;
     double run = 0.0;
-    Ca[n] = 0.0;
-    for (int t = 1; t <= T; ++t) {
-        run += Ca[(long)t * n_atoms + n];
-        Ca[(long)t * n_atoms + n] = run;
+    if (live) {
+        if (c == 0) Ca[n] = 0.0;
+        for (int t = lo; t <= hi; ++t) {
+            run += Ca[(long)t * n_atoms + n];
+            Ca[(long)t * n_atoms + n] = run;
+        }
     }
-    const double total = run;
-    bp[n] = 0.0;
-    for (int k = 1; k < T; ++k) {
-        const double s1 = Ca[(long)(T - k) * n_atoms + n] + (total - Ca[(long)k * n_atoms + n]);
-        bp[(long)k * ld_bp + n] = factor * (s1 / (double)(T - k) - 2.0 * bp[(long)k * ld_bp + n]);
+    tot[c][a] = run;
+    __threadfence_block();
+    __syncthreads();
+    if (!live) return;
+    const double o1 = tot[0][a], o2 = o1 + tot[1][a], o3 = o2 + tot[2][a], total = o3 + tot[3][a];
+    auto C = [&](int t) -> double {  // exclusive prefix sum C[t], t in [0, T]
+        if (t == 0) return 0.0;
+        const int q = (t - 1) / Tc;
+        const double off = q == 0 ? 0.0 : q == 1 ? o1 : q == 2 ? o2 : o3;
+        return Ca[(long)t * n_atoms + n] + off;
+    };
+    // lags split over the four threads of the atom
+    const int Kc = (T + 3) / 4;
+    const int k0 = c * Kc, k1 = (k0 + Kc < T) ? k0 + Kc : T;
+    for (int k = k0; k < k1; ++k) {
+        if (k == 0) {
+            bp[n] = 0.0;
+        } else {
+            const double s1 = C(T - k) + (total - C(k));
+            bp[(long)k * ld_bp + n] = factor * (s1 / (double)(T - k) - 2.0 * bp[(long)k * ld_bp + n]);
+        }
     }
 }
 
@@ -144,7 +170,7 @@ hipError_t launch_helfand_product_bp(const double* vel, const double* pos, const
 
 hipError_t launch_helfand_combine_bp(double* Ca, long n_atoms, int T, double factor, double* bp,
                                      long ld_bp, hipStream_t st) {
-    hipLaunchKernelGGL(k_helfand_combine_bp, dim3((unsigned)((n_atoms + 255) / 256)), dim3(256), 0, st, Ca,
+    hipLaunchKernelGGL(k_helfand_combine_bp, dim3((unsigned)((n_atoms + 63) / 64)), dim3(256), 0, st, Ca,
                        n_atoms, T, factor, bp, ld_bp);
     return hipGetLastError();
 }
