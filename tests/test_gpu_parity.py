@@ -296,13 +296,14 @@ def test_vacf_long_trajectory(ctx, fft):
     assert scale_rel_err(ts, want_ts) < TOL
 
 
-@pytest.mark.parametrize("T,A,D", [(10241, 3, 3), (12000, 5, 3), (16385, 2, 2), (20000, 4, 3),
+@pytest.mark.parametrize("T,A,D", [(10241, 3, 3), (12000, 5, 3), (12000, 7, 3), (20000, 11, 2), (16385, 2, 2), (20000, 4, 3),
                                    (20481, 3, 1), (33000, 2, 3), (50000, 1, 3), (70000, 1, 2),
                                    (90000, 1, 1), (140000, 1, 2), (163840, 1, 1)])
 def test_vacf_fft_long_trajectory_timeseries(ctx, T, A, D):
     """fft=True, lag sums only, n_frames beyond the largest on-chip transform: outer radix
     2/4/8/16 step on the fly + on-chip 8192/10240-point transforms (csrc/fft_long.hip); covers
-    both on-chip plans, an odd column count (unpaired last column) and rows past the end."""
+    both on-chip plans, an odd column count (unpaired last column), rows past the end, and work
+    units of four adjacent pairs gathered 64 bytes per row (full units plus a ragged last one)."""
     from oracle import numpy_oracle as orc
 
     v = orc.synthetic_velocities(T, A, D, seed=T % 1000 + A)
@@ -528,7 +529,7 @@ def test_float32_direct_paths_vs_oracle(ctx, T, A, D):
 
 
 @pytest.mark.parametrize("T,A,D", [(2, 3, 1), (9, 1, 1), (50, 6, 2), (300, 21, 3), (1001, 7, 3),
-                                   (5000, 5, 3), (10240, 2, 2), (12000, 3, 3), (25000, 2, 3)])
+                                   (5000, 5, 3), (10240, 2, 2), (12000, 3, 3), (16500, 2, 3)])
 def test_helfand_fft_option_vs_oracle(ctx, T, A, D):
     """Option "helfand_fft" (extension, csrc/helfand_fft.hip): lag sums as S1 - 2 S2 with S2 from
     the FFT path (on-chip and long-trajectory plans) -- same series as the reference's O(T^2)

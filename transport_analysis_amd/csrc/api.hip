@@ -107,8 +107,8 @@ int get_tables(ta_ctx* ctx, int M, int R0, Tables* out) {
     // [0,2M): W_2M^n.  [2M,3M) and [3M,4M): the first-stage twiddles of pass A and pass B,
     // W_2M^{u(2q+B)} stored [q][u] (u < M/R0) so that a wave's 64 consecutive butterflies read
     // 1 KB contiguous (from the main table the same values sit 2q+B elements apart: one L2
-    // request per lane).  [4M,4M+2): zeros.
-    std::vector<cd> a(4 * (size_t)M + 2, cd{0.0, 0.0});  // + 32 zero bytes: the gather's padding rows
+    // request per lane).  [4M,4M+4): zeros.
+    std::vector<cd> a(4 * (size_t)M + 4, cd{0.0, 0.0});  // + 64 zero bytes: the gathers' padding rows
     const long double pi = 3.141592653589793238462643383279502884L;
     auto w2m = [&](long n) {
         n %= 2L * M;
@@ -125,8 +125,8 @@ int get_tables(ta_ctx* ctx, int M, int R0, Tables* out) {
         for (long q = 0; q < R0; ++q)
             for (long u = 0; u < L0; ++u) a[(2 + B) * (size_t)M + q * L0 + u] = w2m(u * (2 * q + B));
     Tables t;
-    TA_HIP_TRY(ctx, hipMalloc((void**)&t.tw2, sizeof(cd) * (4 * (size_t)M + 2)));
-    TA_HIP_TRY(ctx, hipMemcpy(t.tw2, a.data(), sizeof(cd) * (4 * (size_t)M + 2), hipMemcpyHostToDevice));
+    TA_HIP_TRY(ctx, hipMalloc((void**)&t.tw2, sizeof(cd) * (4 * (size_t)M + 4)));
+    TA_HIP_TRY(ctx, hipMemcpy(t.tw2, a.data(), sizeof(cd) * (4 * (size_t)M + 4), hipMemcpyHostToDevice));
     ctx->tables[M] = t;
     *out = t;
     return TA_OK;
@@ -180,15 +180,15 @@ int fft_long_impl(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int D,
     LongTables lt;
     if ((rc = get_tables(ctx, M, plan->R_first, &tb))) return rc;
     if ((rc = get_long_tables(ctx, M, Rout, &lt))) return rc;
-    const int64_t n_pairs = (A * D + 1) / 2;
+    const int64_t n_quads = ((A * D + 1) / 2 + 3) / 4;  // a workgroup takes four adjacent pairs
     int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu;
-    nwg = std::max<int64_t>(1, std::min(nwg, n_pairs));
+    nwg = std::max<int64_t>(1, std::min(nwg, n_quads));
     if (nwg >= 8) nwg -= nwg % 8;  // XCD-aware walk
     const size_t blk = fft_long_acc_block(M);
     const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * Rout * blk;
     if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->spec, sizeof(double) * 2 * (size_t)Rout * M))) return rc;
-    if ((rc = ensure(ctx, ctx->long_scratch, sizeof(cd) * (size_t)nwg * 2 * Rout * M))) return rc;
+    if ((rc = ensure(ctx, ctx->long_scratch, sizeof(cd) * (size_t)nwg * 4 * 2 * Rout * M))) return rc;
     TA_HIP_TRY(ctx, hipMemsetAsync(ctx->partial.p, 0, acc_bytes, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     TA_HIP_TRY(ctx, launch_fft_long_accum(M, (int)nwg, st, d_vel, ld_row, (int)T, A * D, Rout, tb.tw2,

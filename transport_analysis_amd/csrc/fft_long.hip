@@ -38,9 +38,63 @@ __device__ __forceinline__ cd cfma(cd acc, cd a, cd b) {  // acc + a*b
     return {acc.x + (a.x * b.x - a.y * b.y), acc.y + (a.x * b.y + a.y * b.x)};
 }
 
+// Phase 0 for FOUR adjacent column pairs at once (8 complete columns, 16-byte aligned rows):
+// a lane's four 16-byte loads of a row fall into the same 64 bytes, so the texture addresser
+// sees one scattered line per row and three hits on it instead of four scattered requests --
+// the "wide gather" of DESIGN.md section 6, possible here because the data goes to scratch
+// anyway and does not have to be parked in registers.
+template <class P, int ROUT>
+__device__ __forceinline__ void long_phase0_quad(const double* __restrict__ col, long ld_row, int T,
+                                                 const double* __restrict__ zeros,
+                                                 const cd* __restrict__ twL, cd* __restrict__ scr, int tid) {
+    using S0 = StageInfo<P, 0>;
+    static_assert(S0::TASKS % P::NT == 0, "every thread owns K first-stage butterflies");
+    static_assert(ROUT <= 4, "register budget: G*ROUT*4 loads of 16 bytes in flight");
+    constexpr int NE = S0::K * S0::R;
+    constexpr int G = 4 / ROUT;
+    constexpr int L2 = 2 * ROUT * P::M;
+    constexpr long QS = 2L * ROUT * P::M;  // scratch elements per pair
+    asm volatile("" : "+v"(tid));
+#pragma unroll 1
+    for (int e0 = 0; e0 < NE; e0 += G) {
+        cd z[G][ROUT][4];
+        int t1s[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int e = e0 + g < NE ? e0 + g : NE - 1;
+            const int m = e / S0::R, j0 = e - m * S0::R;
+            const int t1 = tid + m * P::NT + j0 * S0::L;
+            t1s[g] = t1;
+#pragma unroll
+            for (int j = 0; j < ROUT; ++j) {
+                const int t = t1 + P::M * j;
+                const double* p = t < T ? col + (long)t * ld_row : zeros;  // 64 zero bytes there
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double2 v = *reinterpret_cast<const double2*>(p + 2 * q);
+                    z[g][j][q] = cd{v.x, v.y};
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll 1
+            for (int c = 0; c < 2 * ROUT; ++c) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    cd a = z[g][0][q];
+#pragma unroll
+                    for (int j = 1; j < ROUT; ++j) a = cfma(a, z[g][j][q], twL[(c * j * P::M) % L2]);
+                    scr[q * QS + (long)c * P::M + t1s[g]] = a;
+                }
+            }
+        }
+    }
+}
+
 // accg: [gridDim.x][2*Rout][ACC_BLK] float64, zeroed by the caller; block layout as in
 // k_fft_accum ([quad][thread] x 2 doubles).  twL: W_{2M'}^n = exp(-i pi n / M'), n < 2M'.
-// scratch: [gridDim.x][2*Rout][M] complex: the column is gathered ONCE per pair (phase 0: R
+// scratch: [gridDim.x][4][2*Rout][M] complex (a work unit is four adjacent pairs): the column is gathered ONCE per pair (phase 0: R
 // strided rows per element, all in flight together) and the 2R partial sums
 // a_c[t] = sum_j z[t + M j] W_{2R}^{c j} go to the workgroup's scratch (lane = row: contiguous
 // 1 KB stores), from which pass c reads its series back contiguously -- a thread reads exactly
@@ -113,8 +167,8 @@ __global__ void __launch_bounds__(P::NT)
     const int tid = threadIdx.x;
     const int L2 = 2 * Rout * P::M;  // table length 2M'
     double* blk0 = accg + (long)wg * 2 * Rout * ACC_BLK;
-    cd* scr = scratch + (long)wg * 2 * Rout * P::M;
-    const double* zeros = reinterpret_cast<const double*>(tw2 + 4 * P::M);  // 32 zero bytes
+    cd* scr = scratch + (long)wg * 4 * 2 * Rout * P::M;  // four pairs' worth
+    const double* zeros = reinterpret_cast<const double*>(tw2 + 4 * P::M);  // 64 zero bytes
 
     cd seed[4];
     seed[0] = cd{1.0, 0.0};
@@ -124,15 +178,28 @@ __global__ void __launch_bounds__(P::NT)
 
     const bool slab16 = ((reinterpret_cast<unsigned long long>(vel) | ((unsigned long long)ld_row * 8)) & 15) == 0;
     const long n_pairs = (n_cols + 1) / 2;
+    const long n_quads = (n_pairs + 3) / 4;  // work unit: four adjacent column pairs
+    const long QS = 2L * Rout * P::M;        // scratch elements per pair
     auto no_hook = [](int) {};
-    for (long pair = slot; pair < n_pairs; pair += nwg) {
+    for (long quad = slot; quad < n_quads; quad += nwg) {
+      const long pair0 = 4 * quad;
+      const int npq = (int)(n_pairs - pair0 < 4 ? n_pairs - pair0 : 4);
+      // ---- phase 0: gather once, partial sums of all 2R passes -> scratch
+      const bool quadwide = slab16 && Rout <= 4 && 2 * (pair0 + 4) <= n_cols;
+      if (quadwide) {
+          if (Rout == 2) long_phase0_quad<P, 2>(vel + 2 * pair0, ld_row, T, zeros, twL, scr, tid);
+          else long_phase0_quad<P, 4>(vel + 2 * pair0, ld_row, T, zeros, twL, scr, tid);
+      }
+      for (int pq = 0; pq < npq; ++pq) {
+        const long pair = pair0 + pq;
+        cd* scr_p = scr + pq * QS;
+        if (quadwide) continue;
         const double* col = vel + 2 * pair;
         const bool two = 2 * pair + 1 < n_cols;  // an odd last column has no partner
         const bool wide = two && slab16;         // one 16-byte load per row
-        // ---- phase 0: gather once, partial sums of all 2R passes -> scratch
-#define TA_P0(R)                                                                      \
-    if (wide) long_phase0<P, R, true>(col, ld_row, T, two, zeros, twL, scr, tid);    \
-    else long_phase0<P, R, false>(col, ld_row, T, two, zeros, twL, scr, tid);
+#define TA_P0(R)                                                                        \
+    if (wide) long_phase0<P, R, true>(col, ld_row, T, two, zeros, twL, scr_p, tid);    \
+    else long_phase0<P, R, false>(col, ld_row, T, two, zeros, twL, scr_p, tid);
         switch (Rout) {
             case 2: TA_P0(2) break;
             case 4: TA_P0(4) break;
@@ -140,14 +207,17 @@ __global__ void __launch_bounds__(P::NT)
             default: TA_P0(16) break;
         }
 #undef TA_P0
-        __threadfence();
+      }
+      __threadfence();
+      for (int pq = 0; pq < npq; ++pq) {
+        const cd* scr_p = scr + pq * QS;
         for (int c = 0; c < 2 * Rout; ++c) {
             // ---- first stage of pass c: u_c[t] = W_{2M'}^{c t} a_c[t].  Per butterfly u the inputs
             // are scaled by the wave-uniform W_{2M'}^{c j0 L} (hoisted: tj), the outputs by
             // W_{2M'}^{c u} * W_M^{u q} = h g^q (one table entry each per butterfly, powers by
             // repeated multiplication); the next butterfly's operands are loaded while the
             // current one is computed.
-            const cd* __restrict__ ac = scr + (long)c * P::M;
+            const cd* __restrict__ ac = scr_p + (long)c * P::M;
             // per-butterfly offsets depend on tid only: formed here, per pass, or LICM hoists the
             // lot out of both loops and spills it
             int tl = tid;
@@ -196,6 +266,7 @@ __global__ void __launch_bounds__(P::NT)
             last_stage_acc_global<P>(lds, blk0 + (long)c * ACC_BLK, tid, no_hook);
             __syncthreads();
         }
+      }
     }
 }
 

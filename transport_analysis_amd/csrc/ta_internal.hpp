@@ -19,7 +19,7 @@ struct FftArgs {
     long n_cols;   // accum: columns of the shard (n_atoms * D)
     long n_atoms;  // by_particle
     int D;
-    const cd* tw2;        // [0,2M): W_{2M}^n; [2M,3M): first-stage table pass A; [3M,4M): pass B; [4M,4M+2): zeros
+    const cd* tw2;        // [0,2M): W_{2M}^n; [2M,3M): first-stage table pass A; [3M,4M): pass B; [4M,4M+4): zeros
     double* partial;      // accum: [nwg][2][quads*2*NT] float64, zeroed by the caller
     const double* spec;   // finalize: [n_slices][2][M]
     int n_slices;
@@ -65,7 +65,7 @@ void fft_long_perm(int M, std::vector<int>& perm);       // position -> frequenc
 size_t fft_long_acc_block(int M);                        // doubles per workgroup and pass
 hipError_t launch_fft_long_accum(int M, int nwg, hipStream_t st, const double* vel, long ld_row, int T,
                                  long n_cols, int Rout, const cd* tw2, const cd* twL, double* accg,
-                                 cd* scratch /* [nwg][2*Rout][M] */);
+                                 cd* scratch /* [nwg][4][2*Rout][M] */);
 hipError_t launch_fft_long_finish(int M, int Rout, const double* partial, int n_parts, const int* perm,
                                   const cd* twL, int T, double* spec, double* lagsum, hipStream_t st);
 
