@@ -11,8 +11,15 @@
  *   - every call returns int: 0 = TA_OK, negative = error (TA_E_*);
  *     ta_last_error() returns a human-readable message for the last failure
  *     on that context (or on the calling thread when ctx is NULL).
- *   - slabs are the reference's layout: (n_frames, n_atoms, dim) row-major,
- *     float64 (velocityautocorr.py:150-152, viscosity.py:128-134).
+ *   - HOST slabs (and the frame-major d_* inputs of the *_dev calls) are the reference's
+ *     layout: (n_frames, n_atoms, dim) row-major (velocityautocorr.py:150-152,
+ *     viscosity.py:128-134).  The library's own DEVICE slabs are "pair-major": the staging
+ *     calls transpose frames as they are committed, so that a column pair (columns 2p, 2p+1
+ *     of the n_atoms*dim columns) is one contiguous array of 16-byte rows (x[t], y[t]):
+ *         element (t, c) -> slab[((c / 2) * pitch + t) * 2 + (c & 1)],  pitch = n_frames
+ *     rounded up to 8; an odd last column is paired with zeros.  Every kernel reads that
+ *     layout (coalesced along time); frame-major *_dev inputs are transposed into a scratch
+ *     slab first (one more pass over the data and a second copy of it).
  *   - outputs are caller-owned.  "lagsum" outputs are lag-indexed SUMS over the
  *     atoms handled by this call, already divided by the frame-pair count
  *     (n_frames - lag): lagsum[k] = sum_n by_particle[k, n].  The caller divides
@@ -69,17 +76,41 @@ int ta_abi_version(void);
  * ViscosityHelfand._prepare/_single_frame (viscosity.py:111-142,167-199)
  *
  * ta_stage_alloc allocates n_slabs pinned host slabs of (n_frames, n_atoms,
- * dim) elements of `dtype` plus matching device slabs; h_slabs[i] receives the
- * host pointers, which the Python side wraps as NumPy arrays and fills frame
- * by frame.  ta_stage_commit copies frames [frame_lo, frame_hi) of every slab
- * host->device asynchronously (f32 slabs are widened to f64 on the device).
- * ta_stage_device returns the float64 device slab i (valid until the next
- * ta_stage_alloc / ta_ctx_destroy).                                        */
+ * dim) elements of `dtype` (TA_F32 is lossless for MDAnalysis data, which is
+ * float32 at the source, and halves the PCIe bytes) plus float64 pair-major
+ * device slabs; h_slabs[i] receives the host pointers, which the Python side
+ * wraps as NumPy arrays and fills frame by frame.  ta_stage_commit moves
+ * frames [frame_lo, frame_hi) of every slab host->device asynchronously in
+ * their native width (<= 64 MiB pieces) and transposes them into the device
+ * slabs there (the transposition of one piece runs while the next one crosses
+ * PCIe).  Frames never committed read as zeros (np.zeros in the reference).
+ * ta_stage_alloc_device: device slabs only, for data that is already on the
+ * GPU; fill them with ta_stage_commit_dev (frame-major float32/float64 rows
+ * [frame_lo, frame_hi) at d_src, row stride ld_row elements; asynchronous on
+ * `stream`) or ta_stage_synth.  ta_stage_read_dev writes a frame-major
+ * float64 copy of a slab (diagnostics / tests).  ta_stage_device returns the
+ * pair-major device slab i, its pitch (rows per pair) and its pair count
+ * (valid until the next ta_stage_alloc* / ta_stage_free / ta_ctx_destroy).
+ * The pinned host views die with ta_stage_free / the next ta_stage_alloc.   */
 int ta_stage_alloc(ta_ctx *ctx, int64_t n_frames, int64_t n_atoms, int dim, int dtype,
                    int n_slabs, void **h_slabs);
+int ta_stage_alloc_device(ta_ctx *ctx, int64_t n_frames, int64_t n_atoms, int dim, int n_slabs);
 int ta_stage_commit(ta_ctx *ctx, int64_t frame_lo, int64_t frame_hi);
-int ta_stage_device(ta_ctx *ctx, int slab, double **d_slab);
+int ta_stage_commit_dev(ta_ctx *ctx, int slab, const void *d_src, int dtype, int64_t ld_row,
+                        int64_t frame_lo, int64_t frame_hi, void *stream);
+int ta_stage_read_dev(ta_ctx *ctx, int slab, double *d_dst, int64_t ld_row, void *stream);
+int ta_stage_device(ta_ctx *ctx, int slab, double **d_slab, int64_t *pitch_rows, int64_t *n_pairs);
 int ta_stage_free(ta_ctx *ctx);
+/* Benchmark input (a stateless counter-based generator, so that the CPU baseline
+ * and every GPU shard materialise the same tensor without shipping it): element (t, c) of the
+ * slab = synth(seed, t * n_cols_total + col_offset + c), where synth(seed, i) is the sum of the
+ * eight 16-bit fields of splitmix64(seed + 2 i) and splitmix64(seed + 2 i + 1), minus 262140,
+ * times 1/sqrt(8 (65536^2 - 1) / 12): zero mean, unit variance, bit-identical in NumPy
+ * (oracle/synth.py).  Asynchronous on `stream`.                                            */
+int ta_stage_synth(ta_ctx *ctx, int slab, uint64_t seed, int64_t col_offset, int64_t n_cols_total,
+                   void *stream);
+/* release the context's cached workspaces (scratch slabs, partial-sum blocks, landing buffer) */
+int ta_trim(ta_ctx *ctx);
 
 /* ---- compute on staged slabs (host-facing, blocking) -------------------
  * ta_vacf_fft     : VelocityAutocorr._conclude_fft    (velocityautocorr.py:208-215,
@@ -97,12 +128,13 @@ int ta_helfand_msd(ta_ctx *ctx, const double *h_masses, double scale, double *h_
                    double *h_by_particle);
 
 /* ---- compute on caller-provided device memory (asynchronous) -----------
- * Same arithmetic as above on a device-resident shard: d_vel / d_pos are
+ * Same arithmetic as above on a device-resident FRAME-MAJOR shard: d_vel / d_pos are
  * (n_frames, n_atoms, dim) float64 with row stride ld_row elements between
  * frames (ld_row >= n_atoms*dim; == for a dense slab, larger when the shard is a
- * column block of a wider slab).  d_lagsum: (n_frames,) SUM over this shard's
- * atoms.  d_by_particle: (n_frames, ld_bp) or NULL.  Used by the multi-GPU
- * path (one shard per rank, then one RCCL reduce of d_lagsum) and by bench.py. */
+ * column block of a wider slab).  The shard is first transposed into a pair-major
+ * scratch slab owned by the context (see Conventions; ta_stage_alloc_device +
+ * ta_stage_commit_dev + ta_*_staged avoid the copy).  d_lagsum: (n_frames,) SUM over
+ * this shard's atoms.  d_by_particle: (n_frames, ld_bp) or NULL.                   */
 int ta_vacf_fft_dev(ta_ctx *ctx, const double *d_vel, int64_t n_frames, int64_t n_atoms,
                     int dim, int64_t ld_row, double *d_lagsum, double *d_by_particle,
                     int64_t ld_bp, void *stream);
@@ -114,6 +146,16 @@ int ta_helfand_msd_dev(ta_ctx *ctx, const double *d_vel, const double *d_pos,
                        int64_t ld_row, double scale, double *d_lagsum,
                        double *d_by_particle, int64_t ld_bp, void *stream);
 
+/* ---- compute on the staged (pair-major) slabs, device outputs, asynchronous on `stream` ----
+ * Same arithmetic and outputs as the *_dev calls, on the slabs of ta_stage_alloc*: no
+ * transposition, no second copy.  d_masses: (n_atoms,) float64 device array.              */
+int ta_vacf_fft_staged(ta_ctx *ctx, double *d_lagsum, double *d_by_particle, int64_t ld_bp,
+                       void *stream);
+int ta_vacf_direct_staged(ta_ctx *ctx, double *d_lagsum, double *d_by_particle, int64_t ld_bp,
+                          void *stream);
+int ta_helfand_msd_staged(ta_ctx *ctx, const double *d_masses, double scale, double *d_lagsum,
+                          double *d_by_particle, int64_t ld_bp, void *stream);
+
 /* ---- instrumentation ----------------------------------------------------
  * Device time of the last *_dev / host-facing compute call on this context,
  * measured with hipEvents recorded on the stream the kernels were launched on.
@@ -122,7 +164,8 @@ int ta_helfand_msd_dev(ta_ctx *ctx, const double *d_vel, const double *d_pos,
  * have completed.                                                            */
 int ta_last_timing(ta_ctx *ctx, float *total_ms, float *main_kernel_ms);
 /* FFT length bookkeeping for a given n_frames: *m_out = padded half-length M
- * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1).  Up to
+ * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1; the lag-sum
+ * path: M = 2^a or 5*2^a up to 512 frames, R0*512 with R0 in {2,4,5,8,10,16,20} above).  Up to
  * M = 10240 the transform runs on chip; up to 16 x 10240 the lag sums (no
  * by-particle output) use an outer radix step around the on-chip transform
  * (n_stages counts it); beyond that, and for by-particle output past 10240

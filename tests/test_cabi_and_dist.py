@@ -18,7 +18,7 @@ def test_library_exports_header_symbols():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ta_abi_version() == 1
+    assert L.ta_abi_version() == 2
 
 
 def test_no_cpu_fallback():
@@ -40,8 +40,9 @@ def test_no_cpu_fallback():
 def test_plan_info():
     from transport_analysis_amd import _lib
 
-    for T, M in ((1, 16), (16, 16), (17, 20), (1000, 1024), (1025, 1280), (5001, 5120),
-                 (10000, 10240), (10240, 10240)):
+    # up to 512 frames the small plans (2^a, 5*2^a), above them R0 * 512 (csrc/wfft.hpp)
+    for T, M in ((1, 16), (16, 16), (17, 20), (500, 512), (512, 512), (513, 1024), (1000, 1024),
+                 (1025, 2048), (2049, 2560), (5001, 5120), (5121, 8192), (10000, 10240), (10240, 10240)):
         assert _lib.fft_plan_info(T)["M"] == M
     # beyond the on-chip plans: outer radix R x on-chip M (lag sums; csrc/fft_long.hip)
     for T, M in ((10241, 16384), (16385, 20480), (20481, 32768), (40961, 65536), (163840, 163840)):

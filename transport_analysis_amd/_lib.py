@@ -20,9 +20,11 @@ TA_F32, TA_F64 = 0, 1
 #: every symbol include/ta_hip.h declares
 EXPORTS = (
     "ta_abi_version", "ta_device_count", "ta_last_error", "ta_ctx_create", "ta_ctx_destroy",
-    "ta_stage_alloc", "ta_stage_commit", "ta_stage_device", "ta_stage_free",
+    "ta_stage_alloc", "ta_stage_alloc_device", "ta_stage_commit", "ta_stage_commit_dev",
+    "ta_stage_read_dev", "ta_stage_device", "ta_stage_free", "ta_stage_synth", "ta_trim",
     "ta_vacf_fft", "ta_vacf_direct", "ta_helfand_msd",
     "ta_vacf_fft_dev", "ta_vacf_direct_dev", "ta_helfand_msd_dev",
+    "ta_vacf_fft_staged", "ta_vacf_direct_staged", "ta_helfand_msd_staged",
     "ta_last_timing", "ta_fft_plan_info", "ta_set_option",
 )
 
@@ -92,8 +94,16 @@ def lib():
     L.ta_ctx_destroy.argtypes = [vp]
     L.ta_stage_alloc.argtypes = [vp, i64, i64, ci, ci, ci, ctypes.POINTER(vp)]
     L.ta_stage_commit.argtypes = [vp, i64, i64]
-    L.ta_stage_device.argtypes = [vp, ci, ctypes.POINTER(vp)]
+    L.ta_stage_alloc_device.argtypes = [vp, i64, i64, ci, ci]
+    L.ta_stage_commit_dev.argtypes = [vp, ci, vp, ci, i64, i64, i64, vp]
+    L.ta_stage_read_dev.argtypes = [vp, ci, vp, i64, vp]
+    L.ta_stage_device.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.ta_stage_free.argtypes = [vp]
+    L.ta_stage_synth.argtypes = [vp, ci, ctypes.c_uint64, i64, i64, vp]
+    L.ta_trim.argtypes = [vp]
+    L.ta_vacf_fft_staged.argtypes = [vp, vp, vp, i64, vp]
+    L.ta_vacf_direct_staged.argtypes = [vp, vp, vp, i64, vp]
+    L.ta_helfand_msd_staged.argtypes = [vp, vp, dbl, vp, vp, i64, vp]
     L.ta_vacf_fft.argtypes = [vp, vp, vp]
     L.ta_vacf_direct.argtypes = [vp, vp, vp]
     L.ta_helfand_msd.argtypes = [vp, vp, dbl, vp, vp]
@@ -178,10 +188,33 @@ class Context:
     def stage_commit(self, frame_lo, frame_hi):
         self._check(lib().ta_stage_commit(self._h, int(frame_lo), int(frame_hi)))
 
+    def stage_alloc_device(self, n_frames, n_atoms, dim, n_slabs=1):
+        """Device slabs only (pair-major), for data that is already on the GPU."""
+        self._slabs = []
+        self._check(lib().ta_stage_alloc_device(self._h, n_frames, n_atoms, dim, n_slabs))
+        self.shape = (int(n_frames), int(n_atoms), int(dim))
+
+    def stage_commit_dev(self, slab, d_src, ld_row, frame_lo, frame_hi, dtype=np.float64, stream=0):
+        code = TA_F64 if np.dtype(dtype) == np.float64 else TA_F32
+        self._check(lib().ta_stage_commit_dev(self._h, slab, d_src, code, int(ld_row), int(frame_lo),
+                                              int(frame_hi), stream or None))
+
+    def stage_synth(self, slab, seed, col_offset, n_cols_total, stream=0):
+        self._check(lib().ta_stage_synth(self._h, slab, int(seed), int(col_offset), int(n_cols_total),
+                                         stream or None))
+
+    def stage_read_dev(self, slab, d_dst, ld_row, stream=0):
+        self._check(lib().ta_stage_read_dev(self._h, slab, d_dst, int(ld_row), stream or None))
+
     def stage_device(self, slab):
-        p = ctypes.c_void_p()
-        self._check(lib().ta_stage_device(self._h, slab, ctypes.byref(p)))
-        return p.value
+        """(device pointer, rows per column pair, number of pairs) of the pair-major slab."""
+        p, pitch, n_pairs = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(lib().ta_stage_device(self._h, slab, ctypes.byref(p), ctypes.byref(pitch),
+                                          ctypes.byref(n_pairs)))
+        return p.value, pitch.value, n_pairs.value
+
+    def trim(self):
+        self._check(lib().ta_trim(self._h))
 
     def stage_free(self):
         self._slabs = []
@@ -219,6 +252,17 @@ class Context:
         self._check(lib().ta_helfand_msd_dev(self._h, d_vel, d_pos, d_masses, n_frames, n_atoms, dim,
                                              ld_row, scale, d_lagsum, d_bp or None, ld_bp,
                                              stream or None))
+
+    # -- compute on the staged slabs, device outputs (asynchronous) ------
+    def vacf_fft_staged(self, d_lagsum, d_bp=0, ld_bp=0, stream=0):
+        self._check(lib().ta_vacf_fft_staged(self._h, d_lagsum, d_bp or None, ld_bp, stream or None))
+
+    def vacf_direct_staged(self, d_lagsum, d_bp=0, ld_bp=0, stream=0):
+        self._check(lib().ta_vacf_direct_staged(self._h, d_lagsum, d_bp or None, ld_bp, stream or None))
+
+    def helfand_msd_staged(self, d_masses, scale, d_lagsum, d_bp=0, ld_bp=0, stream=0):
+        self._check(lib().ta_helfand_msd_staged(self._h, d_masses, scale, d_lagsum, d_bp or None, ld_bp,
+                                                stream or None))
 
     def last_timing(self):
         t, m = ctypes.c_float(), ctypes.c_float()

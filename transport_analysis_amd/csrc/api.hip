@@ -42,9 +42,12 @@ struct ta_ctx {
     std::string err;
     std::map<int, Tables> tables;
     std::map<long, LongTables> long_tables;  // keyed by M'
-    DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, f32_stage, stage_buf, long_scratch, helf_p, helf_small;
-    // staging
-    int64_t st_T = 0, st_A = 0;
+    std::map<int, cd*> wf_tables;            // wfft.hip tables, keyed by R0
+    DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, bounce, stage_buf, long_scratch, helf_p, helf_small;
+    DevBuf pm_in[2];  // pair-major copies of frame-major *_dev inputs
+    // staging: pinned host slabs keep the reference's (n_frames, n_atoms, dim) layout, the
+    // device slabs are pair-major (layout.hip) with st_pitch rows per column pair
+    int64_t st_T = 0, st_A = 0, st_pitch = 0;
     int st_D = 0, st_dtype = TA_F64, st_nslabs = 0;
     std::vector<void*> h_slabs;
     std::vector<double*> d_slabs;
@@ -90,6 +93,31 @@ int ensure(ta_ctx* ctx, DevBuf& b, size_t bytes) {
     return TA_OK;
 }
 
+inline int64_t pm_pitch(int64_t n_frames) { return (n_frames + 7) / 8 * 8; }
+inline size_t pm_bytes(int64_t n_frames, int64_t n_cols) {
+    return (size_t)((n_cols + 1) / 2) * (size_t)pm_pitch(n_frames) * 16;
+}
+
+int get_wf_table(ta_ctx* ctx, int R0, cd** out) {
+    auto it = ctx->wf_tables.find(R0);
+    if (it != ctx->wf_tables.end()) {
+        *out = it->second;
+        return TA_OK;
+    }
+    std::vector<cd> a(wfft_table_elems(R0));
+    wfft_fill_table(R0, a.data());
+    cd* d = nullptr;
+    TA_HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(cd) * a.size()));
+    hipError_t e = hipMemcpy(d, a.data(), sizeof(cd) * a.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(d);
+        return fail(ctx, TA_E_HIP, std::string("twiddle table upload: ") + hipGetErrorString(e));
+    }
+    ctx->wf_tables[R0] = d;
+    *out = d;
+    return TA_OK;
+}
+
 const PlanEntry* find_plan(int64_t n_frames) {
     const PlanEntry* best = nullptr;
     for (const auto* tab : {&plans_pow2(), &plans_five()})
@@ -126,7 +154,11 @@ int get_tables(ta_ctx* ctx, int M, int R0, Tables* out) {
             for (long u = 0; u < L0; ++u) a[(2 + B) * (size_t)M + q * L0 + u] = w2m(u * (2 * q + B));
     Tables t;
     TA_HIP_TRY(ctx, hipMalloc((void**)&t.tw2, sizeof(cd) * (4 * (size_t)M + 4)));
-    TA_HIP_TRY(ctx, hipMemcpy(t.tw2, a.data(), sizeof(cd) * (4 * (size_t)M + 4), hipMemcpyHostToDevice));
+    hipError_t e = hipMemcpy(t.tw2, a.data(), sizeof(cd) * (4 * (size_t)M + 4), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(t.tw2);
+        return fail(ctx, TA_E_HIP, std::string("twiddle table upload: ") + hipGetErrorString(e));
+    }
     ctx->tables[M] = t;
     *out = t;
     return TA_OK;
@@ -154,10 +186,16 @@ int get_long_tables(ta_ctx* ctx, int M, int Rout, LongTables* out) {
     std::vector<int> perm;
     fft_long_perm(M, perm);
     LongTables t;
-    TA_HIP_TRY(ctx, hipMalloc((void**)&t.twL, sizeof(cd) * a.size()));
-    TA_HIP_TRY(ctx, hipMemcpy(t.twL, a.data(), sizeof(cd) * a.size(), hipMemcpyHostToDevice));
-    TA_HIP_TRY(ctx, hipMalloc((void**)&t.perm, sizeof(int) * perm.size()));
-    TA_HIP_TRY(ctx, hipMemcpy(t.perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc((void**)&t.twL, sizeof(cd) * a.size());
+    if (e == hipSuccess) e = hipMalloc((void**)&t.perm, sizeof(int) * perm.size());
+    if (e == hipSuccess) e = hipMemcpy(t.twL, a.data(), sizeof(cd) * a.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t.perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (t.twL) hipFree(t.twL);
+        if (t.perm) hipFree(t.perm);
+        return fail(ctx, e == hipErrorOutOfMemory ? TA_E_NOMEM : TA_E_HIP,
+                    std::string("long-transform tables: ") + hipGetErrorString(e));
+    }
     ctx->long_tables[Mp] = t;
     *out = t;
     return TA_OK;
@@ -171,7 +209,7 @@ const PlanEntry* plan_of_length(int M) {
 }
 
 // FFT lag sums for n_frames beyond the largest on-chip plan (fft_long.hip); timeseries only.
-int fft_long_impl(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int D, int64_t ld_row,
+int fft_long_impl(ta_ctx* ctx, const double* d_pm, int64_t pitch, int64_t T, int64_t A, int D,
                   double* d_lagsum, hipStream_t st, int M, int Rout) {
     const PlanEntry* plan = plan_of_length(M);
     if (!plan) return fail(ctx, TA_E_INVALID, "no on-chip plan for the long transform");
@@ -191,8 +229,11 @@ int fft_long_impl(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int D,
     if ((rc = ensure(ctx, ctx->long_scratch, sizeof(cd) * (size_t)nwg * 4 * 2 * Rout * M))) return rc;
     TA_HIP_TRY(ctx, hipMemsetAsync(ctx->partial.p, 0, acc_bytes, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    TA_HIP_TRY(ctx, launch_fft_long_accum(M, (int)nwg, st, d_vel, ld_row, (int)T, A * D, Rout, tb.tw2,
-                                          lt.twL, (double*)ctx->partial.p, (cd*)ctx->long_scratch.p));
+    // pair-major slab: rows 2 elements apart, pairs 2*pitch apart, every pair complete (an odd
+    // last column is stored next to zeros)
+    TA_HIP_TRY(ctx, launch_fft_long_accum(M, (int)nwg, st, d_pm, 2, 2 * pitch, (int)T, 2 * ((A * D + 1) / 2),
+                                          Rout, tb.tw2, lt.twL, (double*)ctx->partial.p,
+                                          (cd*)ctx->long_scratch.p));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     TA_HIP_TRY(ctx, launch_fft_long_finish(M, Rout, (const double*)ctx->partial.p, (int)nwg, lt.perm,
                                            lt.twL, (int)T, (double*)ctx->spec.p, d_lagsum, st));
@@ -209,7 +250,7 @@ int check_shape(ta_ctx* ctx, int64_t T, int64_t A, int D, int64_t ld_row) {
 }
 
 int direct_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos,
-                const double* d_masses, int64_t T, int64_t A, int D, int64_t ld_row, double scale,
+                const double* d_masses, int64_t T, int64_t A, int D, int64_t pitch, double scale,
                 double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st) {
     const bool f32 = ctx->opt_direct_f32 != 0;
     // Shape of the launch.  A thread owns one chunk pair (2L lags); a column group = W waves;
@@ -260,7 +301,7 @@ int direct_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos,
     }
     TA_HIP_TRY(ctx, hipMemsetAsync(ctx->ts_partial.p, 0, sizeof(double) * rows * T, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    TA_HIP_TRY(ctx, launch_direct(mode, f32, L, d_vel, d_pos, d_masses, ld_row, (int)T, A, D, scale, d_bp,
+    TA_HIP_TRY(ctx, launch_direct(mode, f32, L, d_vel, d_pos, d_masses, pitch, (int)T, A, D, scale, d_bp,
                                   ld_bp, (double*)ctx->ts_partial.p, (int)nwg, nt, lds, stage_buf,
                                   gnt, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
@@ -268,11 +309,203 @@ int direct_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos,
     return TA_OK;
 }
 
+
+// ---- compute on pair-major slabs (every entry point ends up here) --------------------------
+// FFT VACF.  Lag sums only (d_bp == NULL): T <= 512 the small on-chip plans, T <= 10240 the
+// wave-local kernels of wfft.hpp, T <= 163840 the outer-radix path; with a by-particle array
+// the on-chip plans up to 10240 frames; everything else the direct correlator (same quantity:
+// velocityautocorr.py:217-238 == :208-215 mathematically).
+int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A, int D,
+             double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st) {
+    int rc;
+    const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2;
+    int R0 = 0;
+    if (!d_bp && T > 512 && wfft_choose((long)T, &R0)) {
+        cd* tw = nullptr;
+        if ((rc = get_wf_table(ctx, R0, &tw))) return rc;
+        const int L2 = 2 * R0 * 512;
+        int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * wfft_max_wg_per_cu(R0);
+        nwg = std::max<int64_t>(1, std::min(nwg, n_pairs));
+        if ((rc = ensure(ctx, ctx->partial, sizeof(double) * (size_t)nwg * L2))) return rc;
+        if ((rc = ensure(ctx, ctx->spec, sizeof(double) * (size_t)L2))) return rc;
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+        TA_HIP_TRY(ctx, launch_wfft_accum(R0, (int)nwg, st, pm, pitch, (int)T, n_pairs, tw,
+                                          (double*)ctx->partial.p));
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+        TA_HIP_TRY(ctx, launch_wfft_finish(R0, (const double*)ctx->partial.p, (int)nwg, tw, (int)T,
+                                           (double*)ctx->spec.p, d_lagsum, st));
+        return TA_OK;
+    }
+    const PlanEntry* plan = find_plan(T);
+    int long_M = 0, long_R = 0;
+    if (!plan && !d_bp && fft_long_choose((long)T, &long_M, &long_R))
+        return fft_long_impl(ctx, pm, pitch, T, A, D, d_lagsum, st, long_M, long_R);
+    if (!plan)
+        return direct_impl(ctx, MODE_VACF, pm, nullptr, nullptr, T, A, D, pitch, 1.0, d_lagsum, d_bp, ld_bp, st);
+    Tables tb;
+    if ((rc = get_tables(ctx, plan->M, plan->R_first, &tb))) return rc;
+    FftArgs a{};
+    a.vel = pm;
+    a.ld_row = 2;               // pair-major: rows of a pair are 2 elements apart,
+    a.pair_stride = 2 * pitch;  // pairs 2*pitch elements apart
+    a.flags = (int)ctx->opt_fft_debug;
+    a.T = (int)T;
+    a.n_cols = n_cols;
+    a.n_atoms = A;
+    a.D = D;
+    a.tw2 = tb.tw2;
+    const size_t acc_blk = (size_t)((plan->K_last * plan->R_last + 1) / 2) * 2 * plan->NT;
+    if (!d_bp) {
+        a.n_cols = 2 * n_pairs;  // every stored pair is complete (an odd last column sits next to zeros)
+        int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * plan->max_wg_per_cu(0);
+        nwg = std::max<int64_t>(1, std::min(nwg, n_pairs));
+        if (nwg >= 8) nwg -= nwg % 8;
+        const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * acc_blk;
+        if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
+        const int n_slices = (int)std::min<int64_t>(4, nwg);
+        if ((rc = ensure(ctx, ctx->spec, sizeof(double) * 2 * plan->M * n_slices))) return rc;
+        a.partial = (double*)ctx->partial.p;
+        TA_HIP_TRY(ctx, hipMemsetAsync(a.partial, 0, acc_bytes, st));
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+        TA_HIP_TRY(ctx, plan->accum(true, (int)nwg, st, a));
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+        TA_HIP_TRY(ctx, launch_sum_partials_perm(a.partial, (int)nwg, plan->M, plan->NT, plan->R_last,
+                                                 plan->K_last, plan->TASKS_last, (double*)ctx->spec.p,
+                                                 n_slices, st));
+        a.spec = (const double*)ctx->spec.p;
+        a.n_slices = n_slices;
+        a.lagsum = d_lagsum;
+        TA_HIP_TRY(ctx, plan->finalize(st, a));
+    } else {
+        int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * plan->max_wg_per_cu(2);
+        nwg = std::max<int64_t>(1, std::min(nwg, A));
+        if (nwg >= 8) nwg -= nwg % 8;
+        const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * acc_blk;
+        if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
+        a.partial = (double*)ctx->partial.p;
+        a.by_particle = d_bp;
+        a.ld_bp = ld_bp;
+        TA_HIP_TRY(ctx, hipMemsetAsync(a.partial, 0, acc_bytes, st));
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+        TA_HIP_TRY(ctx, plan->by_particle((int)nwg, st, a));
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+        // lag sums = row sums of the by-particle array (velocityautocorr.py:214)
+        TA_HIP_TRY(ctx, launch_row_sums(d_bp, T, A, ld_bp, d_lagsum, st));
+    }
+    return TA_OK;
+}
+
+// Helfand mean squared differences (viscosity.py:201-233); the "helfand_fft" option evaluates
+// them as S1 - 2 S2 (helfand_fft.hip) where an FFT path exists for the request.
+int helfand_impl(ta_ctx* ctx, const double* pm_vel, const double* pm_pos, const double* d_masses,
+                 int64_t pitch, int64_t T, int64_t A, int D, double scale, double* d_lagsum,
+                 double* d_bp, int64_t ld_bp, hipStream_t st) {
+    int rc;
+    const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2;
+    const bool fft_ok = ctx->opt_helfand_fft && T >= 2;
+    int r0 = 0, lm = 0, lr = 0;
+    const bool has_fft_ts = (T > 512 && wfft_choose((long)T, &r0)) || find_plan(T) || fft_long_choose((long)T, &lm, &lr);
+    if (fft_ok && !d_bp && has_fft_ts) {
+        const int n_parts = (int)std::min<int64_t>(1024, n_pairs);
+        if ((rc = ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)))) return rc;
+        if ((rc = ensure(ctx, ctx->helf_small, sizeof(double) * ((size_t)n_parts * T + 3 * (size_t)T + 1)))) return rc;
+        double* P = (double*)ctx->helf_p.p;
+        double* Qpart = (double*)ctx->helf_small.p;
+        double* Q = Qpart + (size_t)n_parts * T;
+        double* S2 = Q + T;
+        double* C = S2 + T;
+        TA_HIP_TRY(ctx, hipMemsetAsync(Qpart, 0, sizeof(double) * (size_t)n_parts * T, st));
+        TA_HIP_TRY(ctx, launch_helfand_product(pm_vel, pm_pos, d_masses, pitch, T, n_cols, D, P, Qpart, n_parts, st));
+        TA_HIP_TRY(ctx, launch_sum_partials(Qpart, n_parts, T, Q, st));
+        if ((rc = fft_impl(ctx, P, pitch, T, A, D, S2, nullptr, 0, st))) return rc;
+        TA_HIP_TRY(ctx, launch_helfand_combine(Q, S2, C, (int)T, scale / (double)D, d_lagsum, st));
+        return TA_OK;
+    }
+    if (fft_ok && d_bp && find_plan(T)) {
+        if ((rc = ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)))) return rc;
+        if ((rc = ensure(ctx, ctx->helf_small, sizeof(double) * ((size_t)T + 1) * A))) return rc;
+        double* P = (double*)ctx->helf_p.p;
+        double* Ca = (double*)ctx->helf_small.p;
+        if (n_cols & 1)  // the unpaired last column's partner is never written by the product kernel
+            TA_HIP_TRY(ctx, hipMemsetAsync(P + (size_t)(n_pairs - 1) * pitch * 2, 0, (size_t)pitch * 16, st));
+        TA_HIP_TRY(ctx, launch_helfand_product_bp(pm_vel, pm_pos, d_masses, pitch, T, A, D, P, Ca, st));
+        if ((rc = fft_impl(ctx, P, pitch, T, A, D, d_lagsum, d_bp, ld_bp, st))) return rc;
+        TA_HIP_TRY(ctx, launch_helfand_combine_bp(Ca, A, (int)T, scale / (double)D, d_bp, ld_bp, st));
+        TA_HIP_TRY(ctx, launch_row_sums(d_bp, T, A, ld_bp, d_lagsum, st));
+        return TA_OK;
+    }
+    return direct_impl(ctx, MODE_HELFAND, pm_vel, pm_pos, d_masses, T, A, D, pitch, scale, d_lagsum, d_bp,
+                       ld_bp, st);
+}
+
+enum { W_FFT = 0, W_DIRECT = 1, W_HELFAND = 2 };
+
+// one compute call on pair-major slabs, bracketed by the timing events
+int compute_pm(ta_ctx* ctx, int which, const double* pm_vel, const double* pm_pos, const double* d_masses,
+               int64_t pitch, int64_t T, int64_t A, int D, double scale, double* d_lagsum, double* d_bp,
+               int64_t ld_bp, hipStream_t st, bool record_start) {
+    int rc;
+    ctx->timing_valid = false;
+    if (record_start) TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+    // paths without a dominant kernel of their own re-record ev[1]/ev[2] inside
+    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+    if (which == W_FFT) rc = fft_impl(ctx, pm_vel, pitch, T, A, D, d_lagsum, d_bp, ld_bp, st);
+    else if (which == W_DIRECT)
+        rc = direct_impl(ctx, MODE_VACF, pm_vel, nullptr, nullptr, T, A, D, pitch, 1.0, d_lagsum, d_bp, ld_bp, st);
+    else rc = helfand_impl(ctx, pm_vel, pm_pos, d_masses, pitch, T, A, D, scale, d_lagsum, d_bp, ld_bp, st);
+    if (rc) return rc;
+    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
+    ctx->timing_valid = true;
+    return TA_OK;
+}
+
+// frame-major device input of a *_dev entry point -> the context's pair-major scratch slab
+int relayout_input(ta_ctx* ctx, int k, const double* d_src, int64_t T, int64_t n_cols, int64_t ld_row,
+                   hipStream_t st, const double** out) {
+    int rc = ensure(ctx, ctx->pm_in[k], pm_bytes(T, n_cols));
+    if (rc) return rc;
+    TA_HIP_TRY(ctx, launch_relayout(d_src, false, ld_row, n_cols, T, (double*)ctx->pm_in[k].p, pm_pitch(T), 0, st));
+    *out = (const double*)ctx->pm_in[k].p;
+    return TA_OK;
+}
+
+int dev_entry(ta_ctx* ctx, int which, const double* d_vel, const double* d_pos, const double* d_masses,
+              int64_t T, int64_t A, int D, int64_t ld_row, double scale, double* d_lagsum, double* d_bp,
+              int64_t ld_bp, void* stream) {
+    int rc = check_shape(ctx, T, A, D, ld_row);
+    if (rc) return rc;
+    if (!d_vel || !d_lagsum || (which == W_HELFAND && (!d_pos || !d_masses)))
+        return fail(ctx, TA_E_INVALID, "null device pointer");
+    if (d_bp && ld_bp < A) return fail(ctx, TA_E_INVALID, "ld_bp smaller than n_atoms");
+    TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as for any HIP call
+    ctx->timing_valid = false;
+    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+    const double *pv = nullptr, *px = nullptr;
+    if ((rc = relayout_input(ctx, 0, d_vel, T, A * D, ld_row, st, &pv))) return rc;
+    if (which == W_HELFAND && (rc = relayout_input(ctx, 1, d_pos, T, A * D, ld_row, st, &px))) return rc;
+    return compute_pm(ctx, which, pv, px, d_masses, pm_pitch(T), T, A, D, scale, d_lagsum, d_bp, ld_bp, st, false);
+}
+
+int staged_entry(ta_ctx* ctx, int which, const double* d_masses, double scale, double* d_lagsum,
+                 double* d_bp, int64_t ld_bp, void* stream) {
+    if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    const int need = which == W_HELFAND ? 2 : 1;
+    if (ctx->st_nslabs < need) return fail(ctx, TA_E_STATE, "slabs have not been staged");
+    if (!d_lagsum || (which == W_HELFAND && !d_masses)) return fail(ctx, TA_E_INVALID, "null device pointer");
+    if (d_bp && ld_bp < ctx->st_A) return fail(ctx, TA_E_INVALID, "ld_bp smaller than n_atoms");
+    TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return compute_pm(ctx, which, ctx->d_slabs[0], need == 2 ? ctx->d_slabs[1] : nullptr, d_masses,
+                      ctx->st_pitch, ctx->st_T, ctx->st_A, ctx->st_D, scale, d_lagsum, d_bp, ld_bp,
+                      (hipStream_t)stream, true);
+}
+
 }  // namespace
 
 extern "C" {
 
-int ta_abi_version(void) { return 1; }
+int ta_abi_version(void) { return 2; }
 
 int ta_device_count(void) {
     int n = 0;
@@ -295,12 +528,18 @@ int ta_ctx_create(int device, ta_ctx** out) {
     ta_ctx* ctx = new (std::nothrow) ta_ctx();
     if (!ctx) return fail(nullptr, TA_E_NOMEM, "out of host memory");
     ctx->device = device;
-    TA_HIP_TRY(ctx, hipSetDevice(device));
     hipDeviceProp_t prop;
-    TA_HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    for (auto& ev : ctx->ev)
+        if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+        const std::string msg = std::string("context setup: ") + hipGetErrorString(e);
+        ta_ctx_destroy(ctx);  // frees whatever was created
+        return fail(nullptr, TA_E_HIP, msg);
+    }
     ctx->n_cu = prop.multiProcessorCount;
-    TA_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    for (auto& ev : ctx->ev) TA_HIP_TRY(ctx, hipEventCreate(&ev));
     *out = ctx;
     return TA_OK;
 }
@@ -308,6 +547,7 @@ int ta_ctx_create(int device, ta_ctx** out) {
 int ta_stage_free(ta_ctx* ctx) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (void* h : ctx->h_slabs)
         if (h) hipHostFree(h);
     for (double* d : ctx->d_slabs)
@@ -315,7 +555,7 @@ int ta_stage_free(ta_ctx* ctx) {
     ctx->h_slabs.clear();
     ctx->d_slabs.clear();
     ctx->st_nslabs = 0;
-    ctx->st_T = ctx->st_A = 0;
+    ctx->st_T = ctx->st_A = ctx->st_pitch = 0;
     return TA_OK;
 }
 
@@ -324,21 +564,34 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ta_stage_free(ctx);
-    for (auto& kv : ctx->tables) {
-        hipFree(kv.second.tw2);
-    }
+    for (auto& kv : ctx->tables) hipFree(kv.second.tw2);
+    for (auto& kv : ctx->wf_tables) hipFree(kv.second);
     for (auto& kv : ctx->long_tables) {
         hipFree(kv.second.twL);
         hipFree(kv.second.perm);
     }
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
-                      &ctx->masses, &ctx->f32_stage, &ctx->stage_buf, &ctx->long_scratch, &ctx->helf_p,
-                      &ctx->helf_small})
+                      &ctx->masses, &ctx->bounce, &ctx->stage_buf, &ctx->long_scratch, &ctx->helf_p,
+                      &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1]})
         if (b->p) hipFree(b->p);
     for (auto& ev : ctx->ev)
         if (ev) hipEventDestroy(ev);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
+    return TA_OK;
+}
+
+int ta_trim(ta_ctx* ctx) {
+    if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    hipSetDevice(ctx->device);
+    hipDeviceSynchronize();
+    for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_bp, &ctx->bounce, &ctx->stage_buf,
+                      &ctx->long_scratch, &ctx->helf_p, &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1]})
+        if (b->p) {
+            hipFree(b->p);
+            b->p = nullptr;
+            b->bytes = 0;
+        }
     return TA_OK;
 }
 
@@ -356,6 +609,14 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
 }
 
 int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_stages) {
+    int R0 = 0;
+    if (n_frames > 512 && wfft_choose((long)n_frames, &R0)) {
+        // first-stage radix R0, then one wave per 512-point sub-series (8 x 8 x 8)
+        if (m_out) *m_out = (int64_t)R0 * 512;
+        if (n_threads) *n_threads = 512;
+        if (n_stages) *n_stages = 4;
+        return TA_OK;
+    }
     const PlanEntry* p = find_plan(n_frames);
     int long_M = 0, long_R = 0;
     if (!p && fft_long_choose((long)n_frames, &long_M, &long_R)) {
@@ -374,37 +635,52 @@ int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_st
 }
 
 /* ------------------------------------------------------------------ staging */
-int ta_stage_alloc(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, int dim, int dtype, int n_slabs,
-                   void** h_slabs) {
+static int stage_alloc_common(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, int dim, int dtype,
+                              int n_slabs, void** h_slabs) {
     int rc = check_shape(ctx, n_frames, n_atoms, dim, n_atoms * dim);
     if (rc) return rc;
-    if (!h_slabs || n_slabs < 1 || n_slabs > 4) return fail(ctx, TA_E_INVALID, "bad slab count");
+    if (n_slabs < 1 || n_slabs > 4) return fail(ctx, TA_E_INVALID, "bad slab count");
     if (dtype != TA_F32 && dtype != TA_F64) return fail(ctx, TA_E_INVALID, "bad dtype");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ta_stage_free(ctx);
     const size_t n = (size_t)n_frames * n_atoms * dim;
     const size_t esz = dtype == TA_F32 ? 4 : 8;
+    const size_t dbytes = pm_bytes(n_frames, n_atoms * dim);
     for (int i = 0; i < n_slabs; ++i) {
         void* h = nullptr;
         double* d = nullptr;
-        hipError_t e = hipHostMalloc(&h, n * esz, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc((void**)&d, n * sizeof(double));
+        hipError_t e = hipSuccess;
+        if (h_slabs) e = hipHostMalloc(&h, n * esz, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void**)&d, dbytes);
         if (e != hipSuccess) {
             if (h) hipHostFree(h);
             ta_stage_free(ctx);
             return fail(ctx, TA_E_NOMEM, std::string("staging allocation failed: ") + hipGetErrorString(e));
         }
-        memset(h, 0, n * esz);  // the reference starts from np.zeros (velocityautocorr.py:150)
+        if (h) memset(h, 0, n * esz);  // the reference starts from np.zeros (velocityautocorr.py:150)
         ctx->h_slabs.push_back(h);
         ctx->d_slabs.push_back(d);
-        h_slabs[i] = h;
+        // frames never committed read as zeros, like the reference's np.zeros slab
+        TA_HIP_TRY(ctx, hipMemsetAsync(d, 0, dbytes, ctx->stream));
+        if (h_slabs) h_slabs[i] = h;
     }
     ctx->st_T = n_frames;
     ctx->st_A = n_atoms;
     ctx->st_D = dim;
     ctx->st_dtype = dtype;
     ctx->st_nslabs = n_slabs;
+    ctx->st_pitch = pm_pitch(n_frames);
     return TA_OK;
+}
+
+int ta_stage_alloc(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, int dim, int dtype, int n_slabs,
+                   void** h_slabs) {
+    if (!h_slabs) return fail(ctx, TA_E_INVALID, "h_slabs is NULL");
+    return stage_alloc_common(ctx, n_frames, n_atoms, dim, dtype, n_slabs, h_slabs);
+}
+
+int ta_stage_alloc_device(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, int dim, int n_slabs) {
+    return stage_alloc_common(ctx, n_frames, n_atoms, dim, TA_F64, n_slabs, nullptr);
 }
 
 int ta_stage_commit(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
@@ -412,201 +688,103 @@ int ta_stage_commit(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
     if (ctx->st_nslabs == 0) return fail(ctx, TA_E_STATE, "ta_stage_alloc has not been called");
     if (frame_lo < 0 || frame_hi > ctx->st_T || frame_lo > frame_hi)
         return fail(ctx, TA_E_INVALID, "frame range out of bounds");
+    if (!ctx->h_slabs[0]) return fail(ctx, TA_E_STATE, "device-only slabs: use ta_stage_commit_dev");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t row = (size_t)ctx->st_A * ctx->st_D;
-    const size_t n = (size_t)(frame_hi - frame_lo) * row;
-    if (n == 0) return TA_OK;
+    const size_t esz = ctx->st_dtype == TA_F32 ? 4 : 8;
+    if (frame_hi == frame_lo) return TA_OK;
+    // frames cross PCIe in their native width into a landing buffer (<= 64 MiB) and are
+    // transposed into the pair-major slab on the device (float32 widened on the way)
+    const int64_t per = std::max<int64_t>(1, (int64_t)(((size_t)64 << 20) / (row * esz)));
+    const int64_t chunk = std::min<int64_t>(per, frame_hi - frame_lo);
+    int rc = ensure(ctx, ctx->bounce, (size_t)chunk * row * esz);
+    if (rc) return rc;
     for (int i = 0; i < ctx->st_nslabs; ++i) {
-        double* dst = ctx->d_slabs[i] + (size_t)frame_lo * row;
-        if (ctx->st_dtype == TA_F64) {
-            const double* src = (const double*)ctx->h_slabs[i] + (size_t)frame_lo * row;
-            TA_HIP_TRY(ctx, hipMemcpyAsync(dst, src, n * 8, hipMemcpyHostToDevice, ctx->stream));
-        } else {
-            const size_t chunk = std::min(n, (size_t)64 << 20);  // elements per staging round
-            int rc = ensure(ctx, ctx->f32_stage, chunk * 4);
-            if (rc) return rc;
-            const float* src = (const float*)ctx->h_slabs[i] + (size_t)frame_lo * row;
-            for (size_t off = 0; off < n; off += chunk) {
-                const size_t m = std::min(chunk, n - off);
-                TA_HIP_TRY(ctx, hipMemcpyAsync(ctx->f32_stage.p, src + off, m * 4,
-                                               hipMemcpyHostToDevice, ctx->stream));
-                TA_HIP_TRY(ctx, launch_widen_f32((const float*)ctx->f32_stage.p, dst + off, (long)m,
-                                                 ctx->stream));
-            }
+        for (int64_t f = frame_lo; f < frame_hi; f += chunk) {
+            const int64_t m = std::min(chunk, frame_hi - f);
+            const char* src = (const char*)ctx->h_slabs[i] + (size_t)f * row * esz;
+            TA_HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce.p, src, (size_t)m * row * esz, hipMemcpyHostToDevice,
+                                           ctx->stream));
+            TA_HIP_TRY(ctx, launch_relayout(ctx->bounce.p, ctx->st_dtype == TA_F32, (long)row, (long)row, m,
+                                            ctx->d_slabs[i], ctx->st_pitch, f, ctx->stream));
         }
     }
     return TA_OK;
 }
 
-int ta_stage_device(ta_ctx* ctx, int slab, double** d_slab) {
+int ta_stage_commit_dev(ta_ctx* ctx, int slab, const void* d_src, int dtype, int64_t ld_row,
+                        int64_t frame_lo, int64_t frame_hi, void* stream) {
+    if (!ctx || !d_src) return fail(ctx, TA_E_INVALID, "null argument");
+    if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
+    if (dtype != TA_F32 && dtype != TA_F64) return fail(ctx, TA_E_INVALID, "bad dtype");
+    if (frame_lo < 0 || frame_hi > ctx->st_T || frame_lo > frame_hi)
+        return fail(ctx, TA_E_INVALID, "frame range out of bounds");
+    if (ld_row < ctx->st_A * ctx->st_D) return fail(ctx, TA_E_INVALID, "ld_row smaller than n_atoms*dim");
+    TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    TA_HIP_TRY(ctx, launch_relayout(d_src, dtype == TA_F32, ld_row, ctx->st_A * ctx->st_D, frame_hi - frame_lo,
+                                    ctx->d_slabs[slab], ctx->st_pitch, frame_lo, (hipStream_t)stream));
+    return TA_OK;
+}
+
+int ta_stage_synth(ta_ctx* ctx, int slab, uint64_t seed, int64_t col_offset, int64_t n_cols_total,
+                   void* stream) {
+    if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
+    if (col_offset < 0 || col_offset + ctx->st_A * ctx->st_D > n_cols_total)
+        return fail(ctx, TA_E_INVALID, "column block outside the synthetic tensor");
+    TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    TA_HIP_TRY(ctx, launch_synth(ctx->d_slabs[slab], ctx->st_pitch, ctx->st_A * ctx->st_D, ctx->st_T, seed,
+                                 col_offset, n_cols_total, (hipStream_t)stream));
+    return TA_OK;
+}
+
+int ta_stage_read_dev(ta_ctx* ctx, int slab, double* d_dst, int64_t ld_row, void* stream) {
+    if (!ctx || !d_dst) return fail(ctx, TA_E_INVALID, "null argument");
+    if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
+    if (ld_row < ctx->st_A * ctx->st_D) return fail(ctx, TA_E_INVALID, "ld_row smaller than n_atoms*dim");
+    TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    TA_HIP_TRY(ctx, launch_unlayout(ctx->d_slabs[slab], ctx->st_pitch, ctx->st_A * ctx->st_D, ctx->st_T, d_dst,
+                                    ld_row, (hipStream_t)stream));
+    return TA_OK;
+}
+
+int ta_stage_device(ta_ctx* ctx, int slab, double** d_slab, int64_t* pitch_rows, int64_t* n_pairs) {
     if (!ctx || !d_slab) return fail(ctx, TA_E_INVALID, "null argument");
     if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
     *d_slab = ctx->d_slabs[slab];
+    if (pitch_rows) *pitch_rows = ctx->st_pitch;
+    if (n_pairs) *n_pairs = (ctx->st_A * ctx->st_D + 1) / 2;
     return TA_OK;
 }
 
 /* --------------------------------------------------------- device compute */
 int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int D, int64_t ld_row,
                     double* d_lagsum, double* d_bp, int64_t ld_bp, void* stream) {
-    int rc = check_shape(ctx, T, A, D, ld_row);
-    if (rc) return rc;
-    if (!d_vel || !d_lagsum) return fail(ctx, TA_E_INVALID, "null device pointer");
-    if (d_bp && ld_bp < A) return fail(ctx, TA_E_INVALID, "ld_bp smaller than n_atoms");
-    TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as for any HIP call
-    ctx->timing_valid = false;
-    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-    const PlanEntry* plan = find_plan(T);
-    int long_M = 0, long_R = 0;
-    if (!plan && !d_bp && fft_long_choose((long)T, &long_M, &long_R)) {
-        // longer than the largest on-chip transform, lag sums only: outer radix step while
-        // the column is read, on-chip transforms of the derived series (fft_long.hip)
-        rc = fft_long_impl(ctx, d_vel, T, A, D, ld_row, d_lagsum, st, long_M, long_R);
-        if (rc) return rc;
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
-        ctx->timing_valid = true;
-        return TA_OK;
-    }
-    if (!plan) {
-        // by-particle output (or longer than 16 x 10240 frames): the direct correlator computes
-        // the same quantity (velocityautocorr.py:217-238 == :208-215 mathematically)
-        rc = direct_impl(ctx, MODE_VACF, d_vel, nullptr, nullptr, T, A, D, ld_row, 1.0, d_lagsum,
-                         d_bp, ld_bp, st);
-        if (rc) return rc;
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
-        ctx->timing_valid = true;
-        return TA_OK;
-    }
-    Tables tb;
-    if ((rc = get_tables(ctx, plan->M, plan->R_first, &tb))) return rc;
-    FftArgs a{};
-    a.vel = d_vel;
-    a.ld_row = ld_row;
-    a.pair_stride = 2;
-    a.flags = (int)ctx->opt_fft_debug;
-    a.T = (int)T;
-    a.n_cols = A * D;
-    a.n_atoms = A;
-    a.D = D;
-    a.tw2 = tb.tw2;
-    if (!d_bp) {
-        // the all-16-byte-loads instantiation needs every pair complete: an odd column count
-        // (possible with an even ld_row when the shard is a column block of a wider slab) takes
-        // the general one, which still uses 16-byte loads wherever a pair is aligned
-        const bool vec = (ld_row % 2 == 0) && ((uintptr_t)d_vel % 16 == 0) && ((A * D) % 2 == 0);
-        const int64_t n_pairs = (A * D + 1) / 2;
-        int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg
-                                           : (int64_t)ctx->n_cu * plan->max_wg_per_cu(vec ? 0 : 1);
-        nwg = std::max<int64_t>(1, std::min(nwg, n_pairs));
-        if (nwg >= 8) nwg -= nwg % 8;  // XCD-aware walk
-        const size_t acc_blk = (size_t)((plan->K_last * plan->R_last + 1) / 2) * 2 * plan->NT;
-        const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * acc_blk;
-        if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
-        const int n_slices = (int)std::min<int64_t>(4, nwg);
-        if ((rc = ensure(ctx, ctx->spec, sizeof(double) * 2 * plan->M * n_slices))) return rc;
-        a.partial = (double*)ctx->partial.p;
-        TA_HIP_TRY(ctx, hipMemsetAsync(a.partial, 0, acc_bytes, st));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-        TA_HIP_TRY(ctx, plan->accum(vec, (int)nwg, st, a));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-        TA_HIP_TRY(ctx, launch_sum_partials_perm(a.partial, (int)nwg, plan->M, plan->NT, plan->R_last,
-                                                 plan->K_last, plan->TASKS_last,
-                                                 (double*)ctx->spec.p, n_slices, st));
-        a.spec = (const double*)ctx->spec.p;
-        a.n_slices = n_slices;
-        a.lagsum = d_lagsum;
-        TA_HIP_TRY(ctx, plan->finalize(st, a));
-    } else {
-        int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg
-                                           : (int64_t)ctx->n_cu * plan->max_wg_per_cu(2);
-        nwg = std::max<int64_t>(1, std::min(nwg, A));
-        if (nwg >= 8) nwg -= nwg % 8;  // XCD-aware walk
-        // accumulator swap blocks of the small plans (as in the timeseries path)
-        const size_t acc_blk = (size_t)((plan->K_last * plan->R_last + 1) / 2) * 2 * plan->NT;
-        const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * acc_blk;
-        if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
-        a.partial = (double*)ctx->partial.p;
-        a.by_particle = d_bp;
-        a.ld_bp = ld_bp;
-        TA_HIP_TRY(ctx, hipMemsetAsync(a.partial, 0, acc_bytes, st));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-        TA_HIP_TRY(ctx, plan->by_particle((int)nwg, st, a));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-        // lag sums = row sums of the by-particle array (velocityautocorr.py:214)
-        TA_HIP_TRY(ctx, launch_row_sums(d_bp, T, A, ld_bp, d_lagsum, st));
-    }
-    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
-    ctx->timing_valid = true;
-    return TA_OK;
+    return dev_entry(ctx, W_FFT, d_vel, nullptr, nullptr, T, A, D, ld_row, 1.0, d_lagsum, d_bp, ld_bp, stream);
 }
 
-int ta_vacf_direct_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int D,
-                       int64_t ld_row, double* d_lagsum, double* d_bp, int64_t ld_bp, void* stream) {
-    int rc = check_shape(ctx, T, A, D, ld_row);
-    if (rc) return rc;
-    if (!d_vel || !d_lagsum) return fail(ctx, TA_E_INVALID, "null device pointer");
-    if (d_bp && ld_bp < A) return fail(ctx, TA_E_INVALID, "ld_bp smaller than n_atoms");
-    TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as for any HIP call
-    ctx->timing_valid = false;
-    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-    rc = direct_impl(ctx, MODE_VACF, d_vel, nullptr, nullptr, T, A, D, ld_row, 1.0, d_lagsum, d_bp,
-                     ld_bp, st);
-    if (rc) return rc;
-    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
-    ctx->timing_valid = true;
-    return TA_OK;
+int ta_vacf_direct_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int D, int64_t ld_row,
+                       double* d_lagsum, double* d_bp, int64_t ld_bp, void* stream) {
+    return dev_entry(ctx, W_DIRECT, d_vel, nullptr, nullptr, T, A, D, ld_row, 1.0, d_lagsum, d_bp, ld_bp, stream);
 }
 
 int ta_helfand_msd_dev(ta_ctx* ctx, const double* d_vel, const double* d_pos, const double* d_masses,
                        int64_t T, int64_t A, int D, int64_t ld_row, double scale, double* d_lagsum,
                        double* d_bp, int64_t ld_bp, void* stream) {
-    int rc = check_shape(ctx, T, A, D, ld_row);
-    if (rc) return rc;
-    if (!d_vel || !d_pos || !d_masses || !d_lagsum)
-        return fail(ctx, TA_E_INVALID, "null device pointer");
-    if (d_bp && ld_bp < A) return fail(ctx, TA_E_INVALID, "ld_bp smaller than n_atoms");
-    TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as for any HIP call
-    ctx->timing_valid = false;
-    if (ctx->opt_helfand_fft && !d_bp && T >= 2) {
-        // option "helfand_fft" (lag sums only): S1 from prefix sums, S2 = FFT lag sums of the
-        // product slab P = (m v) x (helfand_fft.hip)
-        const size_t n = (size_t)T * A * D;
-        if ((rc = ensure(ctx, ctx->helf_p, sizeof(double) * n))) return rc;
-        if ((rc = ensure(ctx, ctx->helf_small, sizeof(double) * (3 * (size_t)T + 1)))) return rc;
-        double* P = (double*)ctx->helf_p.p;
-        double* Q = (double*)ctx->helf_small.p;
-        double* S2 = Q + T;
-        double* C = S2 + T;
-        TA_HIP_TRY(ctx, launch_helfand_product(d_vel, d_pos, d_masses, ld_row, T, A * D, D, P, Q, st));
-        if ((rc = ta_vacf_fft_dev(ctx, P, T, A, D, A * D, S2, nullptr, 0, stream))) return rc;
-        TA_HIP_TRY(ctx, launch_helfand_combine(Q, S2, C, (int)T, scale / (double)D, d_lagsum, st));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
-        return TA_OK;  // timing: ev[0..2] set by the FFT call, ev[3] after the combine
-    }
-    if (ctx->opt_helfand_fft && d_bp && T >= 2 && find_plan(T)) {
-        // the same per atom (on-chip FFT lengths only; longer trajectories take the direct
-        // correlator below): bp <- FFT by-particle autocorrelation of P, then S1 - 2 S2 in place
-        const size_t n = (size_t)T * A * D;
-        if ((rc = ensure(ctx, ctx->helf_p, sizeof(double) * n))) return rc;
-        if ((rc = ensure(ctx, ctx->helf_small, sizeof(double) * ((size_t)T + 1) * A))) return rc;
-        double* P = (double*)ctx->helf_p.p;
-        double* Ca = (double*)ctx->helf_small.p;
-        TA_HIP_TRY(ctx, launch_helfand_product_bp(d_vel, d_pos, d_masses, ld_row, T, A, D, P, Ca, st));
-        if ((rc = ta_vacf_fft_dev(ctx, P, T, A, D, A * D, d_lagsum, d_bp, ld_bp, stream))) return rc;
-        TA_HIP_TRY(ctx, launch_helfand_combine_bp(Ca, A, (int)T, scale / (double)D, d_bp, ld_bp, st));
-        TA_HIP_TRY(ctx, launch_row_sums(d_bp, T, A, ld_bp, d_lagsum, st));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
-        return TA_OK;
-    }
-    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
-    rc = direct_impl(ctx, MODE_HELFAND, d_vel, d_pos, d_masses, T, A, D, ld_row, scale, d_lagsum,
-                     d_bp, ld_bp, st);
-    if (rc) return rc;
-    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
-    ctx->timing_valid = true;
-    return TA_OK;
+    return dev_entry(ctx, W_HELFAND, d_vel, d_pos, d_masses, T, A, D, ld_row, scale, d_lagsum, d_bp, ld_bp, stream);
+}
+
+int ta_vacf_fft_staged(ta_ctx* ctx, double* d_lagsum, double* d_bp, int64_t ld_bp, void* stream) {
+    return staged_entry(ctx, W_FFT, nullptr, 1.0, d_lagsum, d_bp, ld_bp, stream);
+}
+
+int ta_vacf_direct_staged(ta_ctx* ctx, double* d_lagsum, double* d_bp, int64_t ld_bp, void* stream) {
+    return staged_entry(ctx, W_DIRECT, nullptr, 1.0, d_lagsum, d_bp, ld_bp, stream);
+}
+
+int ta_helfand_msd_staged(ta_ctx* ctx, const double* d_masses, double scale, double* d_lagsum,
+                          double* d_bp, int64_t ld_bp, void* stream) {
+    return staged_entry(ctx, W_HELFAND, d_masses, scale, d_lagsum, d_bp, ld_bp, stream);
 }
 
 int ta_last_timing(ta_ctx* ctx, float* total_ms, float* main_kernel_ms) {
@@ -626,11 +804,10 @@ static int host_compute(ta_ctx* ctx, int which, const double* h_masses, double s
                         double* h_ts, double* h_bp) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     if (!h_ts) return fail(ctx, TA_E_INVALID, "h_timeseries is NULL");
-    const int need = which == 2 ? 2 : 1;
+    const int need = which == W_HELFAND ? 2 : 1;
     if (ctx->st_nslabs < need) return fail(ctx, TA_E_STATE, "slabs have not been staged");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t T = ctx->st_T, A = ctx->st_A;
-    const int D = ctx->st_D;
     int rc = ensure(ctx, ctx->out_lagsum, sizeof(double) * T);
     if (rc) return rc;
     double* d_bp = nullptr;
@@ -639,33 +816,29 @@ static int host_compute(ta_ctx* ctx, int which, const double* h_masses, double s
         d_bp = (double*)ctx->out_bp.p;
     }
     double* d_ls = (double*)ctx->out_lagsum.p;
-    if (which == 0)
-        rc = ta_vacf_fft_dev(ctx, ctx->d_slabs[0], T, A, D, A * D, d_ls, d_bp, A, (void*)ctx->stream);
-    else if (which == 1)
-        rc = ta_vacf_direct_dev(ctx, ctx->d_slabs[0], T, A, D, A * D, d_ls, d_bp, A, (void*)ctx->stream);
-    else {
+    const double* d_m = nullptr;
+    if (which == W_HELFAND) {
         if (!h_masses) return fail(ctx, TA_E_INVALID, "h_masses is NULL");
         if ((rc = ensure(ctx, ctx->masses, sizeof(double) * A))) return rc;
-        TA_HIP_TRY(ctx, hipMemcpyAsync(ctx->masses.p, h_masses, sizeof(double) * A,
-                                       hipMemcpyHostToDevice, ctx->stream));
-        rc = ta_helfand_msd_dev(ctx, ctx->d_slabs[0], ctx->d_slabs[1], (const double*)ctx->masses.p,
-                                T, A, D, A * D, scale, d_ls, d_bp, A, (void*)ctx->stream);
+        TA_HIP_TRY(ctx, hipMemcpyAsync(ctx->masses.p, h_masses, sizeof(double) * A, hipMemcpyHostToDevice,
+                                       ctx->stream));
+        d_m = (const double*)ctx->masses.p;
     }
-    if (rc) return rc;
+    if ((rc = staged_entry(ctx, which, d_m, scale, d_ls, d_bp, A, (void*)ctx->stream))) return rc;
     TA_HIP_TRY(ctx, hipMemcpyAsync(h_ts, d_ls, sizeof(double) * T, hipMemcpyDeviceToHost, ctx->stream));
     if (h_bp)
-        TA_HIP_TRY(ctx, hipMemcpyAsync(h_bp, d_bp, sizeof(double) * (size_t)T * A,
-                                       hipMemcpyDeviceToHost, ctx->stream));
+        TA_HIP_TRY(ctx, hipMemcpyAsync(h_bp, d_bp, sizeof(double) * (size_t)T * A, hipMemcpyDeviceToHost,
+                                       ctx->stream));
     TA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const double n_at = (double)A;  // mean over atoms (velocityautocorr.py:214,237)
     for (int64_t k = 0; k < T; ++k) h_ts[k] /= n_at;
     return TA_OK;
 }
 
-int ta_vacf_fft(ta_ctx* ctx, double* h_ts, double* h_bp) { return host_compute(ctx, 0, nullptr, 1.0, h_ts, h_bp); }
-int ta_vacf_direct(ta_ctx* ctx, double* h_ts, double* h_bp) { return host_compute(ctx, 1, nullptr, 1.0, h_ts, h_bp); }
+int ta_vacf_fft(ta_ctx* ctx, double* h_ts, double* h_bp) { return host_compute(ctx, W_FFT, nullptr, 1.0, h_ts, h_bp); }
+int ta_vacf_direct(ta_ctx* ctx, double* h_ts, double* h_bp) { return host_compute(ctx, W_DIRECT, nullptr, 1.0, h_ts, h_bp); }
 int ta_helfand_msd(ta_ctx* ctx, const double* h_masses, double scale, double* h_ts, double* h_bp) {
-    return host_compute(ctx, 2, h_masses, scale, h_ts, h_bp);
+    return host_compute(ctx, W_HELFAND, h_masses, scale, h_ts, h_bp);
 }
 
 }  // extern "C"

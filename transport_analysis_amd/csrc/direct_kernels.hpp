@@ -254,7 +254,7 @@ __device__ __forceinline__ void chunk_accumulate(const float* __restrict__ s, in
 template <int MODE, int L, bool GLOBAL_STAGE, typename Real>
 __global__ void __launch_bounds__(1024)
     k_direct(const double* __restrict__ vel, const double* __restrict__ pos,
-             const double* __restrict__ masses, long ld_row, int T, long n_atoms, int D,
+             const double* __restrict__ masses, long pitch, int T, long n_atoms, int D,
              double scale, double* __restrict__ by_particle, long ld_bp,
              double* __restrict__ ts_partial, void* __restrict__ stage_buf, int gnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -284,10 +284,14 @@ __global__ void __launch_bounds__(1024)
             for (int a = 0; a < L; ++a) acc1[a] = acc2[a] = 0.0;
             for (int d = 0; d < D; ++d) {
                 __syncthreads();  // previous column fully consumed
+                // pair-major slab (layout.hip): column c, row e at ((c/2)*pitch + e)*2 + (c&1):
+                // consecutive lanes read consecutive rows, 16 bytes apart
+                const long c = atom * D + d;
+                const long cbase = (c >> 1) * pitch * 2 + (c & 1);
                 for (int e = tid; e < n_stage; e += nt) {
                     double val = 0.0;
                     if (valid && e < T) {
-                        const long g = (long)e * ld_row + atom * D + d;
+                        const long g = cbase + 2L * e;
                         val = vel[g];
                         if (MODE == MODE_HELFAND) val = (mass * val) * pos[g];
                     }

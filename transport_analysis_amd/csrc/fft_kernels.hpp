@@ -511,14 +511,17 @@ __global__ void __launch_bounds__(P::NT)
     // (x,y) for even atoms and (y,z) for odd ones (the sum over the atom's columns does not
     // care), so it is one load per row whenever the slab itself is 16-byte aligned.
     const bool slab16 = ((reinterpret_cast<unsigned long long>(vel) | ((unsigned long long)ld_row * 8)) & 15) == 0;
+    // column c of the shard starts at vel + (c/2)*pair_stride + (c&1) (rows ld_row elements
+    // apart): pair-major slabs have ld_row = 2, pair_stride = 2*pitch (layout.hip)
+    auto col_ptr = [&](long c) -> const double* { return vel + (c >> 1) * pair_stride + (c & 1); };
     auto unit_col = [&](long i) -> const double* {
         if constexpr (BYP) {
             const long atom = slot + (i / ppa) * nwg;
             if (D == 3) {
                 const int odd = (int)(atom & 1);
-                return vel + atom * 3 + ((i % ppa) == 0 ? odd : (odd ? 0 : 2));
+                return col_ptr(atom * 3 + ((i % ppa) == 0 ? odd : (odd ? 0 : 2)));
             }
-            return vel + atom * D;
+            return col_ptr(atom * D);
         } else {
             return vel + (slot + i * nwg) * pair_stride;
         }

@@ -44,7 +44,7 @@ __device__ __forceinline__ cd cfma(cd acc, cd a, cd b) {  // acc + a*b
 // the "wide gather" of DESIGN.md section 6, possible here because the data goes to scratch
 // anyway and does not have to be parked in registers.
 template <class P, int ROUT>
-__device__ __forceinline__ void long_phase0_quad(const double* __restrict__ col, long ld_row, int T,
+__device__ __forceinline__ void long_phase0_quad(const double* __restrict__ col, long ld_row, long pair_stride, int T,
                                                  const double* __restrict__ zeros,
                                                  const cd* __restrict__ twL, cd* __restrict__ scr, int tid) {
     using S0 = StageInfo<P, 0>;
@@ -71,7 +71,7 @@ __device__ __forceinline__ void long_phase0_quad(const double* __restrict__ col,
                 const double* p = t < T ? col + (long)t * ld_row : zeros;  // 64 zero bytes there
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const double2 v = *reinterpret_cast<const double2*>(p + 2 * q);
+                    const double2 v = *reinterpret_cast<const double2*>(p + (t < T ? q * pair_stride : 0));
                     z[g][j][q] = cd{v.x, v.y};
                 }
             }
@@ -154,7 +154,7 @@ __device__ __forceinline__ void long_phase0(const double* __restrict__ col, long
 
 template <class P>
 __global__ void __launch_bounds__(P::NT)
-    k_fft_accum_long(const double* __restrict__ vel, long ld_row, int T, long n_cols, int Rout,
+    k_fft_accum_long(const double* __restrict__ vel, long ld_row, long pair_stride, int T, long n_cols, int Rout,
                      const cd* __restrict__ tw2, const cd* __restrict__ twL,
                      double* __restrict__ accg, cd* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -187,14 +187,14 @@ __global__ void __launch_bounds__(P::NT)
       // ---- phase 0: gather once, partial sums of all 2R passes -> scratch
       const bool quadwide = slab16 && Rout <= 4 && 2 * (pair0 + 4) <= n_cols;
       if (quadwide) {
-          if (Rout == 2) long_phase0_quad<P, 2>(vel + 2 * pair0, ld_row, T, zeros, twL, scr, tid);
-          else long_phase0_quad<P, 4>(vel + 2 * pair0, ld_row, T, zeros, twL, scr, tid);
+          if (Rout == 2) long_phase0_quad<P, 2>(vel + pair0 * pair_stride, ld_row, pair_stride, T, zeros, twL, scr, tid);
+          else long_phase0_quad<P, 4>(vel + pair0 * pair_stride, ld_row, pair_stride, T, zeros, twL, scr, tid);
       }
       for (int pq = 0; pq < npq; ++pq) {
         const long pair = pair0 + pq;
         cd* scr_p = scr + pq * QS;
         if (quadwide) continue;
-        const double* col = vel + 2 * pair;
+        const double* col = vel + pair * pair_stride;
         const bool two = 2 * pair + 1 < n_cols;  // an odd last column has no partner
         const bool wide = two && slab16;         // one 16-byte load per row
 #define TA_P0(R)                                                                        \
@@ -328,13 +328,13 @@ __global__ void __launch_bounds__(256)
 }
 
 template <class P>
-hipError_t launch_accum(int nwg, hipStream_t st, const double* vel, long ld_row, int T, long n_cols,
+hipError_t launch_accum(int nwg, hipStream_t st, const double* vel, long ld_row, long pair_stride, int T, long n_cols,
                         int Rout, const cd* tw2, const cd* twL, double* accg, cd* scratch) {
     const size_t lds = (size_t)P::lds_elems() * sizeof(cd);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_accum_long<P>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_fft_accum_long<P>), dim3(nwg), dim3(P::NT), lds, st, vel, ld_row, T, n_cols,
+    hipLaunchKernelGGL((k_fft_accum_long<P>), dim3(nwg), dim3(P::NT), lds, st, vel, ld_row, pair_stride, T, n_cols,
                        Rout, tw2, twL, accg, scratch);
     return hipGetLastError();
 }
@@ -383,13 +383,13 @@ size_t fft_long_acc_block(int M) {  // doubles per workgroup and pass
     return (size_t)(M == PlanA::M ? acc_quads<PlanA>() * 2 * PlanA::NT : acc_quads<PlanB>() * 2 * PlanB::NT);
 }
 
-hipError_t launch_fft_long_accum(int M, int nwg, hipStream_t st, const double* vel, long ld_row, int T,
+hipError_t launch_fft_long_accum(int M, int nwg, hipStream_t st, const double* vel, long ld_row, long pair_stride, int T,
                                  long n_cols, int Rout, const cd* tw2, const cd* twL, double* accg,
                                  cd* scratch) {
     if (Rout != 2 && Rout != 4 && Rout != 8 && Rout != 16) return hipErrorInvalidValue;
     if (M == PlanA::M)
-        return launch_accum<PlanA>(nwg, st, vel, ld_row, T, n_cols, Rout, tw2, twL, accg, scratch);
-    return launch_accum<PlanB>(nwg, st, vel, ld_row, T, n_cols, Rout, tw2, twL, accg, scratch);
+        return launch_accum<PlanA>(nwg, st, vel, ld_row, pair_stride, T, n_cols, Rout, tw2, twL, accg, scratch);
+    return launch_accum<PlanB>(nwg, st, vel, ld_row, pair_stride, T, n_cols, Rout, tw2, twL, accg, scratch);
 }
 
 hipError_t launch_fft_long_finish(int M, int Rout, const double* partial, int n_parts, const int* perm,

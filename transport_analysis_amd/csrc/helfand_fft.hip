@@ -20,30 +20,33 @@
 namespace ta {
 namespace {
 
-// One workgroup per frame: P[t, col] = (m * v) * x, Q[t] = sum_col P^2 (fixed-order tree sum).
+// Pair-major slabs in and out (layout.hip).  A workgroup walks whole column pairs along time
+// (coalesced 16-byte rows): P[t, pair] = ((m v) x) for both columns, and the pair's
+// contribution P.x^2 + P.y^2 to Q[t] is added into the workgroup's own row of Qpart
+// ([gridDim.x][T], zeroed by the caller; summed over workgroups in a fixed order afterwards).
 __global__ void __launch_bounds__(256)
     k_helfand_product(const double* __restrict__ vel, const double* __restrict__ pos,
-                      const double* __restrict__ masses, long ld_row, long n_cols, int D,
-                      double* __restrict__ P, double* __restrict__ Q) {
-    __shared__ double red[256];
-    const long t = blockIdx.x;
-    const int tid = threadIdx.x;
-    const double* v = vel + t * ld_row;
-    const double* x = pos + t * ld_row;
-    double* p = P + t * n_cols;
-    double s = 0.0;
-    for (long c = tid; c < n_cols; c += 256) {
-        const double val = (masses[c / D] * v[c]) * x[c];
-        p[c] = val;
-        s += val * val;
+                      const double* __restrict__ masses, long pitch, long T, long n_cols, int D,
+                      double* __restrict__ P, double* __restrict__ Qpart) {
+    const long n_pairs = (n_cols + 1) / 2;
+    double* q = Qpart + (long)blockIdx.x * T;
+    for (long pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
+        const long c = 2 * pair;
+        const double m0 = masses[c / D];
+        const bool two = c + 1 < n_cols;
+        const double m1 = two ? masses[(c + 1) / D] : 0.0;
+        const double2* v = reinterpret_cast<const double2*>(vel) + pair * pitch;
+        const double2* x = reinterpret_cast<const double2*>(pos) + pair * pitch;
+        double2* p = reinterpret_cast<double2*>(P) + pair * pitch;
+        for (long t = threadIdx.x; t < T; t += 256) {
+            const double2 vv = v[t], xx = x[t];
+            double2 r;
+            r.x = (m0 * vv.x) * xx.x;
+            r.y = two ? (m1 * vv.y) * xx.y : 0.0;
+            p[t] = r;
+            q[t] += r.x * r.x + r.y * r.y;
+        }
     }
-    red[tid] = s;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-        if (tid < h) red[tid] += red[tid + h];
-        __syncthreads();
-    }
-    if (tid == 0) Q[t] = red[0];
 }
 
 // Single workgroup: C = exclusive prefix sums of Q (C[0] = 0 ... C[T]), then
@@ -95,22 +98,26 @@ __global__ void __launch_bounds__(256)
 // by-particle autocorrelation of P on entry; row 0 is set to exactly 0.
 __global__ void __launch_bounds__(256)
     k_helfand_product_bp(const double* __restrict__ vel, const double* __restrict__ pos,
-                         const double* __restrict__ masses, long ld_row, long n_atoms, int D,
+                         const double* __restrict__ masses, long pitch, long T, long n_atoms, int D,
                          double* __restrict__ P, double* __restrict__ Ca) {
-    const long t = blockIdx.y;
-    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // 64 atoms x 64 frames per workgroup; a thread walks 16 consecutive frames of its atom
+    // (pair-major slabs: consecutive rows of a column share cache lines), lanes = atoms, so
+    // the Ca rows are written 512 bytes at a time
+    const long n = (long)blockIdx.x * 64 + (threadIdx.x & 63);
     if (n >= n_atoms) return;
-    const double* v = vel + t * ld_row + n * D;
-    const double* x = pos + t * ld_row + n * D;
-    double* p = P + (t * n_atoms + n) * D;
+    const long t0 = (long)blockIdx.y * 64 + (threadIdx.x >> 6) * 16;
     const double m = masses[n];
-    double s = 0.0;
-    for (int d = 0; d < D; ++d) {
-        const double val = (m * v[d]) * x[d];
-        p[d] = val;
-        s += val * val;
+    for (long t = t0; t < t0 + 16 && t < T; ++t) {
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const long c = n * D + d;
+            const long g = ((c >> 1) * pitch + t) * 2 + (c & 1);
+            const double val = (m * vel[g]) * pos[g];
+            P[g] = val;
+            s += val * val;
+        }
+        Ca[(t + 1) * n_atoms + n] = s;
     }
-    Ca[(t + 1) * n_atoms + n] = s;
 }
 
 // 64 atoms x 4 time quarters per workgroup: every thread scans its quarter of its atom's
@@ -161,10 +168,10 @@ __global__ void __launch_bounds__(256)
 }  // namespace
 
 hipError_t launch_helfand_product_bp(const double* vel, const double* pos, const double* masses,
-                                     long ld_row, long T, long n_atoms, int D, double* P, double* Ca,
+                                     long pitch, long T, long n_atoms, int D, double* P, double* Ca,
                                      hipStream_t st) {
-    hipLaunchKernelGGL(k_helfand_product_bp, dim3((unsigned)((n_atoms + 255) / 256), (unsigned)T), dim3(256),
-                       0, st, vel, pos, masses, ld_row, n_atoms, D, P, Ca);
+    hipLaunchKernelGGL(k_helfand_product_bp, dim3((unsigned)((n_atoms + 63) / 64), (unsigned)((T + 63) / 64)),
+                       dim3(256), 0, st, vel, pos, masses, pitch, T, n_atoms, D, P, Ca);
     return hipGetLastError();
 }
 
@@ -175,11 +182,12 @@ hipError_t launch_helfand_combine_bp(double* Ca, long n_atoms, int T, double fac
     return hipGetLastError();
 }
 
+// Qpart: [n_parts][T], zeroed by the caller; the caller sums it over n_parts into Q.
 hipError_t launch_helfand_product(const double* vel, const double* pos, const double* masses,
-                                  long ld_row, long T, long n_cols, int D, double* P, double* Q,
-                                  hipStream_t st) {
-    hipLaunchKernelGGL(k_helfand_product, dim3((unsigned)T), dim3(256), 0, st, vel, pos, masses, ld_row,
-                       n_cols, D, P, Q);
+                                  long pitch, long T, long n_cols, int D, double* P, double* Qpart,
+                                  int n_parts, hipStream_t st) {
+    hipLaunchKernelGGL(k_helfand_product, dim3((unsigned)n_parts), dim3(256), 0, st, vel, pos, masses, pitch,
+                       T, n_cols, D, P, Qpart);
     return hipGetLastError();
 }
 

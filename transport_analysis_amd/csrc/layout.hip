@@ -1,0 +1,133 @@
+// layout.hip — the device-side slab layout ("pair-major") and the kernels that produce it.
+//
+// The reference stages velocities/positions as (n_frames, n_atoms, dim) row-major float64
+// (/root/reference/transport_analysis/velocityautocorr.py:150-152,192-194, viscosity.py:128-134,
+// 191-199): one atom's consecutive samples are n_atoms*dim*8 bytes apart, which is the worst
+// possible layout for kernels that walk the TIME axis of a column.  The build owns the staging
+// hooks, so frames are re-laid out on the device as they are committed:
+//
+//   column c = atom*dim + d of the shard;  pair p = c / 2;  n_pairs = ceil(n_cols / 2)
+//   element (t, c)  ->  slab[(p * pitch + t) * 2 + (c & 1)],     pitch = n_frames rounded up to 8
+//
+// i.e. every pair of adjacent columns is ONE contiguous array of `pitch` rows of 16 bytes
+// (x[t], y[t]); an odd last column is paired with zeros.  A wave reading consecutive rows of a
+// pair moves 1 KiB per load instruction; a column pair is the FFT kernels' complex series as it
+// stands.  The transposition runs on the committed chunk while the next chunk crosses PCIe.
+#include <hip/hip_runtime.h>
+
+#include "ta_internal.hpp"
+
+namespace ta {
+namespace {
+
+// src: frame-major rows [0, t_count) x columns [0, n_cols), row stride ld_row elements of SrcT.
+// dst rows t_dst0 + [0, t_count) of every pair are written.  64 x 64 tiles through LDS: reads
+// are 512 B (256 B for float32) per row segment, writes 1 KiB per pair (64 rows x 16 B).
+template <typename SrcT>
+__global__ void __launch_bounds__(256)
+    k_relayout(const SrcT* __restrict__ src, long ld_row, long n_cols, long t_count,
+               double* __restrict__ dst, long pitch, long t_dst0) {
+    __shared__ __attribute__((aligned(16))) double tile[64][66];
+    const int tid = threadIdx.x;
+    const long c0 = (long)blockIdx.x * 64, r0 = (long)blockIdx.y * 64;
+    const long n_pairs = (n_cols + 1) / 2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = i * 4 + (tid >> 6), c = tid & 63;
+        double v = 0.0;
+        if (r0 + r < t_count && c0 + c < n_cols) v = (double)src[(r0 + r) * ld_row + c0 + c];
+        tile[r][c] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = k * 256 + tid;
+        const int r = idx & 63, pp = idx >> 6;
+        const long pair = c0 / 2 + pp;
+        if (pair < n_pairs && r0 + r < t_count) {
+            const double2 v = *reinterpret_cast<const double2*>(&tile[r][2 * pp]);
+            *reinterpret_cast<double2*>(dst + (pair * pitch + t_dst0 + r0 + r) * 2) = v;
+        }
+    }
+}
+
+// The inverse, for callers that want a frame-major copy back (tests, diagnostics).
+__global__ void __launch_bounds__(256)
+    k_unlayout(const double* __restrict__ pm, long pitch, long n_cols, long t_count,
+               double* __restrict__ dst, long ld_row) {
+    const long n_pairs = (n_cols + 1) / 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs * t_count;
+         i += (long)gridDim.x * blockDim.x) {
+        const long pair = i / t_count, t = i - pair * t_count;
+        const double2 v = *reinterpret_cast<const double2*>(pm + (pair * pitch + t) * 2);
+        dst[t * ld_row + 2 * pair] = v.x;
+        if (2 * pair + 1 < n_cols) dst[t * ld_row + 2 * pair + 1] = v.y;
+    }
+}
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    unsigned long long z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Benchmark generator (include/ta_hip.h, ta_stage_synth): value of element idx is a function of
+// (seed, idx) only, integer arithmetic plus ONE float64 multiply, so NumPy reproduces it bit for
+// bit (oracle/synth.py): the sum of the eight 16-bit fields of two splitmix64 words, centred
+// and scaled to unit variance (Irwin-Hall, n = 8).
+__device__ __forceinline__ double synth_value(unsigned long long seed, unsigned long long idx) {
+    const unsigned long long a = splitmix64(seed + 2 * idx), b = splitmix64(seed + 2 * idx + 1);
+    long s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += (long)((a >> (16 * k)) & 0xFFFF) + (long)((b >> (16 * k)) & 0xFFFF);
+    return (double)(s - 262140) * 0x1.3988e1412ed76p-16;  // 1 / sqrt(8 (65536^2 - 1) / 12) = 1.8688123650118534e-05
+}
+
+// element (t, c) of the shard = synth(seed, t * n_cols_total + col_offset + c)
+__global__ void __launch_bounds__(256)
+    k_synth(double* __restrict__ pm, long pitch, long n_cols, long T, unsigned long long seed,
+            long col_offset, long n_cols_total) {
+    const long n_pairs = (n_cols + 1) / 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs * T;
+         i += (long)gridDim.x * blockDim.x) {
+        const long pair = i / T, t = i - pair * T;
+        const long c = 2 * pair;
+        double2 v;
+        v.x = synth_value(seed, (unsigned long long)(t * n_cols_total + col_offset + c));
+        v.y = c + 1 < n_cols ? synth_value(seed, (unsigned long long)(t * n_cols_total + col_offset + c + 1)) : 0.0;
+        *reinterpret_cast<double2*>(pm + (pair * pitch + t) * 2) = v;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_relayout(const void* src, bool src_f32, long ld_row, long n_cols, long t_count,
+                           double* dst, long pitch, long t_dst0, hipStream_t st) {
+    if (t_count <= 0 || n_cols <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n_cols + 63) / 64), (unsigned)((t_count + 63) / 64));
+    if (src_f32)
+        hipLaunchKernelGGL(k_relayout<float>, grid, dim3(256), 0, st, (const float*)src, ld_row, n_cols,
+                           t_count, dst, pitch, t_dst0);
+    else
+        hipLaunchKernelGGL(k_relayout<double>, grid, dim3(256), 0, st, (const double*)src, ld_row, n_cols,
+                           t_count, dst, pitch, t_dst0);
+    return hipGetLastError();
+}
+
+hipError_t launch_unlayout(const double* pm, long pitch, long n_cols, long t_count, double* dst,
+                           long ld_row, hipStream_t st) {
+    if (t_count <= 0 || n_cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unlayout, dim3(2048), dim3(256), 0, st, pm, pitch, n_cols, t_count, dst, ld_row);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(double* pm, long pitch, long n_cols, long T, unsigned long long seed,
+                        long col_offset, long n_cols_total, hipStream_t st) {
+    if (T <= 0 || n_cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_synth, dim3(4096), dim3(256), 0, st, pm, pitch, n_cols, T, seed, col_offset,
+                       n_cols_total);
+    return hipGetLastError();
+}
+
+}  // namespace ta

@@ -44,8 +44,9 @@ const std::vector<PlanEntry>& plans_pow2();
 const std::vector<PlanEntry>& plans_five();
 
 // direct.hip
+// vel / pos: pair-major slabs (layout.hip) of `pitch` rows per pair
 hipError_t launch_direct(int mode, bool f32, int L, const double* vel, const double* pos,
-                         const double* masses, long ld_row, int T, long n_atoms, int D,
+                         const double* masses, long pitch, int T, long n_atoms, int D,
                          double scale, double* by_particle, long ld_bp, double* ts_partial, int nwg,
                          int nt, size_t lds_bytes, void* stage_buf, int gnt, hipStream_t st);
 bool direct_chunk_supported(int L);       // lags per chunk compiled in (8, 10)
@@ -63,24 +64,43 @@ hipError_t launch_sum_partials_perm(const double* partial, int n_parts, int M, i
 bool fft_long_choose(long n_frames, int* M, int* Rout);  // smallest M' = Rout*M >= n_frames
 void fft_long_perm(int M, std::vector<int>& perm);       // position -> frequency of plan M's output
 size_t fft_long_acc_block(int M);                        // doubles per workgroup and pass
-hipError_t launch_fft_long_accum(int M, int nwg, hipStream_t st, const double* vel, long ld_row, int T,
+hipError_t launch_fft_long_accum(int M, int nwg, hipStream_t st, const double* vel, long ld_row, long pair_stride, int T,
                                  long n_cols, int Rout, const cd* tw2, const cd* twL, double* accg,
                                  cd* scratch /* [nwg][4][2*Rout][M] */);
 hipError_t launch_fft_long_finish(int M, int Rout, const double* partial, int n_parts, const int* perm,
                                   const cd* twL, int T, double* spec, double* lagsum, hipStream_t st);
 
 // helfand_fft.hip: optional FFT evaluation of the Helfand lag sums
+// pair-major slabs in, product slab P out in the same layout; Qpart [n_parts][T] zeroed by caller
 hipError_t launch_helfand_product(const double* vel, const double* pos, const double* masses,
-                                  long ld_row, long T, long n_cols, int D, double* P, double* Q,
-                                  hipStream_t st);
+                                  long pitch, long T, long n_cols, int D, double* P, double* Qpart,
+                                  int n_parts, hipStream_t st);
 hipError_t launch_helfand_combine(const double* Q, const double* s2n, double* C, int T, double factor,
                                   double* out, hipStream_t st);
 hipError_t launch_helfand_product_bp(const double* vel, const double* pos, const double* masses,
-                                     long ld_row, long T, long n_atoms, int D, double* P, double* Ca,
+                                     long pitch, long T, long n_atoms, int D, double* P, double* Ca,
                                      hipStream_t st);  // Ca: (T+1, n_atoms)
 hipError_t launch_helfand_combine_bp(double* Ca, long n_atoms, int T, double factor, double* bp,
                                      long ld_bp, hipStream_t st);
 
 hipError_t launch_widen_f32(const float* in, double* out, long n, hipStream_t st);
+
+// layout.hip: frame-major (n_frames, ld_row) float32/float64 rows -> pair-major slab rows
+hipError_t launch_relayout(const void* src, bool src_f32, long ld_row, long n_cols, long t_count,
+                           double* dst, long pitch, long t_dst0, hipStream_t st);
+hipError_t launch_unlayout(const double* pm, long pitch, long n_cols, long t_count, double* dst,
+                           long ld_row, hipStream_t st);
+hipError_t launch_synth(double* pm, long pitch, long n_cols, long T, unsigned long long seed,
+                        long col_offset, long n_cols_total, hipStream_t st);
+
+// wfft.hip: power-spectrum accumulation on pair-major slabs, M = R0 * 512
+bool wfft_choose(long n_frames, int* R0);
+size_t wfft_table_elems(int R0);
+void wfft_fill_table(int R0, cd* table);
+int wfft_max_wg_per_cu(int R0);
+hipError_t launch_wfft_accum(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
+                             long n_pairs, const cd* tw, double* accg /* [nwg][2M], natural order */);
+hipError_t launch_wfft_finish(int R0, const double* partial, int n_parts, const cd* tw, int T,
+                              double* spec /* [2M] */, double* lagsum, hipStream_t st);
 
 }  // namespace ta

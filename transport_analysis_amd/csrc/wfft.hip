@@ -1,0 +1,159 @@
+// wfft.hip — launchers of the pair-major power-spectrum kernels (wfft.hpp) and the kernels that
+// turn the summed spectrum into the lag-indexed sums (timeseries path of
+// VelocityAutocorr._conclude_fft, /root/reference/transport_analysis/velocityautocorr.py:208-215).
+#include "wfft.hpp"
+
+#include <vector>
+
+#include "ta_internal.hpp"
+
+namespace ta {
+namespace {
+
+constexpr int kR0s[] = {2, 4, 5, 8, 10, 16, 20};
+
+template <int R0>
+hipError_t launch_accum_r0(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
+                           const cd* tw, double* accg) {
+    using P = WPlan<R0>;
+    auto kern = k_wfft_accum<P, false, WF_TOUCH_DEFAULT, WF_INTER_DEFAULT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_pairs, tw, accg, nullptr);
+    return hipGetLastError();
+}
+
+template <int R0>
+int max_wg_r0() {
+    using P = WPlan<R0>;
+    auto kern = k_wfft_accum<P, false, WF_TOUCH_DEFAULT, WF_INTER_DEFAULT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)P::kLds);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, P::NT, P::kLds) != hipSuccess || n < 1) n = 1;
+    return n;
+}
+
+// spec[k] = sum over workgroups of their natural-order accumulator blocks, k < L2 = 2M
+__global__ void __launch_bounds__(256)
+    k_wf_sum(const double* __restrict__ partial, int n_parts, int L2, double* __restrict__ spec) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= L2) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int w = 0;
+    for (; w + 3 < n_parts; w += 4) {
+        s0 += partial[(long)w * L2 + k];
+        s1 += partial[(long)(w + 1) * L2 + k];
+        s2 += partial[(long)(w + 2) * L2 + k];
+        s3 += partial[(long)(w + 3) * L2 + k];
+    }
+    for (; w < n_parts; ++w) s0 += partial[(long)w * L2 + k];
+    spec[k] = (s0 + s1) + (s2 + s3);
+}
+
+// The lag sums are the real part of the inverse transform of the (real) summed spectrum:
+//   lagsum[n] = (1 / (2M (T - n))) * sum_{k < 2M} P[k] cos(pi k n / M),
+// cosine even in k about M: fold P[k] + P[2M - k] (k < M) first, then one workgroup per lag,
+// the table index (k n) mod 2M advanced by a fixed step per thread, fixed-order tree sum.
+__global__ void k_wf_fold(double* __restrict__ spec, int L2) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > 0 && k < L2 / 2) spec[k] += spec[L2 - k];
+}
+
+__global__ void __launch_bounds__(256)
+    k_wf_lags(const double* __restrict__ spec, const cd* __restrict__ tw2, int L2, int T,
+              double* __restrict__ lagsum) {
+    __shared__ double red[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    int idx = (int)(((long)tid * n) % L2);
+    const int step = (int)((256L * n) % L2);
+    double s = 0.0;
+    for (int k = tid; k <= L2 / 2; k += 256) {
+        s += spec[k] * tw2[idx].x;
+        idx += step;
+        if (idx >= L2) idx -= L2;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) red[tid] += red[tid + h];
+        __syncthreads();
+    }
+    if (tid == 0) lagsum[n] = red[0] / ((double)L2 * (double)(T - n));  // L2 (T-n) < 2^53: exact
+}
+
+}  // namespace
+
+bool wfft_choose(long n_frames, int* R0) {
+    for (int r : kR0s)
+        if ((long)r * 512 >= n_frames) {
+            *R0 = r;
+            return true;
+        }
+    return false;
+}
+
+size_t wfft_table_elems(int R0) { return 2 * (size_t)R0 * 512 + 14 * 64; }
+
+void wfft_fill_table(int R0, cd* a) {
+    const long M = (long)R0 * 512;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    for (long n = 0; n < 2 * M; ++n) {
+        if (n == 0) a[n] = cd{1.0, 0.0};
+        else if (n == M) a[n] = cd{-1.0, 0.0};
+        else if (2 * n == M) a[n] = cd{0.0, -1.0};
+        else if (2 * n == 3 * M) a[n] = cd{0.0, 1.0};
+        else {
+            const long double h = pi * (long double)n / (long double)M;
+            a[n] = cd{(double)cosl(h), (double)-sinl(h)};
+        }
+    }
+    // wave-local stage twiddles [14][64]: W_512^{lane a} (a = 1..7), W_64^{(lane & 7) b} (b = 1..7)
+    for (int r = 1; r < 8; ++r)
+        for (int l = 0; l < 64; ++l) {
+            a[2 * M + (r - 1) * 64 + l] = a[2 * R0 * l * r];
+            a[2 * M + (6 + r) * 64 + l] = a[16 * R0 * (l & 7) * r];
+        }
+}
+
+int wfft_max_wg_per_cu(int R0) {
+    switch (R0) {
+        case 2: return max_wg_r0<2>();
+        case 4: return max_wg_r0<4>();
+        case 5: return max_wg_r0<5>();
+        case 8: return max_wg_r0<8>();
+        case 10: return max_wg_r0<10>();
+        case 16: return max_wg_r0<16>();
+        case 20: return max_wg_r0<20>();
+    }
+    return 1;
+}
+
+hipError_t launch_wfft_accum(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
+                             long n_pairs, const cd* tw, double* accg) {
+    switch (R0) {
+        case 2: return launch_accum_r0<2>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 4: return launch_accum_r0<4>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 5: return launch_accum_r0<5>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 8: return launch_accum_r0<8>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 10: return launch_accum_r0<10>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 16: return launch_accum_r0<16>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 20: return launch_accum_r0<20>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_wfft_finish(int R0, const double* partial, int n_parts, const cd* tw, int T,
+                              double* spec, double* lagsum, hipStream_t st) {
+    const int L2 = 2 * R0 * 512;
+    hipLaunchKernelGGL(k_wf_sum, dim3((L2 + 255) / 256), dim3(256), 0, st, partial, n_parts, L2, spec);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wf_fold, dim3((L2 / 2 + 255) / 256), dim3(256), 0, st, spec, L2);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wf_lags, dim3(T), dim3(256), 0, st, spec, tw, L2, T, lagsum);
+    return hipGetLastError();
+}
+
+}  // namespace ta

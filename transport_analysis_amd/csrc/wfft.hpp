@@ -1,0 +1,388 @@
+// wfft.hpp — power-spectrum accumulation over column pairs, pair-major slabs (gfx950).
+//
+// Replaces the per-atom tidynamics.acf loop of VelocityAutocorr._conclude_fft
+// (/root/reference/transport_analysis/velocityautocorr.py:208-215) on the timeseries path.
+//
+// Input layout ("pair-major", produced by ta_stage_commit / ta_relayout_dev): column pair p
+// (columns 2p, 2p+1 of the (n_atoms*dim) columns) is one contiguous array of `pitch` rows of
+// 16 bytes, row t = (x[t], y[t]) = the complex sample z[t] = x[t] + i y[t].  A workgroup reads
+// a pair as 1 KiB-per-wave coalesced loads, every byte exactly once from HBM (the second pass
+// re-reads it while it is still in the XCD's L2).
+//
+// Transform.  The 2M-point transform of the zero-padded series (M = R0 * 512 >= n_frames) is
+// split into pass A (even bins, FFT_M(z)) and pass B (odd bins, FFT_M(z W_2M^t)); each pass is
+//   S1  one radix-R0 butterfly per thread (thread u: rows u + 512 j), output q scaled by
+//       W_2M^{u (2q + B)} and written to LDS as sub-series q (512 values, 8 KiB);
+//   S2  512-point transforms of the R0 sub-series, ONE WAVE each, radix 8 x 8 x 8 with the data
+//       of a lane in registers and two exchanges through the sub-series' own 8 KiB of LDS: no
+//       workgroup barrier inside S2, so the waves of a SIMD drift apart and the LDS stores of
+//       one hide under the arithmetic of the other; the last radix-8 stage adds |.|^2 into the
+//       wave's register accumulators (bin k = 2 (q + R0 s) + B, s = a + 8 b + 64 c).
+// Sub-transform i = B*R0 + q belongs to wave i % 8, so with R0 = 20 every wave owns exactly
+// five (pass, q) slots and 40 accumulators per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "fft_engine.hpp"
+
+namespace ta {
+
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for_range(F&& f) {
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        (f(std::integral_constant<int, LO + I>{}), ...);
+    }(std::make_integer_sequence<int, (HI > LO ? HI - LO : 0)>{});
+}
+
+typedef unsigned int wf_u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- first-stage DFTs that fft_engine.hpp does not have: prime-factor 2x5 and 4x5 -----------
+// n = (5 n1 + N1 n2) mod N, k1 = k mod N1, k2 = k mod 5: X[k] = sum W_N1^{n1 k1} W_5^{n2 k2} x[n]
+template <>
+struct Dft<10> {
+    static __device__ __forceinline__ void run(cd (&v)[10]) {
+        cd s[2][5];
+#pragma unroll
+        for (int j2 = 0; j2 < 5; ++j2) {
+            const cd a = v[(2 * j2) % 10], b = v[(5 + 2 * j2) % 10];
+            s[0][j2] = a + b;
+            s[1][j2] = a - b;
+        }
+        Dft<5>::run(s[0]);
+        Dft<5>::run(s[1]);
+#pragma unroll
+        for (int q = 0; q < 10; ++q) v[q] = s[q % 2][q % 5];
+    }
+};
+
+template <>
+struct Dft<20> {
+    static __device__ __forceinline__ void run(cd (&v)[20]) {
+        cd s[4][5];
+#pragma unroll
+        for (int j2 = 0; j2 < 5; ++j2) {
+            cd t[4] = {v[(4 * j2) % 20], v[(5 + 4 * j2) % 20], v[(10 + 4 * j2) % 20], v[(15 + 4 * j2) % 20]};
+            Dft<4>::run(t);
+#pragma unroll
+            for (int k1 = 0; k1 < 4; ++k1) s[k1][j2] = t[k1];
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) Dft<5>::run(s[k1]);
+#pragma unroll
+        for (int q = 0; q < 20; ++q) v[q] = s[q % 4][q % 5];
+    }
+};
+
+template <int R0_>
+struct WPlan {
+    static constexpr int R0 = R0_;
+    static constexpr int N1 = 512;          // sub-series length = one wave's transform
+    static constexpr int NT = 512;          // threads: one first-stage butterfly each
+    static constexpr int NW = NT / 64;
+    static constexpr int M = R0 * N1;
+    static constexpr int NS = (2 * R0 + NW - 1) / NW;  // (pass, q) slots per wave
+    static constexpr size_t kLds = (size_t)M * sizeof(cd);
+    // slots a pass can touch (over all waves): i = wave + NW*s in [B R0, (B+1) R0)
+    static constexpr int slot_lo(int B) { return B * R0 < NW ? 0 : (B * R0 - (NW - 1) + NW - 1) / NW; }
+    static constexpr int slot_hi(int B) { return ((B + 1) * R0 - 1) / NW; }
+    // waves that own no sub-series in the pass's conditional slot (a contiguous range)
+    static constexpr int idle_first(int B) {
+        for (int w = 0; w < NW; ++w)
+            if (!wave_has(B, w, slot_lo(B)) || !wave_has(B, w, slot_hi(B))) return w;
+        return 0;
+    }
+    static constexpr int idle_waves(int B) {
+        int n = 0;
+        for (int w = 0; w < NW; ++w)
+            if (!wave_has(B, w, slot_lo(B)) || !wave_has(B, w, slot_hi(B))) ++n;
+        return n == NW ? 0 : n;
+    }
+    static constexpr bool wave_has(int B, int w, int s) { return w + NW * s >= B * R0 && w + NW * s < (B + 1) * R0; }
+    // slot s belongs to pass B for every wave
+    static constexpr bool slot_always(int B, int s) { return NW * s >= B * R0 && NW - 1 + NW * s < (B + 1) * R0; }
+};
+
+__device__ __forceinline__ cd wf_load(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uni_off) {
+    // rows past the end of the series read as zero: the buffer's bounds check IS the padding.
+    // lane_off: per-lane byte offset (VGPR), uni_off: wave-uniform byte offset (SGPR operand)
+    const wf_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uni_off, 0);
+    return __builtin_bit_cast(cd, v);
+}
+
+// One wave's 512-point DIF transform of the sub-series at `reg` (natural order in, the lane's
+// eight outputs c = 0..7 are bins s = (lane>>3) + 8 (lane&7) + 64 c), |.|^2 added to acc.
+// The two exchanges stay inside the sub-series' own 8 KiB; their layouts are conflict-free for
+// ds_write_b128 / ds_read_b128 (verified exhaustively against the lane groups of the LDS):
+//   exchange 1: (a, l)      at a*64 + (l ^ 8 (a&1))
+//   exchange 2: (a, b, n0)  at (8a + b)*8 + (n0 ^ a ^ b)
+// A wave's own DS operations execute in order, so a read issued after a write of the same wave
+// sees it: no barrier, only the compiler has to keep the order (wave_barrier).
+struct WfSub {
+    int lane, hi, lo;
+    __device__ __forceinline__ explicit WfSub(int lane_) : lane(lane_) {
+        // LDS addresses depend on the lane only: re-formed per call (a few integer
+        // operations), otherwise they are hoisted out of the pair loop and spilled
+        asm volatile("" : "+v"(lane));
+        hi = lane >> 3;
+        lo = lane & 7;
+    }
+    __device__ __forceinline__ void read_a(const cd* __restrict__ reg, cd (&v)[8]) const {
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) v[n2] = reg[64 * n2 + lane];
+    }
+    __device__ __forceinline__ void stage_a(cd* __restrict__ reg, cd (&v)[8], const cd (&twa)[7]) const {
+        Dft<8>::run(v);
+#pragma unroll
+        for (int a = 1; a < 8; ++a) v[a] = cmul(v[a], twa[a - 1]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int a = 0; a < 8; ++a) reg[a * 64 + (lane ^ (8 * (a & 1)))] = v[a];
+        __builtin_amdgcn_wave_barrier();
+        const int base = hi * 64 + (lo ^ (8 * (hi & 1)));  // (8 n1 + lo) ^ 8 (hi&1), n1 = 0
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) v[n1] = reg[base ^ (8 * n1)];
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void stage_b(cd* __restrict__ reg, cd (&v)[8], const cd (&twb)[7]) const {
+        Dft<8>::run(v);
+#pragma unroll
+        for (int b = 1; b < 8; ++b) v[b] = cmul(v[b], twb[b - 1]);
+        __builtin_amdgcn_wave_barrier();
+        const int x = lo ^ hi;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) reg[(hi * 8 + b) * 8 + (x ^ b)] = v[b];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int n0 = 0; n0 < 8; ++n0) v[n0] = reg[lane * 8 + (n0 ^ x)];
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void stage_c(cd (&v)[8], double (&acc)[8]) const {
+        Dft<8>::run(v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] += norm2(v[c]);
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+__device__ __forceinline__ void wf_sub512(cd* __restrict__ reg, int lane, const cd (&twa)[7],
+                                          const cd (&twb)[7], double (&acc)[8]) {
+    const WfSub w(lane);
+    cd v[8];
+    w.read_a(reg, v);
+    w.stage_a(reg, v, twa);
+    w.stage_b(reg, v, twb);
+    w.stage_c(v, acc);
+}
+
+// Two sub-series interleaved: while one's butterflies run, the other's exchange (eight 16-byte
+// stores, eight loads, ~300 cycles of LDS round trip) is in flight.
+__device__ __forceinline__ void wf_sub512_x2(cd* __restrict__ reg0, cd* __restrict__ reg1, int lane,
+                                             const cd (&twa)[7], const cd (&twb)[7],
+                                             double (&acc0)[8], double (&acc1)[8]) {
+    const WfSub w(lane);
+    cd v0[8], v1[8];
+    w.read_a(reg0, v0);
+    w.read_a(reg1, v1);
+    __builtin_amdgcn_wave_barrier();
+    w.stage_a(reg0, v0, twa);
+    w.stage_a(reg1, v1, twa);
+    w.stage_b(reg0, v0, twb);
+    w.stage_b(reg1, v1, twb);
+    w.stage_c(v0, acc0);
+    w.stage_c(v1, acc1);
+}
+
+// pm: pair-major slab, pair p at pm + p*pitch*2 doubles; T rows are valid, the rest of the
+// transform length is zero padding.  accg: [gridDim.x][2M] float64, natural bin order.
+// tw2: W_2M^n, n < 2M, followed (at tw2 + 2M) by the wave-local stage twiddles [14][64]:
+// rows 0..6 = W_512^{lane (r+1)}, rows 7..13 = W_64^{(lane&7) (r-6)}.
+//
+// Software pipeline over (pair, pass): the 20 row loads of the NEXT pass are issued before the
+// barrier that ends the current one (they land while the slowest wave finishes), the 14 stage
+// twiddles of a wave are re-loaded from L2 after each first stage instead of being kept across
+// it: a first-stage butterfly's 80 data registers, the 80 accumulator registers and the 56
+// twiddle registers do not fit 256 together.
+// what the library instantiates (measured per build on the GPU: tools/wfft/wfft_test)
+#ifndef WF_TOUCH_DEFAULT
+#define WF_TOUCH_DEFAULT false
+#endif
+#ifndef WF_INTER_DEFAULT
+#define WF_INTER_DEFAULT false
+#endif
+template <class P, bool STAMP = false, bool TOUCH = WF_TOUCH_DEFAULT, bool INTER = WF_INTER_DEFAULT>
+__global__ void __launch_bounds__(P::NT)
+    k_wfft_accum(const double* __restrict__ pm, long pitch, int T, long n_pairs,
+                 const cd* __restrict__ tw2, double* __restrict__ accg,
+                 unsigned long long* __restrict__ stamps = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd* lds = reinterpret_cast<cd*>(smem_raw);
+    constexpr int R0 = P::R0, N1 = P::N1, NS = P::NS, NW = P::NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    double acc[NS][8];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[s][c] = 0.0;
+
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
+    if constexpr (STAMP) st_prev = __builtin_amdgcn_s_memtime();
+#define WF_STAMP(i)                                                   \
+    if constexpr (STAMP) {                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] += now_ - st_prev;                                  \
+        st_prev = now_;                                               \
+    }
+
+    auto rsrc_of = [&](long p) {
+        // a pair past the end gets an empty buffer: its loads return zeros and are never used
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + (p < n_pairs ? p : 0) * pitch * 2), 0,
+                                                 p < n_pairs ? T * 16 : 0, 0x00020000);
+    };
+    // x: the rows of a first-stage butterfly; g = W_2M^{2u}, g2 = g^2, h = W_2M^{u}: seeds of
+    // its output twiddles (per-thread constants, re-loaded with the rows rather than held
+    // across S2, where the registers are short)
+    // (table reads as buffer loads: lane offset in one VGPR, row offset in an SGPR: no per-load
+    // address registers for the compiler to hoist out of the loop and spill)
+    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cd*>(tw2), 0, (2 * P::M + 14 * 64) * 16, 0x00020000);
+    cd x[R0], g, g2, h;
+    auto issue_loads = [&](__amdgpu_buffer_rsrc_t rs) {
+#pragma unroll
+        for (int j = 0; j < R0; ++j) x[j] = wf_load(rs, (unsigned)tid * 16u, (unsigned)(N1 * j) * 16u);
+        g = wf_load(twr, (unsigned)tid * 32u, 0u);
+#ifndef WF_ONECHAIN
+        g2 = wf_load(twr, (unsigned)tid * 64u, 0u);
+#endif
+        h = wf_load(twr, (unsigned)tid * 16u, 0u);
+    };
+    issue_loads(rsrc_of(blockIdx.x));
+
+    for (long p = blockIdx.x; p < n_pairs; p += gridDim.x) {
+        auto one_pass = [&](auto BB) {
+            constexpr int B = decltype(BB)::value;
+            // ---- S1: radix-R0 butterfly u = tid over rows u + 512 j (loaded one pass ahead)
+            if constexpr (B == 1) {
+                // pass B twist, lane-uniform part: W_{2 R0}^j = tw2[j * 512]
+#pragma unroll
+                for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
+            }
+            Dft<R0>::run(x);
+            {
+                // output twiddles W_2M^{u(2q+B)} = h^B g^q: two chains (even / odd q) by g^2.
+                // The chain depends on per-thread constants only: laundered, or LICM hoists
+                // all 2 R0 powers out of the pair loop (and spills them).
+#ifdef WF_ONECHAIN
+                cd w = B ? h : g;
+                if constexpr (B == 1) x[0] = cmul(x[0], w);
+#pragma unroll
+                for (int q = 1; q < R0; ++q) {
+                    if (B == 1 || q > 1) w = cmul(w, g);
+                    x[q] = cmul(x[q], w);
+                }
+#else
+                const cd gg = g, gg2 = g2, hh = h;
+                cd te = B ? hh : cd{1.0, 0.0};
+                cd to = B ? cmul(hh, gg) : gg;
+                if constexpr (B == 1) x[0] = cmul(x[0], te);
+                if constexpr (R0 > 1) x[1] = cmul(x[1], to);
+#pragma unroll
+                for (int q = 2; q < R0; ++q) {
+                    if (q & 1) {
+                        to = cmul(to, gg2);
+                        x[q] = cmul(x[q], to);
+                    } else {
+                        te = cmul(te, gg2);
+                        x[q] = cmul(x[q], te);
+                    }
+                }
+#endif
+            }
+#pragma unroll
+            for (int q = 0; q < R0; ++q) lds[q * N1 + tid] = x[q];
+            // this wave's stage twiddles for S2 (dead during S1); the scheduling barriers keep
+            // the loads from being hoisted over the code before them (which would make their
+            // destination registers live there)
+            __builtin_amdgcn_sched_barrier(0);
+            cd twa[7], twb[7];
+#pragma unroll
+            for (int a = 0; a < 7; ++a) {
+                twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + a * 64) * 16u);
+                twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + (7 + a) * 64) * 16u);
+            }
+            WF_STAMP(2 * B)
+            __syncthreads();
+            // ---- S2: this wave's sub-series of the pass
+            static_for_range<P::slot_lo(B), P::slot_hi(B) + 1>([&](auto ss) {
+                constexpr int s = decltype(ss)::value;
+                constexpr int lo_s = P::slot_lo(B);
+                // slots that every wave owns in this pass are taken two at a time
+                constexpr int first_all = P::slot_always(B, lo_s) ? lo_s : lo_s + 1;
+                constexpr bool in_pair_run = P::slot_always(B, s) && s >= first_all;
+                constexpr int k = s - first_all;  // position inside the run of always-slots
+                constexpr bool pair_head = INTER && in_pair_run && k % 2 == 0 && s + 1 <= P::slot_hi(B) && P::slot_always(B, s + 1);
+                constexpr bool pair_tail = INTER && in_pair_run && k % 2 == 1 && P::slot_always(B, s - 1);
+                const int i = wave + NW * s;
+                if constexpr (pair_head) {
+                    wf_sub512_x2(lds + (i - B * R0) * N1, lds + (i + NW - B * R0) * N1, lane, twa, twb, acc[s],
+                                 acc[s + 1]);
+                } else if constexpr (!pair_tail) {
+                    if (P::slot_always(B, s) || (i >= B * R0 && i < (B + 1) * R0))
+                        wf_sub512(lds + (i - B * R0) * N1, lane, twa, twb, acc[s]);
+                }
+            });
+            // rows of the next pass: the same pair again (pass B), or the next pair
+            __builtin_amdgcn_sched_barrier(0);
+            const __amdgpu_buffer_rsrc_t nrs = rsrc_of(B == 0 ? p : p + gridDim.x);
+            if constexpr (B == 1 && TOUCH && P::idle_waves(B) > 0) {
+                // The waves that own one sub-series fewer in this pass are done early: they
+                // pull the next pair's lines into L2 (one dword per 128-byte line), so that the
+                // row loads issued below by the late waves do not wait for HBM.
+                constexpr int NI = P::idle_waves(B), KT = (P::M * 16 / 128 + NI * 64 - 1) / (NI * 64);
+                const int rank = wave - P::idle_first(B);
+                if (rank >= 0 && rank < NI) {
+                    unsigned t[KT];
+#pragma unroll
+                    for (int k = 0; k < KT; ++k)
+                        t[k] = __builtin_amdgcn_raw_buffer_load_b32(nrs, (unsigned)(rank * 64 + lane) * 128u,
+                                                                    (unsigned)(k * NI * 64) * 128u, 0);
+                    issue_loads(nrs);
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) asm volatile("" ::"v"(t[k]));
+                } else {
+                    issue_loads(nrs);
+                }
+            } else {
+                issue_loads(nrs);
+            }
+            WF_STAMP(2 * B + 1)
+            __syncthreads();
+        };
+        one_pass(std::integral_constant<int, 0>{});
+        one_pass(std::integral_constant<int, 1>{});
+    }
+    // accumulators -> natural bin order
+    double* out = accg + (long)blockIdx.x * 2 * P::M;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = wave + NW * s;
+        if (i < 2 * R0) {
+            const int B = i / R0, q = i - B * R0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int sb = (lane >> 3) + 8 * (lane & 7) + 64 * c;
+                out[2 * (q + R0 * sb) + B] = acc[s][c];
+            }
+        }
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && (wave == 0 || wave == 4))
+            for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + (wave / 4) * 4 + i] = st_acc[i];
+    }
+#undef WF_STAMP
+}
+
+}  // namespace ta
