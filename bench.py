@@ -1,62 +1,201 @@
 #!/usr/bin/env python3
 """Headline benchmark: FFT-VACF lag-points/s on synthetic random velocities.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--scaling weak|strong]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-one rank per GPU (RCCL).  Workload at every N: BASELINE.json configs[2]'s shape,
-10 000 frames x 100 000 atoms x 3 float64 PER GPU (weak scaling: the atom axis is
-the sharded unit, each rank owns a contiguous block of atoms), device-resident
-before the timed region.  A step = one pass of the hot path over the rank's
-block (ta_vacf_fft_dev: power-spectrum accumulation + one inverse transform)
-followed, for N > 1, by the single all-reduce of the (n_frames,) lag sums.
+one rank per GPU (RCCL).  Workload: BASELINE.json configs[2]'s tensor, 10 000 frames x
+100 000 atoms x 3 float64 -- per GPU with --scaling weak (the default: the atom axis is the
+sharded unit, per-GPU work fixed), in total with --scaling strong (configs[2] exactly: 100 000
+atoms over the N GPUs).  Every rank materialises ITS column block of ONE synthetic tensor with
+the library's stateless counter-based generator (ta_stage_synth; oracle/synth.py is its NumPy
+twin) straight into the library's device slab: the input is resident in HBM, in the layout the
+staging path leaves it in, before the timed region starts.  A step = one pass of the hot path
+over the rank's block (ta_vacf_fft_staged: power-spectrum accumulation + one inverse transform)
+followed, for N > 1, by the single all-reduce of the (n_frames,) lag sums (device tensor in,
+device tensor out).
 
-Prints ONE JSON line (rank 0).  `value` = total frames x atoms processed per
-second over all ranks; `roofline` prices the dominant kernel (k_fft_accum)
-against the 8 TB/s HBM roof with its algorithmic bytes (n_frames*n_atoms*dim*8 per
-launch) and its hipEvent-measured duration; `cpu_baseline` is the NumPy oracle
-(per-atom loop + numpy.fft, like the reference) on one host core over an atom
-subsample of the same workload.
+Prints ONE JSON line (rank 0).  `value` = total frames x atoms processed per second over all
+ranks (from the wall time of exactly K steps between two fences, max over ranks).
+`roofline` prices the dominant kernel (k_wfft_accum) against the 8 TB/s HBM roof with its
+algorithmic bytes (n_frames*n_atoms*dim*8 per launch) and the median of its K hipEvent-measured
+durations (recorded by the library on the launch stream, read AFTER the timed region), and
+carries the FP64 vector co-roof beside it.  `cpu_baseline` is the NumPy oracle (per-atom loop
++ numpy.fft, the reference's control flow) on one host core over an atom block of the same
+tensor.  `other_configs` (N = 1) are short driver-timed runs of the other BASELINE configs.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # vector FP64
+FP32_PEAK_TFLOPS = 157.3
+SEED = 20250824
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=10000)
-    ap.add_argument("--atoms", type=int, default=100000, help="atoms PER GPU")
+    ap.add_argument("--atoms", type=int, default=100000,
+                    help="atoms per GPU (--scaling weak) or in total (--scaling strong)")
     ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--mode", default="fft", choices=["fft", "direct", "helfand"])
     ap.add_argument("--by-particle", action="store_true",
-                    help="also materialise vacf_by_particle (secondary number)")
+                    help="also materialise vacf_by_particle (the reference's default output)")
     ap.add_argument("--float32", action="store_true",
                     help="direct / helfand modes: float32 products and block sums (configs[4])")
     ap.add_argument("--helfand-fft", action="store_true",
                     help="--mode helfand: the O(T log T) option (lag sums as S1 - 2 S2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--cpu-sample-atoms", type=int, default=0)
     return ap.parse_args()
 
 
-def cpu_baseline(args, T, D):
-    """NumPy oracle (reference control flow: per-atom loop, tidynamics-style FFT) on
-    ONE core over an atom subsample; linear in the atom count."""
-    import numpy as np
+def fft_flops(T, n_cols, M):
+    """Arithmetic of the lag-sum path per launch: per column pair two M-point
+    complex transforms (5 M log2 M each), the pass-B twist (6 M) and |.|^2 accumulation (3 * 2M)."""
+    import math
 
+    return ((n_cols + 1) // 2) * (2 * 5.0 * M * math.log2(M) + 12.0 * M)
+
+
+def so_sha16():
+    p = os.path.join(ROOT, "transport_analysis_amd", "libta_hip.so")
+    try:
+        return hashlib.sha256(open(p, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def recorded_traffic(key):
+    """HBM bytes per launch from the PMC passes of THIS build (tools/profile_bench.sh writes the
+    library's hash beside the numbers); None when the record is from another build."""
+    f = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(f))
+    except (OSError, ValueError):
+        return None
+    if rec.get("so_sha16") != so_sha16():
+        return None
+    e = rec.get("entries", {}).get(key)
+    return e["hbm_bytes_per_launch"] if e else None
+
+
+class Case:
+    """One workload on one rank: slabs staged on the device, `step()` = one pass of the path."""
+
+    def __init__(self, torch, ctx, dev, mode, T, A, D, col_offset, n_cols_total, seed, by_particle=False,
+                 float32=False, helfand_fft=False):
+        self.torch, self.ctx, self.mode, self.T, self.A, self.D = torch, ctx, mode, T, A, D
+        self.helfand_fft = helfand_fft
+        ctx.set_option("direct_f32", 1 if float32 else 0)
+        ctx.set_option("helfand_fft", 1 if helfand_fft else 0)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        ctx.stage_alloc_device(T, A, D, n_slabs=2 if mode == "helfand" else 1)
+        ctx.stage_synth(0, seed, col_offset, n_cols_total, self.stream)
+        self.masses = None
+        if mode == "helfand":
+            # x[t] = x0 + 0.002 cumsum(v), masses cycled over O, H, H
+            fm = torch.empty((T, A * D), dtype=torch.float64, device=dev)
+            ctx.stage_read_dev(0, fm.data_ptr(), A * D, self.stream)
+            fm = 30.0 + 0.002 * torch.cumsum(fm, dim=0)
+            ctx.stage_commit_dev(1, fm.data_ptr(), A * D, 0, T, stream=self.stream)
+            torch.cuda.synchronize()
+            del fm
+            self.masses = torch.tensor([15.999, 1.008, 1.008], dtype=torch.float64, device=dev).repeat(
+                (A + 2) // 3)[:A].contiguous()
+        self.lagsum = torch.zeros(T, dtype=torch.float64, device=dev)
+        self.bp = torch.empty((T, A), dtype=torch.float64, device=dev) if by_particle else None
+
+    def step(self):
+        d_bp = self.bp.data_ptr() if self.bp is not None else 0
+        if self.mode == "fft":
+            self.ctx.vacf_fft_staged(self.lagsum.data_ptr(), d_bp, self.A, self.stream)
+        elif self.mode == "direct":
+            self.ctx.vacf_direct_staged(self.lagsum.data_ptr(), d_bp, self.A, self.stream)
+        else:
+            self.ctx.helfand_msd_staged(self.masses.data_ptr(), 1.0, self.lagsum.data_ptr(), d_bp, self.A,
+                                        self.stream)
+
+    def kernel_name(self):
+        if self.mode != "fft" and not (self.mode == "helfand" and self.helfand_fft):
+            return "k_direct"
+        if self.bp is not None:
+            return "k_fft_accum (by-particle mode)"
+        return "k_wfft_accum" if 512 < self.T <= 10240 else ("k_fft_accum" if self.T <= 512 else "k_fft_accum_long")
+
+
+def timed(torch, dist, world, steps, warmup, fn):
+    """W warm-ups, then exactly K steps between two fences; wall seconds (max over ranks)."""
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        fn()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
+
+
+def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
+    T, A, D = case.T, case.A, case.D
+    from transport_analysis_amd import _lib
+
+    bytes_algo = T * A * D * 8 * (2 if case.mode == "helfand" else 1)
+    if case.bp is not None:
+        bytes_algo += T * A * 8  # the by-particle array written once
+    gbps = bytes_algo / (kernel_ms * 1e-3) / 1e9
+    if case.mode == "fft" or helfand_fft:
+        M = _lib.fft_plan_info(T)["M"]
+        fl = fft_flops(T, A * D, M)
+        tf = fl / (kernel_ms * 1e-3) / 1e12
+        name = case.kernel_name()
+        return {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": gbps / HBM_PEAK_GBPS, "traffic": None, "kernel": name, "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": bytes_algo,
+                "valu": {"achieved_tflops": tf, "peak": FP64_PEAK_TFLOPS, "frac": tf / FP64_PEAK_TFLOPS,
+                         "algorithmic_flops_per_launch": fl}}
+    # direct correlators: bound by the vector FP issue rate:
+    # windowed VACF 2*D*A*T(T+1)/2 flop, Helfand 3*D*A*T(T-1)/2; HBM is touched once
+    fl = (2.0 * D * A * T * (T + 1) / 2) if case.mode == "direct" else (3.0 * D * A * T * (T - 1) / 2)
+    peak = FP32_PEAK_TFLOPS if float32 else FP64_PEAK_TFLOPS
+    tf = fl / (kernel_ms * 1e-3) / 1e12
+    return {"bound": "valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+            "traffic": None, "kernel": "k_direct", "kernel_ms": kernel_ms,
+            "algorithmic_flops_per_launch": fl, "hbm_GBps_for_reference": gbps}
+
+
+def cpu_baseline(args, T, D, n_cols_total):
+    """NumPy oracle (reference control flow: per-atom loop, tidynamics-style FFT) on ONE core
+    over the first atoms of the SAME synthetic tensor; linear in the atom count."""
     from oracle import numpy_oracle as orc
+    from oracle import synth
 
     all_cpus = None
     try:
@@ -64,31 +203,16 @@ def cpu_baseline(args, T, D):
         os.sched_setaffinity(0, {sorted(all_cpus)[0]})
     except Exception:
         pass
-    if args.mode == "fft":
-        a = args.cpu_sample_atoms or max(8, int(8.0e7 // T))  # ~10-15 s of CPU work
-        v = orc.synthetic_velocities(T, a, D, seed=20250824 + 3)
-        t0 = time.perf_counter()
-        orc.vacf_fft(v)
-        dt = time.perf_counter() - t0
-        what = f"oracle.numpy_oracle.vacf_fft on {T} frames x {a} atoms x {D} (atom subsample of the workload)"
-    elif args.mode == "direct":
-        a = args.cpu_sample_atoms or max(2, int(2.0e9 // (T * T)))
-        v = orc.synthetic_velocities(T, a, D, seed=20250824 + 4)
-        t0 = time.perf_counter()
-        orc.vacf_windowed(v)
-        dt = time.perf_counter() - t0
-        what = f"oracle.numpy_oracle.vacf_windowed on {T} x {a} x {D} (atom subsample)"
-    else:
-        a = args.cpu_sample_atoms or max(2, int(1.0e9 // (T * T)))
-        v, x, m, vol = orc.synthetic_helfand(T, a, D, seed=20250824 + 5)
-        t0 = time.perf_counter()
-        orc.helfand(v, x, m, vol)
-        dt = time.perf_counter() - t0
-        what = f"oracle.numpy_oracle.helfand on {T} x {a} x {D} (atom subsample)"
-    out = {"value": T * a / dt, "unit": "lag-points/s", "cores": 1, "kind": "port",
-           "sample": what, "seconds": round(dt, 2)}
-    # second line: the plain-C oracle (OpenMP, own radix-2 FFT / slab loops) on every host core
-    # over the same subsample -- the "best CPU" figure next to the reference-like NumPy one
+    a = args.cpu_sample_atoms or max(8, int(8.0e7 // T))  # ~10-15 s of CPU work
+    v = synth.synthetic_block(SEED + 3, T, n_cols_total, 0, a * D).reshape(T, a, D)
+    t0 = time.perf_counter()
+    orc.vacf_fft(v)
+    dt = time.perf_counter() - t0
+    what = (f"oracle.numpy_oracle.vacf_fft on {T} frames x the first {a} atoms x {D} of the benchmark tensor "
+            f"(oracle.synth, seed {SEED + 3})")
+    out = {"value": T * a / dt, "unit": "lag-points/s", "cores": 1, "kind": "port", "sample": what,
+           "seconds": round(dt, 2)}
+    # second line: the plain-C oracle (OpenMP, own radix-2 FFT) on every host core over the same block
     try:
         from oracle import c_oracle
 
@@ -96,22 +220,45 @@ def cpu_baseline(args, T, D):
             os.sched_setaffinity(0, all_cpus)
         n = len(all_cpus) if all_cpus else (os.cpu_count() or 1)
         t0 = time.perf_counter()
-        if args.mode == "fft":
-            c_oracle.vacf_fft_lagsum(v, n_threads=n)
-        elif args.mode == "direct":
-            c_oracle.vacf_windowed(v, n_threads=n)
-        else:
-            c_oracle.helfand(v, x, m, vol, n_threads=n)
+        c_oracle.vacf_fft_lagsum(v, n_threads=n)
         dtc = time.perf_counter() - t0
-        out["all_cores"] = {"value": T * a / dtc, "unit": "lag-points/s", "cores": n,
-                            "kind": "port", "impl": "oracle/c (OpenMP)", "seconds": round(dtc, 2)}
+        out["all_cores"] = {"value": T * a / dtc, "unit": "lag-points/s", "cores": n, "kind": "port",
+                            "impl": "oracle/c (OpenMP)", "seconds": round(dtc, 2)}
     except Exception as e:  # the C oracle is optional test infrastructure
         out["all_cores"] = {"error": str(e)[:200]}
     return out
 
 
+def host_path(torch, _lib, dev_index, T, D):
+    """PCIe-inclusive rate of the drop-in path: float32 pinned slab -> ta_stage_commit (H2D in
+    64 MiB pieces + on-device transposition) -> ta_vacf_fft, on an atom block.  Never `value`."""
+    import numpy as np
+
+    A = 20000
+    ctx = _lib.Context(dev_index)
+    try:
+        (slab,) = ctx.stage_alloc(T, A, D, n_slabs=1, dtype=np.float32)
+        rng = np.random.default_rng(5)
+        blk = rng.standard_normal((256, A, D), dtype=np.float32)
+        for t in range(0, T, 256):
+            slab[t:t + 256] = blk[: min(256, T - t)]
+        out = {}
+        for rep in range(2):
+            t0 = time.perf_counter()
+            ctx.stage_commit(0, T)
+            ts, _ = ctx.vacf_fft(by_particle=False)
+            dt = time.perf_counter() - t0
+        out = {"value": T * A / dt, "unit": "lag-points/s", "seconds": dt,
+               "what": f"float32 pinned slab {T}x{A}x{D} -> commit (PCIe + transpose) -> ta_vacf_fft, second of two runs",
+               "pcie_GBps": T * A * D * 4 / dt / 1e9}
+        return out
+    finally:
+        ctx.close()
+
+
 def main():
     args = parse()
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -131,95 +278,72 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from transport_analysis_amd import _lib
-    from transport_analysis_amd.dist import reduce_lagsum
+    from transport_analysis_amd.dist import atom_shard, reduce_lagsum
 
-    T, A, D = args.frames, args.atoms, args.dim
+    T, D = args.frames, args.dim
+    if args.float32 and args.mode == "fft":
+        raise SystemExit("--float32 applies to --mode direct / helfand")
+    if args.helfand_fft and (args.mode != "helfand" or args.float32):
+        raise SystemExit("--helfand-fft applies to --mode helfand without --float32")
+    if args.scaling == "weak":
+        a_total = args.atoms * world
+        lo, hi = args.atoms * rank, args.atoms * (rank + 1)
+    else:
+        a_total = args.atoms
+        lo, hi = atom_shard(a_total, rank, world)
+    A = hi - lo
+    seed = SEED + {"fft": 3, "direct": 4, "helfand": 5}[args.mode]
     ctx = _lib.Context(local_rank)
-    if args.float32:
-        if args.mode == "fft":
-            raise SystemExit("--float32 applies to --mode direct / helfand")
-        ctx.set_option("direct_f32", 1)
-    if args.helfand_fft:
-        if args.mode != "helfand" or args.float32:
-            raise SystemExit("--helfand-fft applies to --mode helfand without --float32")
-        ctx.set_option("helfand_fft", 1)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(20250824 + 3 + 1000 * rank)
-    vel = torch.randn((T, A, D), dtype=torch.float64, device=dev, generator=gen)
-    pos = masses = None
-    if args.mode == "helfand":
-        pos = 30.0 + 0.002 * torch.cumsum(vel, dim=0)
-        masses = torch.tensor([15.999, 1.008, 1.008], dtype=torch.float64, device=dev).repeat(
-            (A + 2) // 3)[:A].contiguous()
-    lagsum = torch.zeros(T, dtype=torch.float64, device=dev)
-    bp = torch.empty((T, A), dtype=torch.float64, device=dev) if args.by_particle else None
-    stream = torch.cuda.current_stream().cuda_stream
-    a_total = A * world
+    case = Case(torch, ctx, dev, args.mode, T, A, D, lo * D, a_total * D, seed, args.by_particle,
+                args.float32, args.helfand_fft)
+
+    result = {}
 
     def step():
-        d_bp = bp.data_ptr() if bp is not None else 0
-        if args.mode == "fft":
-            ctx.vacf_fft_dev(vel.data_ptr(), T, A, D, A * D, lagsum.data_ptr(), d_bp, A, stream)
-        elif args.mode == "direct":
-            ctx.vacf_direct_dev(vel.data_ptr(), T, A, D, A * D, lagsum.data_ptr(), d_bp, A, stream)
-        else:
-            ctx.helfand_msd_dev(vel.data_ptr(), pos.data_ptr(), masses.data_ptr(), T, A, D, A * D,
-                                1.0, lagsum.data_ptr(), d_bp, A, stream)
-        return reduce_lagsum(lagsum, a_total)
+        case.step()
+        result["ts"] = reduce_lagsum(case.lagsum, a_total)  # device tensor in and out
 
-    def fence():
-        if world > 1:
-            dist.barrier()
+    elapsed = timed(torch, dist, world, args.steps, args.warmup, step)
+    hist = ctx.timing_history(min(args.steps, 64))
+    kernel_ms = statistics.median(m for _, m in hist)
+    total_ms = statistics.median(t for t, _ in hist)
+
+    # validity of the timed result (N = 1): the staged tensor IS the NumPy generator's (bit for
+    # bit, on a block), and a few lags agree with plain torch reductions over the whole tensor
+    check = {}
+    if world == 1 and not args.no_check and args.mode in ("fft", "direct"):
+        from oracle import synth
+
+        fm = torch.empty((T, A * D), dtype=torch.float64, device=dev)
+        ctx.stage_read_dev(0, fm.data_ptr(), A * D, case.stream)
         torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        ts = step()
-    fence()
-    kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts = step()
-        # hipEvent pair recorded by the library around the dominant kernel on this stream
-        # (reading it waits for that launch only; it is inside the timed region on purpose)
-        kernel_ms.append(ctx.last_timing()[1])
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # cheap validity check of the timed result: a few lags recomputed with torch ops
-    errs = []
-    if args.mode in ("fft", "direct"):
-        loc = lagsum if world == 1 else None
-        if loc is None:  # lagsum was all-reduced in place: recompute the local part
-            loc = torch.zeros(T, dtype=torch.float64, device=dev)
-            ctx.vacf_fft_dev(vel.data_ptr(), T, A, D, A * D, loc.data_ptr(), 0, A, stream)
-        scale = float((vel * vel).sum().item()) / T
+        blk = synth.synthetic_block(seed, min(T, 64), a_total * D, lo * D, lo * D + min(A * D, 96))
+        check["generator_bit_exact_vs_numpy"] = bool(
+            np.array_equal(fm[: blk.shape[0], : blk.shape[1]].cpu().numpy(), blk))
+        scale = float((fm * fm).sum().item()) / T
+        errs = []
         for k in (0, 1, T // 2, T - 1):
-            ref = float((vel[: T - k] * vel[k:]).sum().item()) / (T - k)
-            errs.append(abs(float(loc[k].item()) - ref) / scale)
-    torch.cuda.synchronize()
+            ref = float((fm[: T - k] * fm[k:]).sum().item()) / (T - k)
+            errs.append(abs(float(case.lagsum[k].item()) - ref) / scale)
+        check["max_scale_rel_err_vs_torch_lags"] = max(errs)
+        del fm
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
     ms_per_step = elapsed / args.steps * 1e3
-    main_ms = sum(kernel_ms) / len(kernel_ms)
-    bytes_algo = T * A * D * 8 * (2 if args.mode == "helfand" else 1)
-    achieved = bytes_algo / (main_ms * 1e-3) / 1e9
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            rec = json.load(open(tfile))
-            key = f"{args.mode}_{T}x{A}x{D}"
-            if key in rec and not args.by_particle:
-                traffic = rec[key]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    roof = roofline_of(case, kernel_ms, args.helfand_fft, args.float32)
+    key = f"{args.mode}_{T}x{A}x{D}" + ("_bp" if args.by_particle else "")
+    roof["traffic"] = recorded_traffic(key)
+    workload = ({"fft": "FFT VACF", "direct": "windowed (direct) VACF",
+                 "helfand": "Helfand MSD (FFT option)" if args.helfand_fft else "Helfand MSD"}[args.mode]
+                + (" with the by-particle array" if args.by_particle else " timeseries")
+                + (f", {T} frames x {args.atoms} atoms x {D} float64 per GPU" if args.scaling == "weak"
+                   else f", {T} frames x {a_total} atoms x {D} float64 in total, atoms sharded over {world} GPU(s)")
+                + (" (BASELINE configs[2] tensor on one GPU)" if (T, a_total, D, args.mode, world) == (10000, 100000, 3, "fft", 1)
+                   else " (BASELINE configs[2])" if (T, a_total, D, args.mode, args.scaling) == (10000, 100000, 3, "fft", "strong")
+                   else ""))
     out = {
         "metric": "VACF lag-points/sec (n_frames x n_atoms / s)",
         "value": T * a_total / (elapsed / args.steps),
@@ -229,44 +353,66 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32 (f64 inputs and accumulators)" if args.float32 else "f64",
         "data": "synthetic",
         "config": {
-            "workload": {"fft": "FFT VACF", "direct": "windowed (direct) VACF",
-                         "helfand": "Helfand MSD (FFT option)" if args.helfand_fft else "Helfand MSD"}[args.mode]
-                        + (" with the by-particle array" if args.by_particle else " timeseries")
-                        + f", {T} frames x {A} atoms x {D} float64 per GPU"
-                        + (" (BASELINE configs[2] shape)" if (T, A, D, args.mode) == (10000, 100000, 3, "fft") else ""),
-            "n_frames": T, "n_atoms_per_gpu": A, "dim": D, "mode": args.mode,
-            "by_particle": bool(args.by_particle), "sharding": f"atoms x{world}",
-            "fft_plan": _lib.fft_plan_info(T),
+            "workload": workload, "n_frames": T, "n_atoms_total": a_total, "n_atoms_this_rank": A, "dim": D,
+            "mode": args.mode, "by_particle": bool(args.by_particle), "sharding": f"atoms x{world}",
+            "fft_plan": _lib.fft_plan_info(T), "input": "library device slab (pair-major), ta_stage_synth",
+            "library_sha16": so_sha16(),
         },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-            "kernel": ("k_fft_accum" if T <= 10240 or args.by_particle else "k_fft_accum_long")
-                      if args.mode == "fft" else "k_direct",
-            "kernel_ms": main_ms, "algorithmic_bytes_per_launch": bytes_algo,
-        },
-        "check": {"max_scale_rel_err_vs_torch_lags": max(errs) if errs else None},
+        "roofline": roof,
+        "device_ms": {"whole_call_median": total_ms, "dominant_kernel_median": kernel_ms},
+        "check": check,
     }
-    if args.mode != "fft" and not args.helfand_fft:
-        # the direct correlators are bound by the vector FP issue rate:
-        # windowed VACF 2*D*A*T(T+1)/2 flop, Helfand 3*D*A*T(T-1)/2; HBM is touched once
-        flops = (2.0 * D * A * T * (T + 1) / 2) if args.mode == "direct" else (3.0 * D * A * T * (T - 1) / 2)
-        peak = 157.3 if args.float32 else 78.6
-        tf = flops / (main_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
-                           "frac": tf / peak, "traffic": None, "kernel": "k_direct", "kernel_ms": main_ms,
-                           "algorithmic_flops_per_launch": flops,
-                           "hbm_GBps_for_reference": achieved}
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, T, D)
+    if world == 1 and not args.no_other_configs and args.mode == "fft" and not args.by_particle:
+        out["other_configs"] = other_configs(torch, dist, _lib, ctx, dev)
+    if world == 1 and not args.no_host_path and args.mode == "fft":
+        try:
+            del case
+            ctx.stage_free()
+            ctx.trim()
+            out["host_path"] = host_path(torch, _lib, local_rank, T, D)
+        except Exception as e:
+            out["host_path"] = {"error": str(e)[:200]}
+    if world == 1 and not args.no_cpu_baseline and args.mode == "fft":
+        out["cpu_baseline"] = cpu_baseline(args, T, D, a_total * D)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def other_configs(torch, dist, _lib, ctx, dev):
+    """Short runs of the other BASELINE configs on this GPU (rank 0, N = 1): configs[1], configs[2]
+    with the by-particle array (the reference's default output), configs[3], and one GPU's
+    share of configs[4] (20000 frames x 25000 atoms, float32 path)."""
+    res = []
+    specs = [
+        ("configs[1]: FFT VACF timeseries 1000 x 10000 x 3", "fft", 1000, 10000, False, False, 10, 3),
+        ("configs[2] shape with vacf_by_particle: FFT VACF 10000 x 100000 x 3", "fft", 10000, 100000, True, False, 3, 1),
+        ("configs[3]: windowed (direct) VACF 5000 x 50000 x 3", "direct", 5000, 50000, False, False, 3, 1),
+        ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float32 path", "helfand", 20000, 25000, False, True, 2, 1),
+    ]
+    for name, mode, T, A, byp, f32, steps, warm in specs:
+        try:
+            ctx.stage_free()
+            ctx.trim()
+            torch.cuda.empty_cache()
+            seed = SEED + {"fft": 3, "direct": 4, "helfand": 5}[mode]
+            c = Case(torch, ctx, dev, mode, T, A, 3, 0, A * 3, seed, byp, f32, False)
+            el = timed(torch, dist, 1, steps, warm, c.step)
+            hist = ctx.timing_history(steps)
+            kms = statistics.median(m for _, m in hist)
+            r = roofline_of(c, kms, False, f32)
+            res.append({"workload": name, "ms_per_step": el / steps * 1e3, "steps": steps,
+                        "value": T * A / (el / steps), "unit": "lag-points/s", "roofline": r})
+            del c
+        except Exception as e:
+            res.append({"workload": name, "error": str(e)[:300]})
+    ctx.set_option("direct_f32", 0)
+    return res
 
 
 if __name__ == "__main__":

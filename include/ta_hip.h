@@ -163,6 +163,10 @@ int ta_helfand_msd_staged(ta_ctx *ctx, const double *d_masses, double scale, dou
  * kernel (FFT accumulate pass / direct correlator).  Blocks until the events
  * have completed.                                                            */
 int ta_last_timing(ta_ctx *ctx, float *total_ms, float *main_kernel_ms);
+/* the same for the last min(max_n, 64, calls so far) compute calls on this context, oldest
+ * first (a caller times K calls back to back and reads the K durations afterwards);
+ * *n_out = number of entries written.  Blocks until those calls have completed.      */
+int ta_timing_history(ta_ctx *ctx, int max_n, float *total_ms, float *main_kernel_ms, int *n_out);
 /* FFT length bookkeeping for a given n_frames: *m_out = padded half-length M
  * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1; the lag-sum
  * path: M = 2^a or 5*2^a up to 512 frames, R0*512 with R0 in {2,4,5,8,10,16,20} above).  Up to

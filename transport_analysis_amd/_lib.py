@@ -25,7 +25,7 @@ EXPORTS = (
     "ta_vacf_fft", "ta_vacf_direct", "ta_helfand_msd",
     "ta_vacf_fft_dev", "ta_vacf_direct_dev", "ta_helfand_msd_dev",
     "ta_vacf_fft_staged", "ta_vacf_direct_staged", "ta_helfand_msd_staged",
-    "ta_last_timing", "ta_fft_plan_info", "ta_set_option",
+    "ta_last_timing", "ta_timing_history", "ta_fft_plan_info", "ta_set_option",
 )
 
 
@@ -111,6 +111,8 @@ def lib():
     L.ta_vacf_direct_dev.argtypes = [vp, vp, i64, i64, ci, i64, vp, vp, i64, vp]
     L.ta_helfand_msd_dev.argtypes = [vp, vp, vp, vp, i64, i64, ci, i64, dbl, vp, vp, i64, vp]
     L.ta_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    L.ta_timing_history.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                    ctypes.POINTER(ci)]
     L.ta_fft_plan_info.argtypes = [i64, ctypes.POINTER(i64), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.ta_set_option.argtypes = [vp, ctypes.c_char_p, i64]
     for name in EXPORTS:
@@ -263,6 +265,14 @@ class Context:
     def helfand_msd_staged(self, d_masses, scale, d_lagsum, d_bp=0, ld_bp=0, stream=0):
         self._check(lib().ta_helfand_msd_staged(self._h, d_masses, scale, d_lagsum, d_bp or None, ld_bp,
                                                 stream or None))
+
+    def timing_history(self, max_n=64):
+        """[(total_ms, main_kernel_ms)] of the last compute calls, oldest first."""
+        n = ctypes.c_int()
+        t = (ctypes.c_float * max_n)()
+        m = (ctypes.c_float * max_n)()
+        self._check(lib().ta_timing_history(self._h, max_n, t, m, ctypes.byref(n)))
+        return [(t[i], m[i]) for i in range(n.value)]
 
     def last_timing(self):
         t, m = ctypes.c_float(), ctypes.c_float()

@@ -51,8 +51,13 @@ struct ta_ctx {
     int st_D = 0, st_dtype = TA_F64, st_nslabs = 0;
     std::vector<void*> h_slabs;
     std::vector<double*> d_slabs;
-    // timing
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // timing: a ring of event quadruples, one per compute call (start, main kernel start,
+    // main kernel end, end), so a caller can time K calls back to back and read all K
+    // durations afterwards (ta_timing_history) instead of synchronising inside its loop
+    static constexpr int kRing = 64;
+    hipEvent_t ring[kRing][4] = {};
+    hipEvent_t* ev = ring[0];
+    long n_calls = 0;  // compute calls completed (their events recorded)
     bool timing_valid = false;
     // options
     int64_t opt_fft_nwg = 0;
@@ -446,7 +451,10 @@ int compute_pm(ta_ctx* ctx, int which, const double* pm_vel, const double* pm_po
                int64_t ld_bp, hipStream_t st, bool record_start) {
     int rc;
     ctx->timing_valid = false;
-    if (record_start) TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+    if (record_start) {
+        ctx->ev = ctx->ring[ctx->n_calls % ta_ctx::kRing];
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+    }
     // paths without a dominant kernel of their own re-record ev[1]/ev[2] inside
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
@@ -457,6 +465,7 @@ int compute_pm(ta_ctx* ctx, int which, const double* pm_vel, const double* pm_po
     if (rc) return rc;
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     ctx->timing_valid = true;
+    ++ctx->n_calls;
     return TA_OK;
 }
 
@@ -481,6 +490,7 @@ int dev_entry(ta_ctx* ctx, int which, const double* d_vel, const double* d_pos, 
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the legacy default stream, as for any HIP call
     ctx->timing_valid = false;
+    ctx->ev = ctx->ring[ctx->n_calls % ta_ctx::kRing];
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     const double *pv = nullptr, *px = nullptr;
     if ((rc = relayout_input(ctx, 0, d_vel, T, A * D, ld_row, st, &pv))) return rc;
@@ -532,8 +542,9 @@ int ta_ctx_create(int device, ta_ctx** out) {
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    for (auto& ev : ctx->ev)
-        if (e == hipSuccess) e = hipEventCreate(&ev);
+    for (auto& q : ctx->ring)
+        for (auto& ev : q)
+            if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e != hipSuccess) {
         const std::string msg = std::string("context setup: ") + hipGetErrorString(e);
         ta_ctx_destroy(ctx);  // frees whatever was created
@@ -574,8 +585,9 @@ int ta_ctx_destroy(ta_ctx* ctx) {
                       &ctx->masses, &ctx->bounce, &ctx->stage_buf, &ctx->long_scratch, &ctx->helf_p,
                       &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1]})
         if (b->p) hipFree(b->p);
-    for (auto& ev : ctx->ev)
-        if (ev) hipEventDestroy(ev);
+    for (auto& q : ctx->ring)
+        for (auto& ev : q)
+            if (ev) hipEventDestroy(ev);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return TA_OK;
@@ -796,6 +808,23 @@ int ta_last_timing(ta_ctx* ctx, float* total_ms, float* main_kernel_ms) {
     TA_HIP_TRY(ctx, hipEventElapsedTime(&m, ctx->ev[1], ctx->ev[2]));
     if (total_ms) *total_ms = t;
     if (main_kernel_ms) *main_kernel_ms = m;
+    return TA_OK;
+}
+
+int ta_timing_history(ta_ctx* ctx, int max_n, float* total_ms, float* main_kernel_ms, int* n_out) {
+    if (!ctx || !n_out) return fail(ctx, TA_E_INVALID, "null argument");
+    const long have = std::min<long>(ctx->n_calls, ta_ctx::kRing);
+    const int n = (int)std::min<long>(have, std::max(0, max_n));
+    for (int i = 0; i < n; ++i) {  // chronological: oldest of the last n first
+        hipEvent_t* q = ctx->ring[(ctx->n_calls - n + i) % ta_ctx::kRing];
+        TA_HIP_TRY(ctx, hipEventSynchronize(q[3]));
+        float t = 0.f, m = 0.f;
+        TA_HIP_TRY(ctx, hipEventElapsedTime(&t, q[0], q[3]));
+        TA_HIP_TRY(ctx, hipEventElapsedTime(&m, q[1], q[2]));
+        if (total_ms) total_ms[i] = t;
+        if (main_kernel_ms) main_kernel_ms[i] = m;
+    }
+    *n_out = n;
     return TA_OK;
 }
 
