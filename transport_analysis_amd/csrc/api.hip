@@ -20,7 +20,8 @@ namespace {
 thread_local std::string g_tls_error;
 
 struct Tables {
-    cd* tw2 = nullptr;  // W_{2M}^n = exp(-i pi n / M), n < 2M
+    cd* tw2 = nullptr;    // W_{2M}^n = exp(-i pi n / M), n < 2M
+    int* perm = nullptr;  // the plan's output position -> frequency (made on first use)
 };
 
 struct LongTables {     // fft_long.hip
@@ -337,8 +338,38 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         TA_HIP_TRY(ctx, launch_wfft_accum(R0, (int)nwg, st, pm, pitch, (int)T, n_pairs, tw,
                                           (double*)ctx->partial.p));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-        TA_HIP_TRY(ctx, launch_wfft_finish(R0, (const double*)ctx->partial.p, (int)nwg, tw, (int)T,
-                                           (double*)ctx->spec.p, d_lagsum, st));
+        // the summed spectrum -> lag sums: ONE inverse transform per launch, run by the on-chip
+        // plan of the same length (its finalize kernel consumes the digit-reversed order, which
+        // the sum over workgroups produces on the way)
+        const PlanEntry* fin = plan_of_length(R0 * 512);
+        if (!fin) {
+            TA_HIP_TRY(ctx, launch_wfft_finish(R0, (const double*)ctx->partial.p, (int)nwg, tw, (int)T,
+                                               (double*)ctx->spec.p, d_lagsum, st));
+            return TA_OK;
+        }
+        Tables tb;
+        if ((rc = get_tables(ctx, fin->M, fin->R_first, &tb))) return rc;
+        if (!tb.perm) {
+            std::vector<int> perm;
+            fin->perm(perm);
+            int* d = nullptr;
+            TA_HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(int) * perm.size()));
+            hipError_t e = hipMemcpy(d, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                hipFree(d);
+                return fail(ctx, TA_E_HIP, std::string("permutation upload: ") + hipGetErrorString(e));
+            }
+            ctx->tables[fin->M].perm = tb.perm = d;
+        }
+        TA_HIP_TRY(ctx, launch_wfft_sum_perm((const double*)ctx->partial.p, (int)nwg, fin->M, tb.perm,
+                                             (double*)ctx->spec.p, st));
+        FftArgs fa{};
+        fa.T = (int)T;
+        fa.tw2 = tb.tw2;
+        fa.spec = (const double*)ctx->spec.p;
+        fa.n_slices = 1;
+        fa.lagsum = d_lagsum;
+        TA_HIP_TRY(ctx, fin->finalize(st, fa));
         return TA_OK;
     }
     const PlanEntry* plan = find_plan(T);
@@ -575,7 +606,10 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ta_stage_free(ctx);
-    for (auto& kv : ctx->tables) hipFree(kv.second.tw2);
+    for (auto& kv : ctx->tables) {
+        hipFree(kv.second.tw2);
+        if (kv.second.perm) hipFree(kv.second.perm);
+    }
     for (auto& kv : ctx->wf_tables) hipFree(kv.second);
     for (auto& kv : ctx->long_tables) {
         hipFree(kv.second.twL);

@@ -38,6 +38,7 @@ struct PlanEntry {
     hipError_t (*finalize)(hipStream_t st, const FftArgs& a);
     hipError_t (*by_particle)(int nwg, hipStream_t st, const FftArgs& a);
     int (*max_wg_per_cu)(int which);  // 0 accum(vec) 1 accum(novec) 2 by_particle
+    void (*perm)(std::vector<int>& out);  // output position -> frequency (digit reversal)
 };
 
 const std::vector<PlanEntry>& plans_pow2();
@@ -102,5 +103,9 @@ hipError_t launch_wfft_accum(int R0, int nwg, hipStream_t st, const double* pm, 
                              long n_pairs, const cd* tw, double* accg /* [nwg][2M], natural order */);
 hipError_t launch_wfft_finish(int R0, const double* partial, int n_parts, const cd* tw, int T,
                               double* spec /* [2M] */, double* lagsum, hipStream_t st);
+// spec[pass*M + p] = sum over workgroups of bin 2*perm[p] + pass: the natural-order blocks summed
+// into the [2][M] digit-reversed layout that the on-chip plan's k_fft_finalize consumes
+hipError_t launch_wfft_sum_perm(const double* partial, int n_parts, int M, const int* perm, double* spec,
+                                hipStream_t st);
 
 }  // namespace ta

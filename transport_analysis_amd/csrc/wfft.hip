@@ -52,6 +52,25 @@ __global__ void __launch_bounds__(256)
     spec[k] = (s0 + s1) + (s2 + s3);
 }
 
+__global__ void __launch_bounds__(256)
+    k_wf_sum_perm(const double* __restrict__ partial, int n_parts, int M, const int* __restrict__ perm,
+                  double* __restrict__ spec) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // pass*M + p
+    if (i >= 2 * M) return;
+    const int pass = i / M, p = i - pass * M;
+    const long k = 2L * perm[p] + pass;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int w = 0;
+    for (; w + 3 < n_parts; w += 4) {
+        s0 += partial[(long)w * 2 * M + k];
+        s1 += partial[(long)(w + 1) * 2 * M + k];
+        s2 += partial[(long)(w + 2) * 2 * M + k];
+        s3 += partial[(long)(w + 3) * 2 * M + k];
+    }
+    for (; w < n_parts; ++w) s0 += partial[(long)w * 2 * M + k];
+    spec[i] = (s0 + s1) + (s2 + s3);
+}
+
 // The lag sums are the real part of the inverse transform of the (real) summed spectrum:
 //   lagsum[n] = (1 / (2M (T - n))) * sum_{k < 2M} P[k] cos(pi k n / M),
 // cosine even in k about M: fold P[k] + P[2M - k] (k < M) first, then one workgroup per lag,
@@ -142,6 +161,12 @@ hipError_t launch_wfft_accum(int R0, int nwg, hipStream_t st, const double* pm, 
         case 20: return launch_accum_r0<20>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_wfft_sum_perm(const double* partial, int n_parts, int M, const int* perm, double* spec,
+                                hipStream_t st) {
+    hipLaunchKernelGGL(k_wf_sum_perm, dim3((2 * M + 255) / 256), dim3(256), 0, st, partial, n_parts, M, perm, spec);
+    return hipGetLastError();
 }
 
 hipError_t launch_wfft_finish(int R0, const double* partial, int n_parts, const cd* tw, int T,

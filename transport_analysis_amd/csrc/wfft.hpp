@@ -209,6 +209,12 @@ __device__ __forceinline__ void wf_sub512_x2(cd* __restrict__ reg0, cd* __restri
 #ifndef WF_TOUCH_DEFAULT
 #define WF_TOUCH_DEFAULT false
 #endif
+#ifndef WF_PRE
+#define WF_PRE 0  // first-stage butterfly before the barrier that frees the LDS (measured: 3-7 % slower)
+#endif
+#ifndef WF_SI
+#define WF_SI 1   // first-stage stores interleaved with the output twiddles
+#endif
 #ifndef WF_INTER_DEFAULT
 #define WF_INTER_DEFAULT false
 #endif
@@ -254,9 +260,7 @@ __global__ void __launch_bounds__(P::NT)
 #pragma unroll
         for (int j = 0; j < R0; ++j) x[j] = wf_load(rs, (unsigned)tid * 16u, (unsigned)(N1 * j) * 16u);
         g = wf_load(twr, (unsigned)tid * 32u, 0u);
-#ifndef WF_ONECHAIN
         g2 = wf_load(twr, (unsigned)tid * 64u, 0u);
-#endif
         h = wf_load(twr, (unsigned)tid * 16u, 0u);
     };
     issue_loads(rsrc_of(blockIdx.x));
@@ -271,24 +275,25 @@ __global__ void __launch_bounds__(P::NT)
                 for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
             }
             Dft<R0>::run(x);
+            // Everything above touches registers only, so it may run BEFORE the barrier that
+            // ends the previous pass's S2 (WF_PRE): a wave that owns one sub-series fewer in
+            // that pass does its butterfly while the others finish theirs.
+            WF_STAMP(2 * B)
+#if WF_PRE
+            __syncthreads();  // every wave has read the previous pass's sub-series: LDS is free
+#endif
             {
-                // output twiddles W_2M^{u(2q+B)} = h^B g^q: two chains (even / odd q) by g^2.
-                // The chain depends on per-thread constants only: laundered, or LICM hoists
-                // all 2 R0 powers out of the pair loop (and spills them).
-#ifdef WF_ONECHAIN
-                cd w = B ? h : g;
-                if constexpr (B == 1) x[0] = cmul(x[0], w);
-#pragma unroll
-                for (int q = 1; q < R0; ++q) {
-                    if (B == 1 || q > 1) w = cmul(w, g);
-                    x[q] = cmul(x[q], w);
-                }
-#else
+                // output twiddles W_2M^{u(2q+B)} = h^B g^q: two chains (even / odd q) by g^2;
+                // WF_SI: each output is stored as soon as it is scaled
                 const cd gg = g, gg2 = g2, hh = h;
                 cd te = B ? hh : cd{1.0, 0.0};
                 cd to = B ? cmul(hh, gg) : gg;
                 if constexpr (B == 1) x[0] = cmul(x[0], te);
-                if constexpr (R0 > 1) x[1] = cmul(x[1], to);
+                if (WF_SI) lds[tid] = x[0];
+                if constexpr (R0 > 1) {
+                    x[1] = cmul(x[1], to);
+                    if (WF_SI) lds[N1 + tid] = x[1];
+                }
 #pragma unroll
                 for (int q = 2; q < R0; ++q) {
                     if (q & 1) {
@@ -298,11 +303,13 @@ __global__ void __launch_bounds__(P::NT)
                         te = cmul(te, gg2);
                         x[q] = cmul(x[q], te);
                     }
+                    if (WF_SI) lds[q * N1 + tid] = x[q];
                 }
-#endif
-            }
+                if (!WF_SI) {
 #pragma unroll
-            for (int q = 0; q < R0; ++q) lds[q * N1 + tid] = x[q];
+                    for (int q = 0; q < R0; ++q) lds[q * N1 + tid] = x[q];
+                }
+            }
             // this wave's stage twiddles for S2 (dead during S1); the scheduling barriers keep
             // the loads from being hoisted over the code before them (which would make their
             // destination registers live there)
@@ -313,8 +320,7 @@ __global__ void __launch_bounds__(P::NT)
                 twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + a * 64) * 16u);
                 twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + (7 + a) * 64) * 16u);
             }
-            WF_STAMP(2 * B)
-            __syncthreads();
+            __syncthreads();  // the sub-series are complete
             // ---- S2: this wave's sub-series of the pass
             static_for_range<P::slot_lo(B), P::slot_hi(B) + 1>([&](auto ss) {
                 constexpr int s = decltype(ss)::value;
@@ -359,7 +365,9 @@ __global__ void __launch_bounds__(P::NT)
                 issue_loads(nrs);
             }
             WF_STAMP(2 * B + 1)
+#if !WF_PRE
             __syncthreads();
+#endif
         };
         one_pass(std::integral_constant<int, 0>{});
         one_pass(std::integral_constant<int, 1>{});
