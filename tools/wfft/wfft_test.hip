@@ -70,7 +70,11 @@ static int run(int argc, char** argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     ncu = prop.multiProcessorCount;
-    const int nwg = (int)std::min<long>(ncu, n_pairs);
+    const bool half = getenv("WF_HALF") && R0 == 20;
+    const int split = getenv("WF_SPLIT") ? atoi(getenv("WF_SPLIT")) : 0;  // 1: plain, 2: interleaved
+    int nwg = (int)std::min<long>(ncu, n_pairs);
+    if (half) nwg = std::max(16, (int)std::min<long>(2 * ncu, 2 * n_pairs) / 16 * 16);
+    if (split) nwg = std::max(16, (int)std::min<long>(ncu, 2 * n_pairs) / 16 * 16);
     // twiddles
     std::vector<cd> tw(2 * (size_t)M + 14 * 64);
     const long double pi = 3.141592653589793238462643383279502884L;
@@ -92,6 +96,11 @@ static int run(int argc, char** argv) {
     CK(hipMalloc(&d_pm, n_el * 8));
     CK(hipMalloc(&d_acc, (size_t)nwg * 2 * M * 8));
     CK(hipMalloc(&d_st, (size_t)nwg * 8 * 8));
+    CK(hipMemset(d_acc, 0, (size_t)nwg * 2 * M * 8));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_whalf_accum<false>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WHalf::kLds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_whalf_accum<true>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WHalf::kLds));
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, d_pm, n_el, 12345ull);
     CK(hipDeviceSynchronize());
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wfft_accum<P, false>),
@@ -106,8 +115,29 @@ static int run(int argc, char** argv) {
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wfft_accum<P, true>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsplit_accum<P, false, false>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsplit_accum<P, false, true>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsplit_accum<P, true, true>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
     auto launch = [&]() {
-        if (stamp && !inter)
+        if (split && stamp)
+            hipLaunchKernelGGL((k_wsplit_accum<P, true, true>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
+                               n_pairs, d_tw, d_acc, d_st);
+        else if (split == 2)
+            hipLaunchKernelGGL((k_wsplit_accum<P, false, true>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
+                               n_pairs, d_tw, d_acc, d_st);
+        else if (split)
+            hipLaunchKernelGGL((k_wsplit_accum<P, false, false>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
+                               n_pairs, d_tw, d_acc, d_st);
+        else if (half && stamp)
+            hipLaunchKernelGGL((k_whalf_accum<true>), dim3(nwg), dim3(256), WHalf::kLds, 0, d_pm, pitch, T, n_pairs,
+                               d_tw, d_acc, d_st);
+        else if (half)
+            hipLaunchKernelGGL((k_whalf_accum<false>), dim3(nwg), dim3(256), WHalf::kLds, 0, d_pm, pitch, T, n_pairs,
+                               d_tw, d_acc, d_st);
+        else if (stamp && !inter)
             hipLaunchKernelGGL((k_wfft_accum<P, true, false, false>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
                                n_pairs, d_tw, d_acc, d_st);
         else if (stamp && !touch)

@@ -331,13 +331,23 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         if ((rc = get_wf_table(ctx, R0, &tw))) return rc;
         const int L2 = 2 * R0 * 512;
         int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * wfft_max_wg_per_cu(R0);
-        nwg = std::max<int64_t>(1, std::min(nwg, n_pairs));
-        if ((rc = ensure(ctx, ctx->partial, sizeof(double) * (size_t)nwg * L2))) return rc;
+        // pass-split form (one pass per workgroup, the two workgroups of a couple share an
+        // XCD's L2: every input byte leaves HBM once) whenever 16 workgroups have work
+        const bool split = std::min<int64_t>(nwg, 2 * n_pairs) >= 16 && ctx->opt_fft_debug != 2;
+        if (split) nwg = std::min<int64_t>(nwg, 2 * n_pairs) / 16 * 16;
+        else nwg = std::max<int64_t>(1, std::min(nwg, n_pairs));
+        int n_parts = (int)(split ? nwg / 2 : nwg);
+        if ((rc = ensure(ctx, ctx->partial, sizeof(double) * (size_t)n_parts * L2))) return rc;
         if ((rc = ensure(ctx, ctx->spec, sizeof(double) * (size_t)L2))) return rc;
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-        TA_HIP_TRY(ctx, launch_wfft_accum(R0, (int)nwg, st, pm, pitch, (int)T, n_pairs, tw,
-                                          (double*)ctx->partial.p));
+        if (split)
+            TA_HIP_TRY(ctx, launch_wfft_split(R0, (int)nwg, st, pm, pitch, (int)T, n_pairs, tw,
+                                              (double*)ctx->partial.p));
+        else
+            TA_HIP_TRY(ctx, launch_wfft_accum(R0, (int)nwg, st, pm, pitch, (int)T, n_pairs, tw,
+                                              (double*)ctx->partial.p));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+        nwg = n_parts;
         // the summed spectrum -> lag sums: ONE inverse transform per launch, run by the on-chip
         // plan of the same length (its finalize kernel consumes the digit-reversed order, which
         // the sum over workgroups produces on the way)

@@ -101,6 +101,9 @@ void wfft_fill_table(int R0, cd* table);
 int wfft_max_wg_per_cu(int R0);
 hipError_t launch_wfft_accum(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
                              long n_pairs, const cd* tw, double* accg /* [nwg][2M], natural order */);
+// pass-split form: nwg a multiple of 16, accg [nwg/2][2M] (every element written by the launch)
+hipError_t launch_wfft_split(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
+                             long n_pairs, const cd* tw, double* accg);
 hipError_t launch_wfft_finish(int R0, const double* partial, int n_parts, const cd* tw, int T,
                               double* spec /* [2M] */, double* lagsum, hipStream_t st);
 // spec[pass*M + p] = sum over workgroups of bin 2*perm[p] + pass: the natural-order blocks summed

@@ -24,6 +24,19 @@ hipError_t launch_accum_r0(int nwg, hipStream_t st, const double* pm, long pitch
     return hipGetLastError();
 }
 
+// pass-split kernel (one pass per workgroup, couples b / b + 8): grid a multiple of 16
+template <int R0>
+hipError_t launch_split_r0(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
+                           const cd* tw, double* accg) {
+    using P = WPlan<R0>;
+    auto kern = k_wsplit_accum<P, false, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_pairs, tw, accg, nullptr);
+    return hipGetLastError();
+}
+
 template <int R0>
 int max_wg_r0() {
     using P = WPlan<R0>;
@@ -167,6 +180,21 @@ hipError_t launch_wfft_sum_perm(const double* partial, int n_parts, int M, const
                                 hipStream_t st) {
     hipLaunchKernelGGL(k_wf_sum_perm, dim3((2 * M + 255) / 256), dim3(256), 0, st, partial, n_parts, M, perm, spec);
     return hipGetLastError();
+}
+
+hipError_t launch_wfft_split(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
+                             long n_pairs, const cd* tw, double* accg) {
+    if (nwg < 16 || nwg % 16) return hipErrorInvalidValue;
+    switch (R0) {
+        case 2: return launch_split_r0<2>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 4: return launch_split_r0<4>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 5: return launch_split_r0<5>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 8: return launch_split_r0<8>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 10: return launch_split_r0<10>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 16: return launch_split_r0<16>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 20: return launch_split_r0<20>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_wfft_finish(int R0, const double* partial, int n_parts, const cd* tw, int T,

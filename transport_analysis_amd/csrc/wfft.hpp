@@ -393,4 +393,306 @@ __global__ void __launch_bounds__(P::NT)
 #undef WF_STAMP
 }
 
+
+// ================================================================================================
+// Pass-split variant: a workgroup does ONE pass (A: even bins, B: odd bins) of every pair of its
+// couple; blocks b and b + 8 (same XCD under round-robin placement, speed only) form a couple
+// and walk the same pair list at the same pace, so the second reader of a pair finds it in the
+// XCD's L2 and every input byte leaves HBM once.  (k_wfft_accum reads a pair twice from one
+// compute unit, half a pair-period apart: with 32 compute units x 160 KiB in flight per 4 MiB
+// L2 the second read mostly misses -- measured 1.8x the algorithmic bytes at the L2's fabric
+// side.)  Half the accumulators per thread (one pass: 20 per lane instead of 40 at R0 = 20),
+// which is what lets the first-stage rows, the stage twiddles and two sub-series in flight fit
+// 256 registers without spilling.
+//
+// grid: a multiple of 16 blocks; block b: pass B = (b >> 3) & 1, couple c = (b & 7) + 8 (b >> 4);
+// accg: [n_couples][2M] natural bin order, the A block writes the even bins of its couple's row,
+// the B block the odd ones.
+template <class P, bool STAMP = false, bool INTER = true>
+__global__ void __launch_bounds__(P::NT)
+    k_wsplit_accum(const double* __restrict__ pm, long pitch, int T, long n_pairs,
+                   const cd* __restrict__ tw2, double* __restrict__ accg,
+                   unsigned long long* __restrict__ stamps = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd* lds = reinterpret_cast<cd*>(smem_raw);
+    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW;
+    constexpr int NS1 = (R0 + NW - 1) / NW;  // sub-series per wave: q = wave + 8 s
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int passB = (blockIdx.x >> 3) & 1;
+    const long couple = (blockIdx.x & 7) + 8 * (blockIdx.x >> 4), n_couples = gridDim.x / 2;
+
+    double acc[NS1][8];
+#pragma unroll
+    for (int s = 0; s < NS1; ++s)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[s][c] = 0.0;
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
+    if constexpr (STAMP) st_prev = __builtin_amdgcn_s_memtime();
+#define WF_STAMP(i)                                                   \
+    if constexpr (STAMP) {                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] += now_ - st_prev;                                  \
+        st_prev = now_;                                               \
+    }
+    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cd*>(tw2), 0, (2 * P::M + 14 * 64) * 16, 0x00020000);
+    auto rsrc_of = [&](long p) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + (p < n_pairs ? p : 0) * pitch * 2), 0,
+                                                 p < n_pairs ? T * 16 : 0, 0x00020000);
+    };
+    cd x[R0], g, g2, h;
+    auto issue_loads = [&](__amdgpu_buffer_rsrc_t rs) {
+#pragma unroll
+        for (int j = 0; j < R0; ++j) x[j] = wf_load(rs, (unsigned)tid * 16u, (unsigned)(N1 * j) * 16u);
+        g = wf_load(twr, (unsigned)tid * 32u, 0u);
+        g2 = wf_load(twr, (unsigned)tid * 64u, 0u);
+        h = wf_load(twr, (unsigned)tid * 16u, 0u);
+    };
+    issue_loads(rsrc_of(couple));
+
+    for (long p = couple; p < n_pairs; p += n_couples) {
+        // ---- S1: radix-R0 butterfly u = tid over rows u + 512 j (loaded one pair ahead)
+        if (passB) {
+            // pass B twist, lane-uniform part: W_{2 R0}^j = tw2[j * 512]
+#pragma unroll
+            for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
+        }
+        Dft<R0>::run(x);
+        {
+            // output twiddles W_2M^{u(2q+B)} = h^B g^q: two chains (even / odd q) by g^2, each
+            // output stored as soon as it is scaled
+            cd te = passB ? h : cd{1.0, 0.0};
+            cd to = passB ? cmul(h, g) : g;
+            if (passB) x[0] = cmul(x[0], te);
+            lds[tid] = x[0];
+            if constexpr (R0 > 1) {
+                x[1] = cmul(x[1], to);
+                lds[N1 + tid] = x[1];
+            }
+#pragma unroll
+            for (int q = 2; q < R0; ++q) {
+                if (q & 1) {
+                    to = cmul(to, g2);
+                    x[q] = cmul(x[q], to);
+                } else {
+                    te = cmul(te, g2);
+                    x[q] = cmul(x[q], te);
+                }
+                lds[q * N1 + tid] = x[q];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cd twa[7], twb[7];
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+            twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + a * 64) * 16u);
+            twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + (7 + a) * 64) * 16u);
+        }
+        WF_STAMP(0)
+        __syncthreads();
+        // ---- S2: sub-series q = wave + 8 s; slots every wave owns go two at a time
+        static_for_range<0, NS1>([&](auto ss) {
+            constexpr int s = decltype(ss)::value;
+            constexpr bool full = NW * s + NW - 1 < R0;             // every wave has this slot
+            constexpr bool nfull = NW * (s + 1) + NW - 1 < R0;      // ... and the next one
+            constexpr bool pfull = s > 0 && NW * (s - 1) + NW - 1 < R0;
+            // pair up full slots (0,1), (2,3), ...: s is a head if it is full, even-positioned and its successor is full
+            constexpr bool head = INTER && full && nfull && (s % 2 == 0);
+            constexpr bool tail = INTER && full && pfull && (s % 2 == 1);
+            const int q = wave + NW * s;
+            if constexpr (head) {
+                wf_sub512_x2(lds + q * N1, lds + (q + NW) * N1, lane, twa, twb, acc[s], acc[s + 1]);
+            } else if constexpr (!tail) {
+                if (full || q < R0) wf_sub512(lds + q * N1, lane, twa, twb, acc[s]);
+            }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        issue_loads(rsrc_of(p + n_couples));
+        WF_STAMP(1)
+        __syncthreads();
+    }
+    double* out = accg + couple * 2 * P::M;
+#pragma unroll
+    for (int s = 0; s < NS1; ++s) {
+        const int q = wave + NW * s;
+        if (q < R0) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int sb = (lane >> 3) + 8 * (lane & 7) + 64 * c;
+                out[2 * (q + R0 * sb) + passB] = acc[s][c];
+            }
+        }
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && (wave == 0 || wave == 4))
+            for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + (wave / 4) * 4 + i] = st_acc[i];
+    }
+#undef WF_STAMP
+}
+
+// ================================================================================================
+// M = 10240, two workgroups per compute unit ("half passes").
+//
+// k_wfft_accum holds a whole pass (160 KiB) in LDS, so a compute unit runs ONE workgroup whose
+// waves move through the phases together: the first stage (vector-arithmetic bound) and the
+// sub-series transforms (LDS bound) never overlap.  Here a workgroup is 256 threads with 80 KiB
+// of LDS and does ONE pass (A: even bins or B: odd bins, by block index) in two halves: half H
+// holds the ten sub-series q = H, H+2, ..., H+18 (the prime-factor 4 x 5 butterfly splits by
+// q mod 4 in {H, H+2} at no extra arithmetic: a DFT4 needs 4 of its 8 additions for two of
+// its outputs).  Two such workgroups share a compute unit and drift apart, so one's first
+// stage runs under the other's exchanges.  The price: a pair's rows are read four times (twice
+// per pass), three of them from L2; the A and B workgroups of a couple (blocks b and b + 8:
+// same XCD under round-robin placement) walk the same pair list at the same pace.
+template <int H>
+__device__ __forceinline__ void dft20_half(const cd (&x)[20], cd (&y)[10]) {
+    cd s0[5], s1[5];  // outputs k1 = H and H + 2 of the five DFT4 (over j1), indexed by j2
+#pragma unroll
+    for (int j2 = 0; j2 < 5; ++j2) {
+        const cd a0 = x[(4 * j2) % 20], a1 = x[(5 + 4 * j2) % 20], a2 = x[(10 + 4 * j2) % 20],
+                 a3 = x[(15 + 4 * j2) % 20];
+        if constexpr (H == 0) {
+            const cd t0 = a0 + a2, t2 = a1 + a3;
+            s0[j2] = t0 + t2;
+            s1[j2] = t0 - t2;
+        } else {
+            const cd t1 = a0 - a2, t3 = mul_mi(a1 - a3);
+            s0[j2] = t1 + t3;
+            s1[j2] = t1 - t3;
+        }
+    }
+    Dft<5>::run(s0);
+    Dft<5>::run(s1);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const int q = 2 * r + H;
+        y[r] = (q % 4 == H) ? s0[q % 5] : s1[q % 5];
+    }
+}
+
+struct WHalf {
+    static constexpr int R0 = 20, N1 = 512, NT = 256, NW = 4, M = R0 * N1, NSUB = 10, NS = 5;
+    static constexpr size_t kLds = (size_t)NSUB * N1 * sizeof(cd);
+    // sub-series i = 10 H + r of a pass belongs to wave i % 4, slot i / 4
+    static constexpr int slot_lo(int H) { return H * NSUB < NW ? 0 : (H * NSUB - (NW - 1) + NW - 1) / NW; }
+    static constexpr int slot_hi(int H) { return ((H + 1) * NSUB - 1) / NW; }
+};
+
+// grid: a multiple of 16 blocks; block b: pass B = (b >> 3) & 1, couple c = (b & 7) + 8 (b >> 4);
+// accg: [n_couples][2M], the A block writes the even bins of its couple's row, the B block the odd.
+template <bool STAMP = false>
+__global__ void __launch_bounds__(256, 2)
+    k_whalf_accum(const double* __restrict__ pm, long pitch, int T, long n_pairs,
+                  const cd* __restrict__ tw2, double* __restrict__ accg,
+                  unsigned long long* __restrict__ stamps = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd* lds = reinterpret_cast<cd*>(smem_raw);
+    using P = WHalf;
+    constexpr int N1 = P::N1, NS = P::NS, NW = P::NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int passB = (blockIdx.x >> 3) & 1;
+    const long couple = (blockIdx.x & 7) + 8 * (blockIdx.x >> 4), n_couples = gridDim.x / 2;
+
+    double acc[NS][8];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[s][c] = 0.0;
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
+    if constexpr (STAMP) st_prev = __builtin_amdgcn_s_memtime();
+#define WF_STAMP(i)                                                   \
+    if constexpr (STAMP) {                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] += now_ - st_prev;                                  \
+        st_prev = now_;                                               \
+    }
+    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cd*>(tw2), 0, (2 * P::M + 14 * 64) * 16, 0x00020000);
+    auto rsrc_of = [&](long p) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + (p < n_pairs ? p : 0) * pitch * 2), 0,
+                                                 p < n_pairs ? T * 16 : 0, 0x00020000);
+    };
+    // rows of butterfly u and the seeds of its output twiddles: g = W_2M^{2u}, g2 = g^2, h = W_2M^u
+    cd x[20], g, g2, h;
+    auto issue_loads = [&](__amdgpu_buffer_rsrc_t rs, int u) {
+#pragma unroll
+        for (int j = 0; j < 20; ++j) x[j] = wf_load(rs, (unsigned)u * 16u, (unsigned)(N1 * j) * 16u);
+        g = wf_load(twr, (unsigned)u * 32u, 0u);
+        g2 = wf_load(twr, (unsigned)u * 64u, 0u);
+        h = wf_load(twr, (unsigned)u * 16u, 0u);
+    };
+    issue_loads(rsrc_of(couple), tid);
+
+    for (long p = couple; p < n_pairs; p += n_couples) {
+        const __amdgpu_buffer_rsrc_t rs = rsrc_of(p);
+        auto one_half = [&](auto HH) {
+            constexpr int H = decltype(HH)::value;
+            // ---- S1: two butterflies per thread (u = tid, tid + 256), ten outputs each
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                const int u = tid + 256 * rep;
+                if (rep == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_loads(rs, u);
+                }
+                if (passB) {
+                    // pass B twist, lane-uniform part: W_40^j = tw2[j * 512]
+#pragma unroll
+                    for (int j = 1; j < 20; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
+                }
+                cd y[10];
+                dft20_half<H>(x, y);
+                // output twiddles W_2M^{u (2q + B)}, q = 2r + H: start h^B g^H, step g^2
+                cd w = passB ? h : cd{1.0, 0.0};
+                if constexpr (H == 1) w = passB ? cmul(w, g) : g;
+#pragma unroll
+                for (int r = 0; r < 10; ++r) {
+                    if (r > 0) w = cmul(w, g2);
+                    if (r > 0 || H == 1 || passB) y[r] = cmul(y[r], w);
+                    lds[r * N1 + u] = y[r];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cd twa[7], twb[7];
+#pragma unroll
+            for (int a = 0; a < 7; ++a) {
+                twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + a * 64) * 16u);
+                twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + (7 + a) * 64) * 16u);
+            }
+            WF_STAMP(2 * H)
+            __syncthreads();
+            // ---- S2: this wave's sub-series of the half
+            static_for_range<P::slot_lo(H), P::slot_hi(H) + 1>([&](auto ss) {
+                constexpr int s = decltype(ss)::value;
+                const int i = wave + NW * s;
+                if (i >= H * P::NSUB && i < (H + 1) * P::NSUB)
+                    wf_sub512(lds + (i - H * P::NSUB) * N1, lane, twa, twb, acc[s]);
+            });
+            // first butterfly of the next half: the same pair again, or the next pair
+            __builtin_amdgcn_sched_barrier(0);
+            issue_loads(H == 0 ? rs : rsrc_of(p + n_couples), tid);
+            WF_STAMP(2 * H + 1)
+            __syncthreads();
+        };
+        one_half(std::integral_constant<int, 0>{});
+        one_half(std::integral_constant<int, 1>{});
+    }
+    // accumulators -> natural bin order: bin 2 (q + 20 sb) + B, q = 2r + H, i = 10 H + r
+    double* out = accg + couple * 2 * P::M;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i = wave + NW * s;
+        const int H = i / P::NSUB, r = i - H * P::NSUB, q = 2 * r + H;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int sb = (lane >> 3) + 8 * (lane & 7) + 64 * c;
+            out[2 * (q + 20 * sb) + passB] = acc[s][c];
+        }
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && wave == 0)
+            for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + i] = st_acc[i];
+    }
+#undef WF_STAMP
+}
+
 }  // namespace ta
