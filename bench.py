@@ -18,7 +18,7 @@ device tensor out).
 
 Prints ONE JSON line (rank 0).  `value` = total frames x atoms processed per second over all
 ranks (from the wall time of exactly K steps between two fences, max over ranks).
-`roofline` prices the dominant kernel (k_wfft_accum) against the 8 TB/s HBM roof with its
+`roofline` prices the dominant kernel (k_wsplit_accum) against the 8 TB/s HBM roof with its
 algorithmic bytes (n_frames*n_atoms*dim*8 per launch) and the median of its K hipEvent-measured
 durations (recorded by the library on the launch stream, read AFTER the timed region), and
 carries the FP64 vector co-roof beside it.  `cpu_baseline` is the NumPy oracle (per-atom loop
@@ -138,7 +138,7 @@ class Case:
             return "k_direct"
         if self.bp is not None:
             return "k_fft_accum (by-particle mode)"
-        return "k_wfft_accum" if 512 < self.T <= 10240 else ("k_fft_accum" if self.T <= 512 else "k_fft_accum_long")
+        return "k_wsplit_accum" if 512 < self.T <= 10240 else ("k_fft_accum" if self.T <= 512 else "k_fft_accum_long")
 
 
 def timed(torch, dist, world, steps, warmup, fn):

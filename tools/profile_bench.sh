@@ -8,7 +8,7 @@ TAG=${1:-r01}
 shift || true
 ARGS=${@:-"--steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-host-path --no-check"}
 KEY=${TA_TRAFFIC_KEY:-fft_10000x100000x3}
-KERN=${TA_TRAFFIC_KERNEL:-k_wfft_accum}
+KERN=${TA_TRAFFIC_KERNEL:-k_wsplit_accum}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -76,17 +76,8 @@ static int run(int argc, char** argv) {
     if (half) nwg = std::max(16, (int)std::min<long>(2 * ncu, 2 * n_pairs) / 16 * 16);
     if (split) nwg = std::max(16, (int)std::min<long>(ncu, 2 * n_pairs) / 16 * 16);
     // twiddles
-    std::vector<cd> tw(2 * (size_t)M + 14 * 64);
-    const long double pi = 3.141592653589793238462643383279502884L;
-    for (long n = 0; n < 2L * M; ++n) {
-        const long double a = pi * (long double)n / (long double)M;
-        tw[n] = cd{(double)cosl(a), (double)-sinl(a)};
-    }
-    for (int a = 1; a < 8; ++a)
-        for (int l = 0; l < 64; ++l) {
-            tw[2 * (size_t)M + (a - 1) * 64 + l] = tw[(size_t)(2 * R0 * l * a)];
-            tw[2 * (size_t)M + (6 + a) * 64 + l] = tw[(size_t)(16 * R0 * (l & 7) * a)];
-        }
+    std::vector<cd> tw(wf_table_elems(R0));
+    wf_fill_table(R0, tw.data());
     cd* d_tw;
     double *d_pm, *d_acc;
     unsigned long long* d_st;

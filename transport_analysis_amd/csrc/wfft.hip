@@ -126,28 +126,9 @@ bool wfft_choose(long n_frames, int* R0) {
     return false;
 }
 
-size_t wfft_table_elems(int R0) { return 2 * (size_t)R0 * 512 + 14 * 64; }
+size_t wfft_table_elems(int R0) { return wf_table_elems(R0); }
 
-void wfft_fill_table(int R0, cd* a) {
-    const long M = (long)R0 * 512;
-    const long double pi = 3.141592653589793238462643383279502884L;
-    for (long n = 0; n < 2 * M; ++n) {
-        if (n == 0) a[n] = cd{1.0, 0.0};
-        else if (n == M) a[n] = cd{-1.0, 0.0};
-        else if (2 * n == M) a[n] = cd{0.0, -1.0};
-        else if (2 * n == 3 * M) a[n] = cd{0.0, 1.0};
-        else {
-            const long double h = pi * (long double)n / (long double)M;
-            a[n] = cd{(double)cosl(h), (double)-sinl(h)};
-        }
-    }
-    // wave-local stage twiddles [14][64]: W_512^{lane a} (a = 1..7), W_64^{(lane & 7) b} (b = 1..7)
-    for (int r = 1; r < 8; ++r)
-        for (int l = 0; l < 64; ++l) {
-            a[2 * M + (r - 1) * 64 + l] = a[2 * R0 * l * r];
-            a[2 * M + (6 + r) * 64 + l] = a[16 * R0 * (l & 7) * r];
-        }
-}
+void wfft_fill_table(int R0, cd* a) { wf_fill_table(R0, a); }
 
 int wfft_max_wg_per_cu(int R0) {
     switch (R0) {

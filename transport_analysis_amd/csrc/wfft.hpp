@@ -76,6 +76,36 @@ struct Dft<20> {
     }
 };
 
+// Twiddle table of plan R0 (host side; shared by the library and tools/wfft):
+//   [0, 2M)                      W_2M^n = exp(-i pi n / M)
+//   [2M, 2M + 896)               wave-local stage twiddles [14][64]: rows 0..6 W_512^{lane (r+1)},
+//                                rows 7..13 W_64^{(lane & 7) (r-6)}
+//   [2M + 896, 4M + 896)         first-stage output twiddles [B][q][u] = W_2M^{u (2q + B)}
+inline size_t wf_table_elems(int R0) { return 4 * (size_t)R0 * 512 + 14 * 64; }
+inline void wf_fill_table(int R0, cd* a) {
+    const long M = (long)R0 * 512;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    for (long n = 0; n < 2 * M; ++n) {
+        if (n == 0) a[n] = cd{1.0, 0.0};
+        else if (n == M) a[n] = cd{-1.0, 0.0};
+        else if (2 * n == M) a[n] = cd{0.0, -1.0};
+        else if (2 * n == 3 * M) a[n] = cd{0.0, 1.0};
+        else {
+            const long double h = pi * (long double)n / (long double)M;
+            a[n] = cd{(double)cosl(h), (double)-sinl(h)};
+        }
+    }
+    for (int r = 1; r < 8; ++r)
+        for (int l = 0; l < 64; ++l) {
+            a[2 * M + (r - 1) * 64 + l] = a[2 * R0 * l * r];
+            a[2 * M + (6 + r) * 64 + l] = a[16 * R0 * (l & 7) * r];
+        }
+    for (int B = 0; B < 2; ++B)
+        for (long q = 0; q < R0; ++q)
+            for (long u = 0; u < 512; ++u)
+                a[2 * M + 896 + (B * R0 + q) * 512 + u] = a[(u * (2 * q + B)) % (2 * M)];
+}
+
 template <int R0_>
 struct WPlan {
     static constexpr int R0 = R0_;
@@ -162,7 +192,7 @@ struct WfSub {
     __device__ __forceinline__ void stage_c(cd (&v)[8], double (&acc)[8]) const {
         Dft<8>::run(v);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] += norm2(v[c]);
+        for (int c = 0; c < 8; ++c) acc[c] = fma(v[c].y, v[c].y, fma(v[c].x, v[c].x, acc[c]));
         __builtin_amdgcn_wave_barrier();
     }
 };
@@ -214,6 +244,15 @@ __device__ __forceinline__ void wf_sub512_x2(cd* __restrict__ reg0, cd* __restri
 #endif
 #ifndef WF_SI
 #define WF_SI 1   // first-stage stores interleaved with the output twiddles
+#endif
+#ifndef WF_TWRES
+#define WF_TWRES 1  // split kernel: stage twiddles resident in registers (1) or re-loaded per pair (0)
+#endif
+#ifndef WF_TW1
+#define WF_TW1 0    // first-stage output twiddles from the table (1) or by two product chains (0)
+#endif
+#ifndef WF_EARLY
+#define WF_EARLY 0  // next pair's rows requested before the last single sub-series of S2
 #endif
 #ifndef WF_INTER_DEFAULT
 #define WF_INTER_DEFAULT false
@@ -435,29 +474,65 @@ __global__ void __launch_bounds__(P::NT)
         st_prev = now_;                                               \
     }
     const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<cd*>(tw2), 0, (2 * P::M + 14 * 64) * 16, 0x00020000);
+        const_cast<cd*>(tw2), 0, (4 * P::M + 14 * 64) * 16, 0x00020000);
+    // this pass's first-stage output twiddles [q][u]: read from the table (L2 hits, issued
+    // before the butterfly, landed after it) instead of 19 complex products per butterfly
+    const unsigned tw1_off = (unsigned)(2 * P::M + 14 * 64 + passB * R0 * N1) * 16u;
     auto rsrc_of = [&](long p) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + (p < n_pairs ? p : 0) * pitch * 2), 0,
                                                  p < n_pairs ? T * 16 : 0, 0x00020000);
     };
-    cd x[R0], g, g2, h;
+    cd x[R0];
     auto issue_loads = [&](__amdgpu_buffer_rsrc_t rs) {
 #pragma unroll
         for (int j = 0; j < R0; ++j) x[j] = wf_load(rs, (unsigned)tid * 16u, (unsigned)(N1 * j) * 16u);
-        g = wf_load(twr, (unsigned)tid * 32u, 0u);
-        g2 = wf_load(twr, (unsigned)tid * 64u, 0u);
-        h = wf_load(twr, (unsigned)tid * 16u, 0u);
     };
     issue_loads(rsrc_of(couple));
+#if WF_TWRES
+    // the wave-local stage twiddles stay in registers for the whole launch (one pass's
+    // accumulators leave room for them: 14 fewer loads per wave and pair)
+    cd twa[7], twb[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+        twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + a * 64) * 16u);
+        twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + (7 + a) * 64) * 16u);
+    }
+#endif
 
     for (long p = couple; p < n_pairs; p += n_couples) {
-        // ---- S1: radix-R0 butterfly u = tid over rows u + 512 j (loaded one pair ahead)
+        // ---- S1: radix-R0 butterfly u = tid over rows u + 512 j (loaded during the previous S2)
+#if WF_TW1
+        // (two batches: all R0 of them next to the R0 rows and the butterfly's temporaries do
+        // not fit the register file at R0 = 20)
+        constexpr int QH = R0 > 10 ? R0 / 2 : R0;
+        cd t1[R0];
+#pragma unroll
+        for (int q = 0; q < QH; ++q) t1[q] = wf_load(twr, (unsigned)tid * 16u, tw1_off + (unsigned)(q * N1) * 16u);
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        const cd g = wf_load(twr, (unsigned)tid * 32u, 0u), g2 = wf_load(twr, (unsigned)tid * 64u, 0u),
+                 h = wf_load(twr, (unsigned)tid * 16u, 0u);
+#endif
         if (passB) {
             // pass B twist, lane-uniform part: W_{2 R0}^j = tw2[j * 512]
 #pragma unroll
             for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
         }
         Dft<R0>::run(x);
+#if WF_TW1
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = QH; q < R0; ++q) t1[q] = wf_load(twr, (unsigned)tid * 16u, tw1_off + (unsigned)(q * N1) * 16u);
+        __builtin_amdgcn_sched_barrier(0);
+        // output q scaled by W_2M^{u(2q+B)} and stored at once (stores spread between products)
+        if (passB) x[0] = cmul(x[0], t1[0]);
+        lds[tid] = x[0];
+#pragma unroll
+        for (int q = 1; q < R0; ++q) {
+            x[q] = cmul(x[q], t1[q]);
+            lds[q * N1 + tid] = x[q];
+        }
+#else
         {
             // output twiddles W_2M^{u(2q+B)} = h^B g^q: two chains (even / odd q) by g^2, each
             // output stored as soon as it is scaled
@@ -481,6 +556,8 @@ __global__ void __launch_bounds__(P::NT)
                 lds[q * N1 + tid] = x[q];
             }
         }
+#endif
+#if !WF_TWRES
         __builtin_amdgcn_sched_barrier(0);
         cd twa[7], twb[7];
 #pragma unroll
@@ -488,26 +565,36 @@ __global__ void __launch_bounds__(P::NT)
             twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + a * 64) * 16u);
             twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + (7 + a) * 64) * 16u);
         }
+#endif
         WF_STAMP(0)
         __syncthreads();
-        // ---- S2: sub-series q = wave + 8 s; slots every wave owns go two at a time
+        // ---- S2: sub-series q = wave + 8 s; slots every wave owns go two at a time.  The next
+        // pair's rows are requested before the LAST slot when that one is a single sub-series
+        // (registers allow it there), i.e. about one sub-series time before the barrier.
+        const __amdgpu_buffer_rsrc_t nrs = rsrc_of(p + n_couples);
         static_for_range<0, NS1>([&](auto ss) {
             constexpr int s = decltype(ss)::value;
             constexpr bool full = NW * s + NW - 1 < R0;             // every wave has this slot
             constexpr bool nfull = NW * (s + 1) + NW - 1 < R0;      // ... and the next one
             constexpr bool pfull = s > 0 && NW * (s - 1) + NW - 1 < R0;
-            // pair up full slots (0,1), (2,3), ...: s is a head if it is full, even-positioned and its successor is full
             constexpr bool head = INTER && full && nfull && (s % 2 == 0);
             constexpr bool tail = INTER && full && pfull && (s % 2 == 1);
             const int q = wave + NW * s;
             if constexpr (head) {
                 wf_sub512_x2(lds + q * N1, lds + (q + NW) * N1, lane, twa, twb, acc[s], acc[s + 1]);
             } else if constexpr (!tail) {
+                if constexpr (s == NS1 - 1 && WF_EARLY) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_loads(nrs);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (full || q < R0) wf_sub512(lds + q * N1, lane, twa, twb, acc[s]);
             }
+            if constexpr (s == NS1 - 1 && (head || tail || !WF_EARLY)) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_loads(nrs);
+            }
         });
-        __builtin_amdgcn_sched_barrier(0);
-        issue_loads(rsrc_of(p + n_couples));
         WF_STAMP(1)
         __syncthreads();
     }
