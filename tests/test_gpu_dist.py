@@ -1,0 +1,71 @@
+"""Two ranks on ONE GPU (gloo process group): every rank runs the real drop-in classes with
+distributed=True on the real HIP library -- stages and correlates only its atom block -- and
+the reduced timeseries must equal the oracle's over ALL atoms (scale-relative 1e-10).  What a
+1-GPU box can prove about the N > 1 path: HIP-computed partial lag sums reduced across ranks
+(velocityautocorr.py:214,237, viscosity.py:233 are the reduce points in the reference)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import scale_rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _worker(rank, world, port, T, A, out_dir):
+    import torch.distributed as dist
+
+    from oracle import numpy_oracle as orc
+    from transport_analysis_amd import VelocityAutocorr, ViscosityHelfand
+    from transport_analysis_amd._mini_mda import ArrayUniverse
+
+    os.environ.pop("LOCAL_RANK", None)
+    os.environ["TA_AMD_DEVICE"] = "0"  # both ranks share the box's one GPU
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=321)
+    u = ArrayUniverse(positions=x, velocities=v, masses=m, dimensions=[60, 60, 60, 90, 90, 90])
+    out = {}
+    for fft in (True, False):
+        for byp in (True, False):
+            a = VelocityAutocorr(u.atoms, fft=fft, distributed=True, by_particle=byp).run()
+            out[f"vacf_ts_{int(fft)}_{int(byp)}"] = a.results.timeseries
+            if byp:
+                out[f"vacf_bp_{int(fft)}"] = a.results.vacf_by_particle
+            out["range"] = np.array(a.results.particle_range)
+    h = ViscosityHelfand(u.atoms, distributed=True).run()
+    out["visc_ts"] = h.results.timeseries
+    out["visc_bp"] = h.results.visc_by_particle
+    np.savez(os.path.join(out_dir, f"g_{rank}.npz"), **out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T,A", [(700, 7), (64, 1), (1500, 33)])
+def test_classes_distributed_two_ranks_one_gpu(tmp_path, T, A):
+    import torch.multiprocessing as mp
+
+    from oracle import numpy_oracle as orc
+
+    world = 2
+    port = 33500 + (os.getpid() % 2000) + A
+    mp.spawn(_worker, args=(world, port, T, A, str(tmp_path)), nprocs=world, join=True)
+    v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=321)
+    v32 = v.astype(np.float32).astype(np.float64)  # ArrayUniverse hands out float32 like MDAnalysis
+    x32 = x.astype(np.float32).astype(np.float64)
+    want_bp, want_ts = orc.vacf_fft_batched(v32)
+    hbp, hts = orc.helfand(v32, x32, m, np.full(T, 60.0**3), 300.0)
+    for r in range(world):
+        z = np.load(tmp_path / f"g_{r}.npz", allow_pickle=True)
+        lo, hi = z["range"]
+        assert (lo, hi) == ((A * r) // world, (A * (r + 1)) // world)
+        for fft in (0, 1):
+            for byp in (0, 1):
+                assert scale_rel_err(z[f"vacf_ts_{fft}_{byp}"], want_ts) < TOL
+            if hi > lo:
+                assert scale_rel_err(z[f"vacf_bp_{fft}"], want_bp[:, lo:hi]) < TOL
+            else:
+                assert z[f"vacf_bp_{fft}"].shape == (T, 0)
+        assert scale_rel_err(z["visc_ts"], hts) < TOL
+        if hi > lo:
+            assert scale_rel_err(z["visc_bp"], hbp[:, lo:hi]) < TOL

@@ -58,6 +58,7 @@ struct ta_ctx {
     static constexpr int kRing = 64;
     hipEvent_t ring[kRing][4] = {};
     hipEvent_t* ev = ring[0];
+    hipEvent_t ev_stage = nullptr;  // orders a caller's stream behind the staging stream
     long n_calls = 0;  // compute calls completed (their events recorded)
     bool timing_valid = false;
     // options
@@ -539,6 +540,15 @@ int dev_entry(ta_ctx* ctx, int which, const double* d_vel, const double* d_pos, 
     return compute_pm(ctx, which, pv, px, d_masses, pm_pitch(T), T, A, D, scale, d_lagsum, d_bp, ld_bp, st, false);
 }
 
+// frames committed by ta_stage_commit travel on the context's own stream: a caller's stream that
+// is about to touch the slabs waits for them (a no-op when nothing is pending)
+int order_after_staging(ta_ctx* ctx, hipStream_t st) {
+    if (st == ctx->stream) return TA_OK;
+    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
+    TA_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_stage, 0));
+    return TA_OK;
+}
+
 int staged_entry(ta_ctx* ctx, int which, const double* d_masses, double scale, double* d_lagsum,
                  double* d_bp, int64_t ld_bp, void* stream) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
@@ -547,6 +557,8 @@ int staged_entry(ta_ctx* ctx, int which, const double* d_masses, double scale, d
     if (!d_lagsum || (which == W_HELFAND && !d_masses)) return fail(ctx, TA_E_INVALID, "null device pointer");
     if (d_bp && ld_bp < ctx->st_A) return fail(ctx, TA_E_INVALID, "ld_bp smaller than n_atoms");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = order_after_staging(ctx, (hipStream_t)stream);
+    if (rc) return rc;
     return compute_pm(ctx, which, ctx->d_slabs[0], need == 2 ? ctx->d_slabs[1] : nullptr, d_masses,
                       ctx->st_pitch, ctx->st_T, ctx->st_A, ctx->st_D, scale, d_lagsum, d_bp, ld_bp,
                       (hipStream_t)stream, true);
@@ -586,6 +598,7 @@ int ta_ctx_create(int device, ta_ctx** out) {
     for (auto& q : ctx->ring)
         for (auto& ev : q)
             if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming);
     if (e != hipSuccess) {
         const std::string msg = std::string("context setup: ") + hipGetErrorString(e);
         ta_ctx_destroy(ctx);  // frees whatever was created
@@ -632,6 +645,7 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     for (auto& q : ctx->ring)
         for (auto& ev : q)
             if (ev) hipEventDestroy(ev);
+    if (ctx->ev_stage) hipEventDestroy(ctx->ev_stage);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return TA_OK;
@@ -726,6 +740,8 @@ static int stage_alloc_common(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, in
     ctx->st_dtype = dtype;
     ctx->st_nslabs = n_slabs;
     ctx->st_pitch = pm_pitch(n_frames);
+    // the zero fill ran on the context's stream; later fills may come on any stream
+    TA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TA_OK;
 }
 
@@ -777,6 +793,7 @@ int ta_stage_commit_dev(ta_ctx* ctx, int slab, const void* d_src, int dtype, int
         return fail(ctx, TA_E_INVALID, "frame range out of bounds");
     if (ld_row < ctx->st_A * ctx->st_D) return fail(ctx, TA_E_INVALID, "ld_row smaller than n_atoms*dim");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc_ = order_after_staging(ctx, (hipStream_t)stream)) return rc_;
     TA_HIP_TRY(ctx, launch_relayout(d_src, dtype == TA_F32, ld_row, ctx->st_A * ctx->st_D, frame_hi - frame_lo,
                                     ctx->d_slabs[slab], ctx->st_pitch, frame_lo, (hipStream_t)stream));
     return TA_OK;
@@ -789,6 +806,7 @@ int ta_stage_synth(ta_ctx* ctx, int slab, uint64_t seed, int64_t col_offset, int
     if (col_offset < 0 || col_offset + ctx->st_A * ctx->st_D > n_cols_total)
         return fail(ctx, TA_E_INVALID, "column block outside the synthetic tensor");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc_ = order_after_staging(ctx, (hipStream_t)stream)) return rc_;
     TA_HIP_TRY(ctx, launch_synth(ctx->d_slabs[slab], ctx->st_pitch, ctx->st_A * ctx->st_D, ctx->st_T, seed,
                                  col_offset, n_cols_total, (hipStream_t)stream));
     return TA_OK;
@@ -799,6 +817,7 @@ int ta_stage_read_dev(ta_ctx* ctx, int slab, double* d_dst, int64_t ld_row, void
     if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
     if (ld_row < ctx->st_A * ctx->st_D) return fail(ctx, TA_E_INVALID, "ld_row smaller than n_atoms*dim");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc_ = order_after_staging(ctx, (hipStream_t)stream)) return rc_;
     TA_HIP_TRY(ctx, launch_unlayout(ctx->d_slabs[slab], ctx->st_pitch, ctx->st_A * ctx->st_D, ctx->st_T, d_dst,
                                     ld_row, (hipStream_t)stream));
     return TA_OK;

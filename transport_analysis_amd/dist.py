@@ -60,6 +60,60 @@ def shard_of_this_rank(n_atoms):
     return rank, world, lo, hi
 
 
+def default_device():
+    """GPU index of the calling rank: $TA_AMD_DEVICE, else $LOCAL_RANK (torchrun: one process per
+    GPU), else torch's current device when a process group is up, else 0."""
+    import os
+
+    for key in ("TA_AMD_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(key, "") != "":
+            return int(os.environ[key])
+    try:
+        import torch
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and torch.cuda.is_available():
+            return int(torch.cuda.current_device())
+    except Exception:
+        pass
+    return 0
+
+
+def uses_device_reduce():
+    """True when the process group reduces device tensors (nccl = RCCL on ROCm)."""
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+
+
+def staged_timeseries_on_device(ctx, which, n_frames, n_local, n_atoms_total, device, masses=None,
+                                scale=1.0, by_particle=False):
+    """This rank's staged block -> lag sums (device) -> ONE all-reduce over RCCL -> mean over
+    ALL atoms.  The (n_frames,) float64 sums never leave the GPU before the reduce.
+    which: "fft" | "direct" | "helfand".  Returns (timeseries ndarray, by_particle ndarray|None)."""
+    import torch
+
+    dev = torch.device("cuda", device)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        lag = torch.zeros(n_frames, dtype=torch.float64, device=dev)
+        bp = torch.empty((n_frames, max(n_local, 1)), dtype=torch.float64, device=dev) if by_particle else None
+        d_bp = bp.data_ptr() if bp is not None else 0
+        if n_local:  # more ranks than atoms: this rank contributes zeros
+            if which == "fft":
+                ctx.vacf_fft_staged(lag.data_ptr(), d_bp, n_local, stream)
+            elif which == "direct":
+                ctx.vacf_direct_staged(lag.data_ptr(), d_bp, n_local, stream)
+            else:
+                m = torch.as_tensor(np.ascontiguousarray(masses, dtype=np.float64), device=dev)
+                ctx.helfand_msd_staged(m.data_ptr(), float(scale), lag.data_ptr(), d_bp, n_local, stream)
+        ts = reduce_lagsum(lag, n_atoms_total)
+        out_bp = None
+        if bp is not None:
+            out_bp = bp.cpu().numpy() if n_local else np.zeros((n_frames, 0))
+        return ts.cpu().numpy(), out_bp
+
+
 def allreduce_mean_over_atoms(ts_local, n_local, n_atoms_total, device=None):
     """Turn this rank's mean over ITS atoms into the mean over ALL atoms: one all-reduce of the
     (n_frames,) float64 lag sums (RCCL when the group's backend is nccl, gloo on CPU)."""

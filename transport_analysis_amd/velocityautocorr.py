@@ -39,7 +39,12 @@ class VelocityAutocorr(AnalysisBase):
         on the GPU before the single inverse transform) and
         ``results.vacf_by_particle`` is ``None``.
     device : int, keyword-only
-        GPU index (default: ``$TA_AMD_DEVICE`` or 0).
+        GPU index (default: ``$TA_AMD_DEVICE`` or 0; with ``distributed=True``:
+        ``$TA_AMD_DEVICE``, else ``$LOCAL_RANK``, else torch's current device).
+    stage_dtype : numpy dtype, keyword-only
+        Element type of the pinned staging slab.  Default: the dtype MDAnalysis hands the
+        velocities out in (float32) -- lossless, half the PCIe bytes of the reference's
+        float64 slab; the device slab and all arithmetic are float64 either way.
     distributed : bool, keyword-only, default False
         One process per GPU under ``torch.distributed`` (e.g. ``torchrun``): every rank runs
         the same script on the same AtomGroup, stages and correlates only its contiguous block
@@ -57,8 +62,17 @@ class VelocityAutocorr(AnalysisBase):
 
     def __init__(self, atomgroup, dim_type="xyz", fft=True, **kwargs):
         self._want_by_particle = bool(kwargs.pop("by_particle", True))
-        self._device = int(kwargs.pop("device", os.environ.get("TA_AMD_DEVICE", 0)))
         self._distributed = bool(kwargs.pop("distributed", False))
+        self._stage_dtype = kwargs.pop("stage_dtype", None)
+        device = kwargs.pop("device", None)
+        if device is None:
+            if self._distributed:  # one process per GPU: this rank's own device
+                from .dist import default_device
+
+                device = default_device()
+            else:
+                device = os.environ.get("TA_AMD_DEVICE", 0)
+        self._device = int(device)
         super().__init__(atomgroup.universe.trajectory, **kwargs)
 
         if isinstance(atomgroup, UpdatingAtomGroup):
@@ -75,6 +89,26 @@ class VelocityAutocorr(AnalysisBase):
 
     _parse_dim_type = staticmethod(parse_dim_type)
 
+    # MDAnalysis >= 2.8 parallel-analysis protocol: frames are staged into ONE device slab per
+    # analysis object and every lag couples all frames, so a frame-split backend cannot apply;
+    # the data-parallel axis of this path is atoms (distributed=True), not frames.
+    _analysis_algorithm_is_parallelizable = False
+
+    @classmethod
+    def get_supported_backends(cls):
+        return ("serial",)
+
+    def _pick_stage_dtype(self):
+        """float32 when the trajectory hands out float32 (MDAnalysis always does); the
+        reference upcasts into a float64 slab (:150-152,192-194), which the device slab is."""
+        if self._stage_dtype is not None:
+            return np.dtype(self._stage_dtype)
+        try:
+            dt = np.asarray(self.atomgroup.velocities).dtype
+        except Exception:  # no velocities: _single_frame raises NoDataError, as the reference does
+            return np.dtype(np.float64)
+        return np.dtype(np.float32) if dt == np.float32 else np.dtype(np.float64)
+
     # ------------------------------------------------------------ hooks
     def _prepare(self):
         """Pinned host slab + device slab instead of ``np.zeros`` (:142-153)."""
@@ -87,9 +121,10 @@ class VelocityAutocorr(AnalysisBase):
             _, _, self._lo, self._hi = shard_of_this_rank(self.n_particles)
             self.results.particle_range = (self._lo, self._hi)
         self._n_local = self._hi - self._lo
+        dtype = self._pick_stage_dtype()
         (self._velocities,) = self._ctx.stage_alloc(
-            self.n_frames, max(self._n_local, 1), self.dim_fac, n_slabs=1)
-        frame_bytes = max(1, self._n_local * self.dim_fac * 8)
+            self.n_frames, max(self._n_local, 1), self.dim_fac, n_slabs=1, dtype=dtype)
+        frame_bytes = max(1, self._n_local * self.dim_fac * dtype.itemsize)
         self._commit_every = max(1, _COMMIT_BYTES // frame_bytes)
         self._committed = 0
         self.results.vacf_by_particle = None
@@ -117,11 +152,25 @@ class VelocityAutocorr(AnalysisBase):
             self._conclude_simple()
 
     def _conclude_fft(self):
-        ts, bp = self._ctx.vacf_fft(by_particle=self._want_by_particle)
-        self._store(ts, bp)
+        self._compute("fft")
 
     def _conclude_simple(self):
-        ts, bp = self._ctx.vacf_direct(by_particle=self._want_by_particle)
+        self._compute("direct")
+
+    def _compute(self, which):
+        if self._distributed:
+            from .dist import staged_timeseries_on_device, uses_device_reduce
+
+            if uses_device_reduce():  # RCCL: the lag sums stay on the GPU through the reduce
+                ts, bp = staged_timeseries_on_device(self._ctx, which, self.n_frames, self._n_local,
+                                                     self.n_particles, self._device,
+                                                     by_particle=self._want_by_particle)
+                self.results.vacf_by_particle = bp
+                self.results.timeseries = ts
+                self._run_called = True
+                return
+        fn = self._ctx.vacf_fft if which == "fft" else self._ctx.vacf_direct
+        ts, bp = fn(by_particle=self._want_by_particle)
         self._store(ts, bp)
 
     def _store(self, ts, bp):

@@ -56,8 +56,17 @@ class ViscosityHelfand(AnalysisBase):
     def __init__(self, atomgroup, temp_avg=300.0, dim_type="xyz", linear_fit_window=None,
                  **kwargs):
         self._want_by_particle = bool(kwargs.pop("by_particle", True))
-        self._device = int(kwargs.pop("device", os.environ.get("TA_AMD_DEVICE", 0)))
         self._distributed = bool(kwargs.pop("distributed", False))
+        self._stage_dtype = kwargs.pop("stage_dtype", None)
+        device = kwargs.pop("device", None)
+        if device is None:
+            if self._distributed:  # one process per GPU: this rank's own device
+                from .dist import default_device
+
+                device = default_device()
+            else:
+                device = os.environ.get("TA_AMD_DEVICE", 0)
+        self._device = int(device)
         self._float32 = bool(kwargs.pop("float32", False))
         self._fft = bool(kwargs.pop("fft", False))
         if self._fft and self._float32:
@@ -78,6 +87,25 @@ class ViscosityHelfand(AnalysisBase):
 
     _parse_dim_type = staticmethod(parse_dim_type)
 
+    # see VelocityAutocorr: atoms, not frames, are this path's parallel axis
+    _analysis_algorithm_is_parallelizable = False
+
+    @classmethod
+    def get_supported_backends(cls):
+        return ("serial",)
+
+    def _pick_stage_dtype(self):
+        """float32 when the trajectory hands out float32 velocities AND positions (MDAnalysis
+        does): lossless, half the PCIe bytes; the device slabs are float64 (:128-134)."""
+        if self._stage_dtype is not None:
+            return np.dtype(self._stage_dtype)
+        try:
+            f32 = (np.asarray(self.atomgroup.velocities).dtype == np.float32
+                   and np.asarray(self.atomgroup.positions).dtype == np.float32)
+        except Exception:  # missing data: _single_frame raises NoDataError, as the reference does
+            return np.dtype(np.float64)
+        return np.dtype(np.float32) if f32 else np.dtype(np.float64)
+
     def _prepare(self):
         """Two pinned slabs (velocities, positions) + volumes + masses (:111-142)."""
         if self._ctx is None:
@@ -91,14 +119,15 @@ class ViscosityHelfand(AnalysisBase):
             _, _, self._lo, self._hi = shard_of_this_rank(self.n_particles)
             self.results.particle_range = (self._lo, self._hi)
         self._n_local = self._hi - self._lo
+        dtype = self._pick_stage_dtype()
         self._velocities, self._positions = self._ctx.stage_alloc(
-            self.n_frames, max(self._n_local, 1), self.dim_fac, n_slabs=2)
+            self.n_frames, max(self._n_local, 1), self.dim_fac, n_slabs=2, dtype=dtype)
         self._volumes = np.zeros(self.n_frames)
         self._masses = np.asarray(self.atomgroup.masses, dtype=np.float64)[self._lo:self._hi]
         if self._n_local == 0:
             self._masses = np.ones(1)
         self.boltzmann = BOLTZMANN
-        frame_bytes = max(1, 2 * self._n_local * self.dim_fac * 8)
+        frame_bytes = max(1, 2 * self._n_local * self.dim_fac * dtype.itemsize)
         self._commit_every = max(1, _COMMIT_BYTES // frame_bytes)
         self._committed = 0
         self.results.visc_by_particle = None
@@ -127,8 +156,18 @@ class ViscosityHelfand(AnalysisBase):
         self._vol_avg = np.average(self._volumes)
         # everything is divided by 2 kB <V> T (:229-231)
         scale = 1.0 / (2 * self.boltzmann * self._vol_avg * self.temp_avg)
-        ts, bp = self._ctx.helfand_msd(self._masses, scale, by_particle=self._want_by_particle)
+        device_reduce = False
         if self._distributed:
+            from .dist import staged_timeseries_on_device, uses_device_reduce
+
+            device_reduce = uses_device_reduce()
+        if device_reduce:  # RCCL: the lag sums stay on the GPU through the reduce
+            ts, bp = staged_timeseries_on_device(self._ctx, "helfand", self.n_frames, self._n_local,
+                                                 self.n_particles, self._device, masses=self._masses,
+                                                 scale=scale, by_particle=self._want_by_particle)
+        else:
+            ts, bp = self._ctx.helfand_msd(self._masses, scale, by_particle=self._want_by_particle)
+        if self._distributed and not device_reduce:
             from .dist import allreduce_mean_over_atoms
 
             if self._n_local == 0:
