@@ -46,6 +46,7 @@ struct ta_ctx {
     std::map<int, cd*> wf_tables;            // wfft.hip tables, keyed by R0
     DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, bounce, stage_buf, long_scratch, helf_p, helf_small;
     DevBuf pm_in[2];  // pair-major copies of frame-major *_dev inputs
+    DevBuf bp_scratch;  // atom-major by-particle results before the transposition
     // staging: pinned host slabs keep the reference's (n_frames, n_atoms, dim) layout, the
     // device slabs are pair-major (layout.hip) with st_pitch rows per column pair
     int64_t st_T = 0, st_A = 0, st_pitch = 0;
@@ -306,13 +307,22 @@ int direct_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos,
         if ((rc = ensure(ctx, ctx->stage_buf, col * rows))) return rc;
         stage_buf = ctx->stage_buf.p;
     }
+    // by-particle values leave the kernel atom-major (contiguous stores) and are transposed
+    // into the caller's (n_frames, ld_bp) array afterwards
+    double* bp_am = nullptr;
+    const int64_t Tp = pm_pitch(T);
+    if (d_bp) {
+        if ((rc = ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp))) return rc;
+        bp_am = (double*)ctx->bp_scratch.p;
+    }
     TA_HIP_TRY(ctx, hipMemsetAsync(ctx->ts_partial.p, 0, sizeof(double) * rows * T, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    TA_HIP_TRY(ctx, launch_direct(mode, f32, L, d_vel, d_pos, d_masses, pitch, (int)T, A, D, scale, d_bp,
-                                  ld_bp, (double*)ctx->ts_partial.p, (int)nwg, nt, lds, stage_buf,
+    TA_HIP_TRY(ctx, launch_direct(mode, f32, L, d_vel, d_pos, d_masses, pitch, (int)T, A, D, scale, bp_am,
+                                  Tp, (double*)ctx->ts_partial.p, (int)nwg, nt, lds, stage_buf,
                                   gnt, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)rows, T, d_lagsum, st));
+    if (d_bp) TA_HIP_TRY(ctx, launch_bp_transpose(bp_am, Tp, A, T, d_bp, ld_bp, nullptr, st));
     return TA_OK;
 }
 
@@ -429,15 +439,23 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         if (nwg >= 8) nwg -= nwg % 8;
         const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * acc_blk;
         if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
+        // lag values leave the kernel atom-major (512-byte stores per wave); the transposition
+        // into the caller's (n_frames, ld_bp) array also adds up its 64 atoms per lag
+        const int64_t Tp = pm_pitch(T);
+        const int64_t n_tiles = (A + 63) / 64;
+        if ((rc = ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp))) return rc;
+        if ((rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T))) return rc;
         a.partial = (double*)ctx->partial.p;
-        a.by_particle = d_bp;
-        a.ld_bp = ld_bp;
+        a.by_particle = (double*)ctx->bp_scratch.p;
+        a.ld_bp = Tp;
         TA_HIP_TRY(ctx, hipMemsetAsync(a.partial, 0, acc_bytes, st));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
         TA_HIP_TRY(ctx, plan->by_particle((int)nwg, st, a));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-        // lag sums = row sums of the by-particle array (velocityautocorr.py:214)
-        TA_HIP_TRY(ctx, launch_row_sums(d_bp, T, A, ld_bp, d_lagsum, st));
+        TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp,
+                                            (double*)ctx->ts_partial.p, st));
+        // lag sums = sums over atoms of the by-particle values (velocityautocorr.py:214)
+        TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)n_tiles, T, d_lagsum, st));
     }
     return TA_OK;
 }
@@ -640,7 +658,7 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     }
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
                       &ctx->masses, &ctx->bounce, &ctx->stage_buf, &ctx->long_scratch, &ctx->helf_p,
-                      &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1]})
+                      &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1], &ctx->bp_scratch})
         if (b->p) hipFree(b->p);
     for (auto& q : ctx->ring)
         for (auto& ev : q)
@@ -656,7 +674,8 @@ int ta_trim(ta_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_bp, &ctx->bounce, &ctx->stage_buf,
-                      &ctx->long_scratch, &ctx->helf_p, &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1]})
+                      &ctx->long_scratch, &ctx->helf_p, &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1],
+                      &ctx->bp_scratch})
         if (b->p) {
             hipFree(b->p);
             b->p = nullptr;

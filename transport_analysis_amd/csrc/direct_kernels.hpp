@@ -314,7 +314,8 @@ __global__ void __launch_bounds__(1024)
                         if (k < T) {
                             double val = (h ? acc2[a] : acc1[a]) / (double)(T - k);
                             if (MODE == MODE_HELFAND) val = (k == 0) ? 0.0 : (val / (double)D) * scale;
-                            if (by_particle) by_particle[(long)k * ld_bp + atom] = val;
+                            // atom-major scratch (ld_bp = row pitch >= T), transposed afterwards
+                            if (by_particle) by_particle[(long)atom * ld_bp + k] = val;
                             ts_out[k] += val;
                         }
                     }

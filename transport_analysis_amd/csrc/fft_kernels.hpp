@@ -716,7 +716,9 @@ __global__ void __launch_bounds__(P::NT)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int n = n0 + k * P::NT;
-                        if (n < T) by_particle[(long)n * ld_bp + atom] = val[k];
+                        // atom-major scratch (ld_bp = row pitch >= T): a wave stores 512 contiguous
+                        // bytes; k_bp_transpose turns it into the caller's (n_frames, n_atoms) array
+                        if (n < T) by_particle[(long)atom * ld_bp + n] = val[k];
                     }
                 }
                 agpr_fence<P>();

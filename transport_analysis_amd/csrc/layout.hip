@@ -65,6 +65,38 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// By-particle results leave the correlators atom-major (src[atom * src_ld + lag], contiguous
+// stores); the caller's array is (n_frames, ld_bp) like results.vacf_by_particle
+// (velocityautocorr.py:145-147).  64 x 64 tiles through LDS, both sides coalesced; with
+// `partial` the tile also adds its 64 atoms per lag: partial[tile_a][lag] (the mean over atoms,
+// velocityautocorr.py:214, summed over tiles in a fixed order afterwards).
+__global__ void __launch_bounds__(256)
+    k_bp_transpose(const double* __restrict__ src, long src_ld, long n_atoms, long T,
+                   double* __restrict__ bp, long ld_bp, double* __restrict__ partial) {
+    __shared__ double tile[64][65];
+    const int tid = threadIdx.x;
+    const long a0 = (long)blockIdx.x * 64, t0 = (long)blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int a = i * 4 + (tid >> 6), t = tid & 63;
+        double v = 0.0;
+        if (a0 + a < n_atoms && t0 + t < T) v = src[(a0 + a) * src_ld + t0 + t];
+        tile[a][t] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int t = i * 4 + (tid >> 6), a = tid & 63;
+        if (a0 + a < n_atoms && t0 + t < T) bp[(t0 + t) * ld_bp + a0 + a] = tile[a][t];
+    }
+    if (partial && tid < 64 && t0 + tid < T) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int a = 0; a < 64; ++a) s += tile[a][tid];  // rows past n_atoms hold zeros
+        partial[(long)blockIdx.x * T + t0 + tid] = s;
+    }
+}
+
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     unsigned long long z = x + 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -119,6 +151,14 @@ hipError_t launch_unlayout(const double* pm, long pitch, long n_cols, long t_cou
                            long ld_row, hipStream_t st) {
     if (t_count <= 0 || n_cols <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_unlayout, dim3(2048), dim3(256), 0, st, pm, pitch, n_cols, t_count, dst, ld_row);
+    return hipGetLastError();
+}
+
+hipError_t launch_bp_transpose(const double* src, long src_ld, long n_atoms, long T, double* bp, long ld_bp,
+                               double* partial, hipStream_t st) {
+    if (T <= 0 || n_atoms <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bp_transpose, dim3((unsigned)((n_atoms + 63) / 64), (unsigned)((T + 63) / 64)), dim3(256),
+                       0, st, src, src_ld, n_atoms, T, bp, ld_bp, partial);
     return hipGetLastError();
 }
 

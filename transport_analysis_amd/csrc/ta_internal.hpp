@@ -91,6 +91,9 @@ hipError_t launch_relayout(const void* src, bool src_f32, long ld_row, long n_co
                            double* dst, long pitch, long t_dst0, hipStream_t st);
 hipError_t launch_unlayout(const double* pm, long pitch, long n_cols, long t_count, double* dst,
                            long ld_row, hipStream_t st);
+// atom-major by-particle scratch -> (n_frames, ld_bp); partial: [ceil(n_atoms/64)][T] or NULL
+hipError_t launch_bp_transpose(const double* src, long src_ld, long n_atoms, long T, double* bp, long ld_bp,
+                               double* partial, hipStream_t st);
 hipError_t launch_synth(double* pm, long pitch, long n_cols, long T, unsigned long long seed,
                         long col_offset, long n_cols_total, hipStream_t st);
 
