@@ -693,3 +693,91 @@ def test_classes_float32_and_float64_staging_bit_equal(fft):
         assert h32._positions.dtype == np.float32
         assert np.array_equal(h32.results.timeseries, h64.results.timeseries)
         assert np.array_equal(h32.results.visc_by_particle, h64.results.visc_by_particle)
+
+
+def test_helfand_config4_full_per_gpu_share(ctx):
+    """BASELINE configs[4] at ONE GPU's full share: 20000 frames x 25000 atoms x 3, float32 path,
+    staged pair-major (viscosity.py:210-226 is the loop replaced).  Size-independent checks:
+    lag 0 exactly 0; selected lags against float64 slab differences over the whole block; the
+    lag sums of the two half blocks add up to the whole's."""
+    import torch
+
+    T, A, D = 20000, 25000, 3
+    st = torch.cuda.current_stream().cuda_stream
+    m = torch.tensor([15.999, 1.008, 1.008], dtype=torch.float64, device="cuda").repeat((A + 2) // 3)[:A].contiguous()
+
+    def stage(lo, hi):
+        n = hi - lo
+        ctx.stage_alloc_device(T, n, D, n_slabs=2)
+        ctx.stage_synth(0, 20250824 + 5, lo * D, A * D, st)
+        fm = torch.empty((T, n * D), dtype=torch.float64, device="cuda")
+        ctx.stage_read_dev(0, fm.data_ptr(), n * D, st)
+        xm = 30.0 + 0.002 * torch.cumsum(fm, dim=0)
+        ctx.stage_commit_dev(1, xm.data_ptr(), n * D, 0, T, stream=st)
+        torch.cuda.synchronize()
+        return fm, xm
+
+    ctx.set_option("direct_f32", 1)
+    try:
+        v, x = stage(0, A)
+        whole = torch.zeros(T, dtype=torch.float64, device="cuda")
+        ctx.helfand_msd_staged(m.data_ptr(), 1.0, whole.data_ptr(), 0, A, st)
+        torch.cuda.synchronize()
+        assert float(whole[0].item()) == 0.0
+        P = (m[None, :, None] * v.view(T, A, D)) * x.view(T, A, D)
+        scale = None
+        for k in (1, 7, 1000, T // 2, T - 1):
+            w = float(((P[: T - k] - P[k:]) ** 2).sum().item()) / (T - k) / D
+            scale = scale or w
+            assert abs(float(whole[k].item()) - w) < TOL_F32 * max(w, scale), (k, float(whole[k].item()), w)
+        del v, x, P
+        torch.cuda.empty_cache()
+        parts = torch.zeros(T, dtype=torch.float64, device="cuda")
+        for lo, hi in ((0, A // 2), (A // 2, A)):
+            v, x = stage(lo, hi)
+            del v, x
+            part = torch.zeros(T, dtype=torch.float64, device="cuda")
+            ctx.helfand_msd_staged(m[lo:hi].contiguous().data_ptr(), 1.0, part.data_ptr(), 0, hi - lo, st)
+            torch.cuda.synchronize()
+            parts += part
+        assert float((parts - whole).abs().max().item()) < TOL_F32 * float(whole.abs().max().item())
+    finally:
+        ctx.set_option("direct_f32", 0)
+        ctx.stage_free()
+        ctx.trim()
+        torch.cuda.empty_cache()
+
+
+def test_vacf_by_particle_config2_full_size(ctx):
+    """The reference's default output at BASELINE configs[2]'s size on one GPU: 10000 x 100000 x 3
+    with the (n_frames, n_atoms) by-particle array (8 GB).  The mean over atoms of the array is
+    the lag-sum path's timeseries (velocityautocorr.py:214), a block of atoms agrees with the
+    oracle, and every row of the array is written."""
+    import torch
+
+    from oracle import numpy_oracle as orc
+    from oracle import synth
+
+    T, A, D = 10000, 100000, 3
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.stage_alloc_device(T, A, D, n_slabs=1)
+    ctx.stage_synth(0, 20250824 + 3, 0, A * D, st)
+    bp = torch.full((T, A), float("nan"), dtype=torch.float64, device="cuda")
+    lag_bp = torch.zeros(T, dtype=torch.float64, device="cuda")
+    lag_ts = torch.zeros(T, dtype=torch.float64, device="cuda")
+    ctx.vacf_fft_staged(lag_bp.data_ptr(), bp.data_ptr(), A, st)
+    ctx.vacf_fft_staged(lag_ts.data_ptr(), 0, 0, st)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(bp).any().item())
+    scale = float(lag_ts.abs().max().item())
+    assert float((lag_bp - lag_ts).abs().max().item()) < TOL * scale
+    assert float((bp.sum(dim=1) - lag_ts).abs().max().item()) < TOL * scale
+    for lo in (0, 49999, A - 4):
+        v = synth.synthetic_block(20250824 + 3, T, A * D, lo * D, (lo + 4) * D).reshape(T, 4, D)
+        want, _ = orc.vacf_fft_batched(v)
+        got = bp[:, lo:lo + 4].cpu().numpy()
+        assert scale_rel_err(got, want) < TOL
+    del bp
+    ctx.stage_free()
+    ctx.trim()
+    torch.cuda.empty_cache()

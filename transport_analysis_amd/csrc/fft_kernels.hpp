@@ -43,8 +43,10 @@ namespace ta {
 // gathered column pair (up to 40 complex f64 = 160 dwords per thread) and one
 // accumulator set (up to 48 f64 = 96 dwords) are "cold" for most of an iteration and
 // are kept there EXPLICITLY, at fixed register numbers, through the accessors of
-// agpr_slots.inc (inline asm; the file is compiled with
-// -mllvm -amdgpu-spill-vgpr-to-agpr=0 so the compiler itself never touches an AGPR).
+// agpr_slots.inc (inline asm).  The compiler DOES use AGPRs of its own under pressure and cannot
+// be told the manual slots are live: code-free clobber fences keep its live ranges below the
+// manual range and tools/check_agpr.py (a Makefile step on the generated ISA) fails the build
+// if any compiler-owned instruction reads or writes inside it.
 // That makes the software pipeline deterministic: the gather is issued as
 // global_load_dwordx4 with an AGPR destination, nobody waits for it or spills it, and
 // the compiler's own 256 VGPRs are left for one butterfly's working set.

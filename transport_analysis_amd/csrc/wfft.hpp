@@ -245,6 +245,9 @@ __device__ __forceinline__ void wf_sub512_x2(cd* __restrict__ reg0, cd* __restri
 #ifndef WF_SI
 #define WF_SI 1   // first-stage stores interleaved with the output twiddles
 #endif
+#ifndef WF_SPRE
+#define WF_SPRE 0   // split kernel: first-stage butterfly before the barrier that frees the LDS
+#endif
 #ifndef WF_TWRES
 #define WF_TWRES 1  // split kernel: stage twiddles resident in registers (1) or re-loaded per pair (0)
 #endif
@@ -519,6 +522,11 @@ __global__ void __launch_bounds__(P::NT)
             for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
         }
         Dft<R0>::run(x);
+#if WF_SPRE
+        // everything above is register work: it runs BEFORE the barrier that frees the LDS, so a
+        // wave that owns one sub-series fewer does its butterfly while the others finish
+        __syncthreads();
+#endif
 #if WF_TW1
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -596,7 +604,9 @@ __global__ void __launch_bounds__(P::NT)
             }
         });
         WF_STAMP(1)
+#if !WF_SPRE
         __syncthreads();
+#endif
     }
     double* out = accg + couple * 2 * P::M;
 #pragma unroll
