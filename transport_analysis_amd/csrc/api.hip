@@ -393,6 +393,26 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         TA_HIP_TRY(ctx, fin->finalize(st, fa));
         return TA_OK;
     }
+    if (d_bp && T > 512 && wfft_choose((long)T, &R0) && ctx->opt_fft_debug != 3) {
+        // by-particle mode on the wave-local machinery (k_wbp): per-atom lag values to an
+        // atom-major scratch (512-byte stores), then the transposition into the caller's
+        // (n_frames, ld_bp) array, which also adds up its 64 atoms per lag
+        cd* tw = nullptr;
+        if ((rc = get_wf_table(ctx, R0, &tw))) return rc;
+        const int64_t Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
+        int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * wfft_max_wg_per_cu(R0);
+        nwg = std::max<int64_t>(1, std::min(nwg, A));
+        if ((rc = ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp))) return rc;
+        if ((rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T))) return rc;
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+        TA_HIP_TRY(ctx, launch_wfft_by_particle(R0, (int)nwg, st, pm, pitch, (int)T, A, D, tw,
+                                                (double*)ctx->bp_scratch.p, Tp));
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+        TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp,
+                                            (double*)ctx->ts_partial.p, st));
+        TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)n_tiles, T, d_lagsum, st));
+        return TA_OK;
+    }
     const PlanEntry* plan = find_plan(T);
     int long_M = 0, long_R = 0;
     if (!plan && !d_bp && fft_long_choose((long)T, &long_M, &long_R))

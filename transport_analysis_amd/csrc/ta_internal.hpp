@@ -104,6 +104,9 @@ void wfft_fill_table(int R0, cd* table);
 int wfft_max_wg_per_cu(int R0);
 hipError_t launch_wfft_accum(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
                              long n_pairs, const cd* tw, double* accg /* [nwg][2M], natural order */);
+// by-particle mode (k_wbp): lag values of every atom, atom-major out[atom * ld + lag]
+hipError_t launch_wfft_by_particle(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
+                                   long n_atoms, int D, const cd* tw, double* out, long ld);
 // pass-split form: nwg a multiple of 16, accg [nwg/2][2M] (every element written by the launch)
 hipError_t launch_wfft_split(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
                              long n_pairs, const cd* tw, double* accg);

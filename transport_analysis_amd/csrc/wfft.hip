@@ -38,6 +38,18 @@ hipError_t launch_split_r0(int nwg, hipStream_t st, const double* pm, long pitch
 }
 
 template <int R0>
+hipError_t launch_bp_r0(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_atoms, int D,
+                        const cd* tw, double* out, long ld) {
+    using P = WPlan<R0>;
+    auto kern = k_wbp<P, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_atoms, D, tw, out, ld, nullptr);
+    return hipGetLastError();
+}
+
+template <int R0>
 int max_wg_r0() {
     using P = WPlan<R0>;
     auto kern = k_wfft_accum<P, false, WF_TOUCH_DEFAULT, WF_INTER_DEFAULT>;
@@ -161,6 +173,20 @@ hipError_t launch_wfft_sum_perm(const double* partial, int n_parts, int M, const
                                 hipStream_t st) {
     hipLaunchKernelGGL(k_wf_sum_perm, dim3((2 * M + 255) / 256), dim3(256), 0, st, partial, n_parts, M, perm, spec);
     return hipGetLastError();
+}
+
+hipError_t launch_wfft_by_particle(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
+                                   long n_atoms, int D, const cd* tw, double* out, long ld) {
+    switch (R0) {
+        case 2: return launch_bp_r0<2>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
+        case 4: return launch_bp_r0<4>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
+        case 5: return launch_bp_r0<5>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
+        case 8: return launch_bp_r0<8>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
+        case 10: return launch_bp_r0<10>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
+        case 16: return launch_bp_r0<16>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
+        case 20: return launch_bp_r0<20>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_wfft_split(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,

@@ -792,4 +792,252 @@ __global__ void __launch_bounds__(256, 2)
 #undef WF_STAMP
 }
 
+
+// ================================================================================================
+// By-particle mode: results.vacf_by_particle (velocityautocorr.py:145-147, 210-214).
+//
+// A workgroup takes whole atoms.  An atom's columns are transformed as one or two UNITS (its
+// 16-byte aligned column pair as a complex series, a single column as a real one), both passes
+// each, and |.|^2 is accumulated in registers as in the lag-sum kernels -- sub-series q of BOTH
+// passes belongs to wave q % 8, so a lane holds P_A[j] and P_B[j] of the same bins j.  After the
+// atom's last unit those accumulators ARE its power spectrum; its lag values are one M-point
+// transform of P_A + i P_B, run by the TRANSPOSE of the forward algorithm (the DFT matrix is
+// symmetric): input in the accumulators' own bin order, output in natural order:
+//   sub-series q (registers c = 0..7 of lane 8a + b: bin a + 8b + 64c)
+//     -> DFT8 over c, x W_64^{b n0} -> exchange -> DFT8 over b -> exchange, x W_512^{l a}
+//     -> DFT8 over a -> G_q[64 n2 + l] to LDS           (same exchange layouts as forward)
+//   thread u: Q[u + 512 j'] = DFT_R0 over q of G_q[u] W_M^{uq}
+// and with Qm[n] = Q[M - n] (one more trip through LDS, natural order):
+//   lag[n] = ( Re(Q+Qm)/2 + cos(pi n/M) Im(Q+Qm)/2 - sin(pi n/M) Re(Q-Qm)/2 ) / (2M (T - n)).
+// Output: atom-major scratch out[atom * ld + n] (512-byte stores), transposed afterwards.
+struct WfSubT {
+    int lane, hi, lo;
+    __device__ __forceinline__ explicit WfSubT(int lane_) : lane(lane_) {
+        asm volatile("" : "+v"(lane));
+        hi = lane >> 3;
+        lo = lane & 7;
+    }
+    // v[c] (bins of this lane) -> the sub-series' transform G[64 n2 + lane] stored at reg
+    __device__ __forceinline__ void run(cd* __restrict__ reg, cd (&v)[8], const cd (&twa)[7],
+                                        const cd (&twb)[7]) const {
+        Dft<8>::run(v);  // over c -> n0
+#pragma unroll
+        for (int n0 = 1; n0 < 8; ++n0) v[n0] = cmul(v[n0], twb[n0 - 1]);  // W_64^{b n0}, b = lane & 7
+        __builtin_amdgcn_wave_barrier();
+        const int x = lo ^ hi;
+#pragma unroll
+        for (int n0 = 0; n0 < 8; ++n0) reg[(hi * 8 + n0) * 8 + (x ^ n0)] = v[n0];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v[b] = reg[lane * 8 + (b ^ x)];  // lane = (a, n0)
+        __builtin_amdgcn_wave_barrier();
+        Dft<8>::run(v);  // over b -> n1
+        __builtin_amdgcn_wave_barrier();
+        const int base = hi * 64 + (lo ^ (8 * (hi & 1)));
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) reg[base ^ (8 * n1)] = v[n1];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int a = 0; a < 8; ++a) v[a] = reg[a * 64 + (lane ^ (8 * (a & 1)))];  // lane = l = 8 n1 + n0
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int a = 1; a < 8; ++a) v[a] = cmul(v[a], twa[a - 1]);  // W_512^{l a}
+        Dft<8>::run(v);  // over a -> n2
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) reg[64 * n2 + lane] = v[n2];
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+// pm: pair-major slab of the shard (n_atoms * D columns); out: [n_atoms][ld] atom-major lags.
+template <class P, bool STAMP = false>
+__global__ void __launch_bounds__(P::NT)
+    k_wbp(const double* __restrict__ pm, long pitch, int T, long n_atoms, int D,
+          const cd* __restrict__ tw2, double* __restrict__ out, long ld,
+          unsigned long long* __restrict__ stamps = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd* lds = reinterpret_cast<cd*>(smem_raw);
+    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW, M = P::M;
+    constexpr int NSA = (R0 + NW - 1) / NW;  // sub-series per wave and pass: q = wave + 8 s
+    int tid = threadIdx.x, lane = tid & 63;
+    const int wave = tid >> 6;
+    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cd*>(tw2), 0, (4 * M + 14 * 64) * 16, 0x00020000);
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
+    if constexpr (STAMP) st_prev = __builtin_amdgcn_s_memtime();
+#define WF_STAMP(i)                                                   \
+    if constexpr (STAMP) {                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] += now_ - st_prev;                                  \
+        st_prev = now_;                                               \
+    }
+    // units of an atom: (pair index, kind) with kind 2 = both columns of the pair (complex
+    // series), 0 / 1 = only that half (real series)
+    const int n_units = D == 3 ? 2 : 1;
+    auto unit_of = [&](long atom, int k, long* pair, int* kind) {
+        const long c0 = atom * D;
+        if (D == 2) {
+            *pair = atom, *kind = 2;
+        } else if (D == 1) {
+            *pair = c0 >> 1, *kind = (int)(c0 & 1);
+        } else if ((c0 & 1) == 0) {  // even first column: (x, y) aligned, z alone
+            if (k == 0) *pair = c0 >> 1, *kind = 2;
+            else *pair = (c0 >> 1) + 1, *kind = 0;
+        } else {                     // x alone (second half of a pair), (y, z) aligned
+            if (k == 0) *pair = c0 >> 1, *kind = 1;
+            else *pair = (c0 >> 1) + 1, *kind = 2;
+        }
+    };
+    cd x[R0], g, g2, h;
+    auto issue_loads = [&](long pair) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double*>(pm + pair * pitch * 2), 0, T * 16, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < R0; ++j) x[j] = wf_load(rs, (unsigned)tid * 16u, (unsigned)(N1 * j) * 16u);
+    };
+    auto load_seeds = [&]() {  // after the butterfly: its temporaries are dead by then
+        g = wf_load(twr, (unsigned)tid * 32u, 0u);
+        g2 = wf_load(twr, (unsigned)tid * 64u, 0u);
+        h = wf_load(twr, (unsigned)tid * 16u, 0u);
+    };
+    auto load_stage_tw = [&](cd (&twa)[7], cd (&twb)[7]) {
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+            twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * M + a * 64) * 16u);
+            twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * M + (7 + a) * 64) * 16u);
+        }
+    };
+
+    for (long atom = blockIdx.x; atom < n_atoms; atom += gridDim.x) {
+        double accA[NSA][8], accB[NSA][8];
+#pragma unroll
+        for (int s = 0; s < NSA; ++s)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) accA[s][c] = accB[s][c] = 0.0;
+        for (int k = 0; k < n_units; ++k) {
+            long pair;
+            int kind;
+            unit_of(atom, k, &pair, &kind);
+            auto one_pass = [&](auto BB, double (&acc)[NSA][8]) {
+                constexpr int B = decltype(BB)::value;
+                // per-thread offsets and LDS addresses are re-formed per pass: hoisted out of the
+                // atom loop they would be spilled
+                asm volatile("" : "+v"(tid), "+v"(lane));
+                // (requesting the rows a pass ahead costs more in scratch traffic than the
+                // latency it hides here: measured 24.7 -> 31.2 ms at 10000 x 100000 x 3)
+                issue_loads(pair);
+                if (kind != 2) {  // a single real column: the other half of the rows is not ours
+#pragma unroll
+                    for (int j = 0; j < R0; ++j) x[j] = cd{kind ? x[j].y : x[j].x, 0.0};
+                }
+                if constexpr (B == 1) {
+#pragma unroll
+                    for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
+                }
+                Dft<R0>::run(x);
+                __builtin_amdgcn_sched_barrier(0);
+                load_seeds();
+                {
+                    cd te = B ? h : cd{1.0, 0.0};
+                    cd to = B ? cmul(h, g) : g;
+                    if constexpr (B == 1) x[0] = cmul(x[0], te);
+                    lds[tid] = x[0];
+                    if constexpr (R0 > 1) {
+                        x[1] = cmul(x[1], to);
+                        lds[N1 + tid] = x[1];
+                    }
+#pragma unroll
+                    for (int q = 2; q < R0; ++q) {
+                        if (q & 1) {
+                            to = cmul(to, g2);
+                            x[q] = cmul(x[q], to);
+                        } else {
+                            te = cmul(te, g2);
+                            x[q] = cmul(x[q], te);
+                        }
+                        lds[q * N1 + tid] = x[q];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cd twa[7], twb[7];
+                load_stage_tw(twa, twb);
+                WF_STAMP(0)
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < NSA; ++s) {
+                    const int q = wave + NW * s;
+                    if (NW * s + NW - 1 < R0 || q < R0) wf_sub512(lds + q * N1, lane, twa, twb, acc[s]);
+                }
+                WF_STAMP(1)
+                __syncthreads();
+            };
+            one_pass(std::integral_constant<int, 0>{}, accA);
+            one_pass(std::integral_constant<int, 1>{}, accB);
+        }
+        // ---- the atom's lag values: transposed transform of P_A + i P_B
+        asm volatile("" : "+v"(tid), "+v"(lane));
+        {
+            cd twa[7], twb[7];
+            load_stage_tw(twa, twb);
+            const WfSubT wt(lane);
+#pragma unroll
+            for (int s = 0; s < NSA; ++s) {
+                const int q = wave + NW * s;
+                if (NW * s + NW - 1 < R0 || q < R0) {
+                    cd v[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = cd{accA[s][c], accB[s][c]};
+                    wt.run(lds + q * N1, v, twa, twb);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            load_seeds();  // g = W_M^u
+#pragma unroll
+            for (int q = 0; q < R0; ++q) x[q] = lds[q * N1 + tid];
+            cd te = cd{1.0, 0.0}, to = g;
+            if constexpr (R0 > 1) x[1] = cmul(x[1], to);
+#pragma unroll
+            for (int q = 2; q < R0; ++q) {
+                if (q & 1) {
+                    to = cmul(to, g2);
+                    x[q] = cmul(x[q], to);
+                } else {
+                    te = cmul(te, g2);
+                    x[q] = cmul(x[q], te);
+                }
+            }
+            Dft<R0>::run(x);  // x[j'] = Q[tid + 512 j']
+        }
+        __syncthreads();  // every thread has read its G values: LDS free for Q in natural order
+#pragma unroll
+        for (int j = 0; j < R0; ++j) lds[tid + N1 * j] = x[j];
+        __syncthreads();
+        {
+            double* o = out + atom * ld;
+            // Q[M - n] for n = u + 512 j: element (512 - u) + 512 (R0 - 1 - j), u > 0
+            const int mu = tid == 0 ? 0 : N1 - tid;
+#pragma unroll
+            for (int j = 0; j < R0; ++j) {
+                const int n = tid + N1 * j;
+                const int jm = tid == 0 ? (R0 - j) % R0 : R0 - 1 - j;
+                const cd qm = lds[mu + N1 * jm];
+                // W_2M^n = W_2M^u * W_{2 R0}^j = cos - i sin (the second factor lane-uniform)
+                const cd w = j == 0 ? h : cmul(h, tw_uniform(tw2, j * N1));
+                const double ar = 0.5 * (x[j].x + qm.x), br = 0.5 * (x[j].y + qm.y), bi = -0.5 * (x[j].x - qm.x);
+                const double L = ar + (w.x * br - w.y * bi);
+                if (n < T) o[n] = L / (2.0 * (double)M * (double)(T - n));  // 2M(T-n) < 2^53: exact product
+            }
+        }
+        __syncthreads();  // Q consumed before the next atom's first stage overwrites the LDS
+    }
+    if constexpr (STAMP) {
+        if (lane == 0 && wave == 0)
+            for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + i] = st_acc[i];
+    }
+#undef WF_STAMP
+}
+
 }  // namespace ta
