@@ -30,6 +30,11 @@
 
 namespace ta {
 
+#ifndef WF_ABL
+#define WF_ABL 0  // timing ablations (wrong results): 1 no S2, 2 no S1 arithmetic, 3 no row loads,
+                  // 4 no S2 arithmetic (LDS traffic only), 5 no S2 exchanges (arithmetic only)
+#endif
+
 template <int LO, int HI, class F>
 __device__ __forceinline__ void static_for_range(F&& f) {
     [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -164,33 +169,43 @@ struct WfSub {
         for (int n2 = 0; n2 < 8; ++n2) v[n2] = reg[64 * n2 + lane];
     }
     __device__ __forceinline__ void stage_a(cd* __restrict__ reg, cd (&v)[8], const cd (&twa)[7]) const {
+#if WF_ABL != 4
         Dft<8>::run(v);
 #pragma unroll
         for (int a = 1; a < 8; ++a) v[a] = cmul(v[a], twa[a - 1]);
+#endif
         __builtin_amdgcn_wave_barrier();
+#if WF_ABL != 5
 #pragma unroll
         for (int a = 0; a < 8; ++a) reg[a * 64 + (lane ^ (8 * (a & 1)))] = v[a];
         __builtin_amdgcn_wave_barrier();
         const int base = hi * 64 + (lo ^ (8 * (hi & 1)));  // (8 n1 + lo) ^ 8 (hi&1), n1 = 0
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) v[n1] = reg[base ^ (8 * n1)];
+#endif
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ void stage_b(cd* __restrict__ reg, cd (&v)[8], const cd (&twb)[7]) const {
+#if WF_ABL != 4
         Dft<8>::run(v);
 #pragma unroll
         for (int b = 1; b < 8; ++b) v[b] = cmul(v[b], twb[b - 1]);
+#endif
         __builtin_amdgcn_wave_barrier();
+#if WF_ABL != 5
         const int x = lo ^ hi;
 #pragma unroll
         for (int b = 0; b < 8; ++b) reg[(hi * 8 + b) * 8 + (x ^ b)] = v[b];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int n0 = 0; n0 < 8; ++n0) v[n0] = reg[lane * 8 + (n0 ^ x)];
+#endif
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ void stage_c(cd (&v)[8], double (&acc)[8]) const {
+#if WF_ABL != 4
         Dft<8>::run(v);
+#endif
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = fma(v[c].y, v[c].y, fma(v[c].x, v[c].x, acc[c]));
         __builtin_amdgcn_wave_barrier();
@@ -225,6 +240,29 @@ __device__ __forceinline__ void wf_sub512_x2(cd* __restrict__ reg0, cd* __restri
     w.stage_c(v1, acc1);
 }
 
+// Three sub-series interleaved (the waves that own one more than the others: they then finish
+// together with their SIMD partner's two instead of running a third alone).
+__device__ __forceinline__ void wf_sub512_x3(cd* __restrict__ reg0, cd* __restrict__ reg1,
+                                             cd* __restrict__ reg2, int lane, const cd (&twa)[7],
+                                             const cd (&twb)[7], double (&acc0)[8], double (&acc1)[8],
+                                             double (&acc2)[8]) {
+    const WfSub w(lane);
+    cd v0[8], v1[8], v2[8];
+    w.read_a(reg0, v0);
+    w.read_a(reg1, v1);
+    w.read_a(reg2, v2);
+    __builtin_amdgcn_wave_barrier();
+    w.stage_a(reg0, v0, twa);
+    w.stage_a(reg1, v1, twa);
+    w.stage_a(reg2, v2, twa);
+    w.stage_b(reg0, v0, twb);
+    w.stage_b(reg1, v1, twb);
+    w.stage_b(reg2, v2, twb);
+    w.stage_c(v0, acc0);
+    w.stage_c(v1, acc1);
+    w.stage_c(v2, acc2);
+}
+
 // pm: pair-major slab, pair p at pm + p*pitch*2 doubles; T rows are valid, the rest of the
 // transform length is zero padding.  accg: [gridDim.x][2M] float64, natural bin order.
 // tw2: W_2M^n, n < 2M, followed (at tw2 + 2M) by the wave-local stage twiddles [14][64]:
@@ -244,6 +282,9 @@ __device__ __forceinline__ void wf_sub512_x2(cd* __restrict__ reg0, cd* __restri
 #endif
 #ifndef WF_SI
 #define WF_SI 1   // first-stage stores interleaved with the output twiddles
+#endif
+#ifndef WF_X3
+#define WF_X3 1     // split kernel: three sub-series in flight in the waves that own three
 #endif
 #ifndef WF_SPRE
 #define WF_SPRE 0   // split kernel: first-stage butterfly before the barrier that frees the LDS
@@ -516,12 +557,14 @@ __global__ void __launch_bounds__(P::NT)
         const cd g = wf_load(twr, (unsigned)tid * 32u, 0u), g2 = wf_load(twr, (unsigned)tid * 64u, 0u),
                  h = wf_load(twr, (unsigned)tid * 16u, 0u);
 #endif
+#if WF_ABL != 2
         if (passB) {
             // pass B twist, lane-uniform part: W_{2 R0}^j = tw2[j * 512]
 #pragma unroll
             for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
         }
         Dft<R0>::run(x);
+#endif
 #if WF_SPRE
         // everything above is register work: it runs BEFORE the barrier that frees the LDS, so a
         // wave that owns one sub-series fewer does its butterfly while the others finish
@@ -580,6 +623,25 @@ __global__ void __launch_bounds__(P::NT)
         // pair's rows are requested before the LAST slot when that one is a single sub-series
         // (registers allow it there), i.e. about one sub-series time before the barrier.
         const __amdgpu_buffer_rsrc_t nrs = rsrc_of(p + n_couples);
+#if WF_ABL == 1
+        if (T < 0)
+#endif
+#if WF_X3
+        if constexpr (NS1 == 3 && NW * 2 + NW - 1 >= R0 && NW * 1 + NW - 1 < R0) {
+            // two full slots and a partial third: the waves that own three sub-series take them
+            // three at a time, the others two at a time
+            if (wave + 2 * NW < R0)
+                wf_sub512_x3(lds + wave * N1, lds + (wave + NW) * N1, lds + (wave + 2 * NW) * N1, lane, twa, twb,
+                             acc[0], acc[1], acc[2]);
+            else
+                wf_sub512_x2(lds + wave * N1, lds + (wave + NW) * N1, lane, twa, twb, acc[0], acc[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#if WF_ABL != 3
+            issue_loads(nrs);
+#endif
+        } else
+#endif
+        {
         static_for_range<0, NS1>([&](auto ss) {
             constexpr int s = decltype(ss)::value;
             constexpr bool full = NW * s + NW - 1 < R0;             // every wave has this slot
@@ -603,6 +665,7 @@ __global__ void __launch_bounds__(P::NT)
                 issue_loads(nrs);
             }
         });
+        }
         WF_STAMP(1)
 #if !WF_SPRE
         __syncthreads();
