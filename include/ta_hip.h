@@ -188,6 +188,9 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *                      viscosity.py:201-233, which stays the default): ~1e-15 of the series'
  *                      scale, but the relative error of lags whose mean squared difference
  *                      is far below P^2 grows by that ratio.  Needs T*A*D*8 bytes more.
+ *   "bp_block" n     : host-facing calls with a by-particle array process atoms in blocks of n
+ *                      (rounded up to 64; default 16384) so that a block's device->host copy
+ *                      runs under the next block's compute;
  *   "fft_nwg", "direct_nwg" : persistent workgroup counts (0 = automatic);
  *   "direct_chunk" 0|8|10, "direct_groups" n : force the direct correlators' lags per chunk /
  *                      cap the atoms a workgroup works on at once (0 = automatic);

@@ -781,3 +781,29 @@ def test_vacf_by_particle_config2_full_size(ctx):
     ctx.stage_free()
     ctx.trim()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode,D", [("fft", 3), ("fft", 1), ("direct", 2), ("helfand", 3)])
+def test_host_path_by_particle_in_atom_blocks(ctx, mode, D):
+    """Host-facing calls with a by-particle array process atoms in blocks (copy of block c
+    under the compute of block c + 1): same results as one block, block edges on pair
+    boundaries for every dim."""
+    from oracle import numpy_oracle as orc
+
+    T, A = 700, 200
+    v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=5)
+    v, x = v[:, :, :D], x[:, :, :D]
+    ctx.set_option("bp_block", 64)
+    try:
+        if mode == "helfand":
+            ts, bp = run_helfand(ctx, v, x, m, 0.37, True)
+            want_bp, want_ts = orc.helfand(v, x, m, np.ones(T), temp_avg=1.0, boltzmann=0.5)
+            want_bp, want_ts = want_bp * 0.37, want_ts * 0.37
+        else:
+            ts, bp = run_vacf(ctx, v, mode == "fft", True)
+            want_bp, want_ts = orc.vacf_fft_batched(v)
+    finally:
+        ctx.set_option("bp_block", 0)
+    assert bp.shape == (T, A)
+    assert scale_rel_err(bp, want_bp) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL

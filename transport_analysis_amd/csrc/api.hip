@@ -40,6 +40,7 @@ struct ta_ctx {
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // device->host copies of by-particle blocks (host_compute)
     std::string err;
     std::map<int, Tables> tables;
     std::map<long, LongTables> long_tables;  // keyed by M'
@@ -70,6 +71,7 @@ struct ta_ctx {
     int64_t opt_direct_groups = 0;
     int64_t opt_direct_chunk = 0;
     int64_t opt_helfand_fft = 0;
+    int64_t opt_bp_block = 0;
 };
 
 namespace {
@@ -684,6 +686,7 @@ int ta_ctx_destroy(ta_ctx* ctx) {
         for (auto& ev : q)
             if (ev) hipEventDestroy(ev);
     if (ctx->ev_stage) hipEventDestroy(ctx->ev_stage);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return TA_OK;
@@ -713,6 +716,7 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "direct_groups")) ctx->opt_direct_groups = value;
     else if (!strcmp(key, "direct_chunk")) ctx->opt_direct_chunk = value;
     else if (!strcmp(key, "helfand_fft")) ctx->opt_helfand_fft = value;
+    else if (!strcmp(key, "bp_block")) ctx->opt_bp_block = value;
     else return fail(ctx, TA_E_INVALID, std::string("unknown option ") + key);
     return TA_OK;
 }
@@ -954,6 +958,43 @@ static int host_compute(ta_ctx* ctx, int which, const double* h_masses, double s
         TA_HIP_TRY(ctx, hipMemcpyAsync(ctx->masses.p, h_masses, sizeof(double) * A, hipMemcpyHostToDevice,
                                        ctx->stream));
         d_m = (const double*)ctx->masses.p;
+    }
+    // With a by-particle array the device->host copy (8 GB at 10000 x 100000) is several times
+    // the compute: atoms go in blocks, the copy of block c (a strided 2-D copy into the caller's
+    // (n_frames, n_atoms) array, on a second stream) runs under the compute of block c + 1.
+    const int64_t CH = ctx->opt_bp_block > 0 ? (ctx->opt_bp_block + 63) / 64 * 64 : 16384;
+    if (h_bp && A >= 2 * CH) {
+        const int64_t n_blocks = (A + CH - 1) / CH;
+        if ((rc = ensure(ctx, ctx->out_lagsum, sizeof(double) * T * n_blocks))) return rc;
+        d_ls = (double*)ctx->out_lagsum.p;
+        if (!ctx->copy_stream) TA_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        std::vector<double> part((size_t)T * n_blocks);
+        const int D = ctx->st_D;
+        for (int64_t b = 0; b < n_blocks; ++b) {
+            const int64_t lo = b * CH, hi = std::min(A, lo + CH);
+            const int64_t pair_lo = lo * D / 2;  // lo is a multiple of 64: a pair boundary
+            const double* v = ctx->d_slabs[0] + pair_lo * ctx->st_pitch * 2;
+            const double* x = need == 2 ? ctx->d_slabs[1] + pair_lo * ctx->st_pitch * 2 : nullptr;
+            if ((rc = compute_pm(ctx, which, v, x, d_m ? d_m + lo : nullptr, ctx->st_pitch, T, hi - lo, D, scale,
+                                 d_ls + b * T, d_bp + lo, A, ctx->stream, true)))
+                return rc;
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
+            TA_HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_stage, 0));
+            TA_HIP_TRY(ctx, hipMemcpy2DAsync(h_bp + lo, sizeof(double) * A, d_bp + lo, sizeof(double) * A,
+                                             sizeof(double) * (hi - lo), T, hipMemcpyDeviceToHost,
+                                             ctx->copy_stream));
+        }
+        TA_HIP_TRY(ctx, hipMemcpyAsync(part.data(), d_ls, sizeof(double) * T * n_blocks, hipMemcpyDeviceToHost,
+                                       ctx->stream));
+        TA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        TA_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+        const double n_at = (double)A;
+        for (int64_t k = 0; k < T; ++k) {
+            double sum = 0.0;
+            for (int64_t b = 0; b < n_blocks; ++b) sum += part[(size_t)b * T + k];
+            h_ts[k] = sum / n_at;
+        }
+        return TA_OK;
     }
     if ((rc = staged_entry(ctx, which, d_m, scale, d_ls, d_bp, A, (void*)ctx->stream))) return rc;
     TA_HIP_TRY(ctx, hipMemcpyAsync(h_ts, d_ls, sizeof(double) * T, hipMemcpyDeviceToHost, ctx->stream));
