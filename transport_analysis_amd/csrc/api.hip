@@ -339,17 +339,18 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
     int rc;
     const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2;
     int R0 = 0;
-    if (!d_bp && T > 512 && wfft_choose((long)T, &R0)) {
+    if (!d_bp && wfft_choose((long)T, &R0)) {
         cd* tw = nullptr;
         if ((rc = get_wf_table(ctx, R0, &tw))) return rc;
         const int L2 = 2 * R0 * 512;
         int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * wfft_max_wg_per_cu(R0);
         // pass-split form (one pass per workgroup, the two workgroups of a couple share an
         // XCD's L2: every input byte leaves HBM once) whenever 16 workgroups have work
-        const bool split = std::min<int64_t>(nwg, 2 * n_pairs) >= 16 && ctx->opt_fft_debug != 2;
+        const bool split = R0 > 1 && std::min<int64_t>(nwg, 2 * n_pairs) >= 16 && ctx->opt_fft_debug != 2;
         if (split) nwg = std::min<int64_t>(nwg, 2 * n_pairs) / 16 * 16;
+        else if (R0 == 1) nwg = std::max<int64_t>(1, std::min(nwg, (n_pairs + 3) / 4));  // a wave per pair
         else nwg = std::max<int64_t>(1, std::min(nwg, n_pairs));
-        int n_parts = (int)(split ? nwg / 2 : nwg);
+        int n_parts = (int)(split ? nwg / 2 : R0 == 1 ? 4 * nwg : nwg);
         if ((rc = ensure(ctx, ctx->partial, sizeof(double) * (size_t)n_parts * L2))) return rc;
         if ((rc = ensure(ctx, ctx->spec, sizeof(double) * (size_t)L2))) return rc;
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
@@ -395,7 +396,7 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         TA_HIP_TRY(ctx, fin->finalize(st, fa));
         return TA_OK;
     }
-    if (d_bp && T > 512 && wfft_choose((long)T, &R0) && ctx->opt_fft_debug != 3) {
+    if (d_bp && wfft_choose((long)T, &R0)) {
         // by-particle mode on the wave-local machinery (k_wbp): per-atom lag values to an
         // atom-major scratch (512-byte stores), then the transposition into the caller's
         // (n_frames, ld_bp) array, which also adds up its 64 atoms per lag
@@ -403,7 +404,7 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         if ((rc = get_wf_table(ctx, R0, &tw))) return rc;
         const int64_t Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
         int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * wfft_max_wg_per_cu(R0);
-        nwg = std::max<int64_t>(1, std::min(nwg, A));
+        nwg = std::max<int64_t>(1, std::min(nwg, R0 == 1 ? (A + 3) / 4 : A));
         if ((rc = ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp))) return rc;
         if ((rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T))) return rc;
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
@@ -491,7 +492,7 @@ int helfand_impl(ta_ctx* ctx, const double* pm_vel, const double* pm_pos, const 
     const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2;
     const bool fft_ok = ctx->opt_helfand_fft && T >= 2;
     int r0 = 0, lm = 0, lr = 0;
-    const bool has_fft_ts = (T > 512 && wfft_choose((long)T, &r0)) || find_plan(T) || fft_long_choose((long)T, &lm, &lr);
+    const bool has_fft_ts = wfft_choose((long)T, &r0) || fft_long_choose((long)T, &lm, &lr);
     if (fft_ok && !d_bp && has_fft_ts) {
         const int n_parts = (int)std::min<int64_t>(1024, n_pairs);
         if ((rc = ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)))) return rc;
@@ -508,7 +509,7 @@ int helfand_impl(ta_ctx* ctx, const double* pm_vel, const double* pm_pos, const 
         TA_HIP_TRY(ctx, launch_helfand_combine(Q, S2, C, (int)T, scale / (double)D, d_lagsum, st));
         return TA_OK;
     }
-    if (fft_ok && d_bp && find_plan(T)) {
+    if (fft_ok && d_bp && wfft_choose((long)T, &r0)) {
         if ((rc = ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)))) return rc;
         if ((rc = ensure(ctx, ctx->helf_small, sizeof(double) * ((size_t)T + 1) * A))) return rc;
         double* P = (double*)ctx->helf_p.p;
@@ -723,11 +724,11 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
 
 int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_stages) {
     int R0 = 0;
-    if (n_frames > 512 && wfft_choose((long)n_frames, &R0)) {
-        // first-stage radix R0, then one wave per 512-point sub-series (8 x 8 x 8)
+    if (wfft_choose((long)n_frames, &R0)) {
+        // first-stage radix R0 (none up to 512 frames), then one wave per 512-point sub-series (8 x 8 x 8)
         if (m_out) *m_out = (int64_t)R0 * 512;
-        if (n_threads) *n_threads = 512;
-        if (n_stages) *n_stages = 4;
+        if (n_threads) *n_threads = R0 == 1 ? 64 : 512;
+        if (n_stages) *n_stages = R0 == 1 ? 3 : 4;
         return TA_OK;
     }
     const PlanEntry* p = find_plan(n_frames);

@@ -10,7 +10,7 @@
 namespace ta {
 namespace {
 
-constexpr int kR0s[] = {2, 4, 5, 8, 10, 16, 20};
+constexpr int kR0s[] = {1, 2, 4, 5, 8, 10, 16, 20};
 
 template <int R0>
 hipError_t launch_accum_r0(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
@@ -144,6 +144,7 @@ void wfft_fill_table(int R0, cd* a) { wf_fill_table(R0, a); }
 
 int wfft_max_wg_per_cu(int R0) {
     switch (R0) {
+        case 1: return 2;  // 64 KiB of LDS per 256-thread workgroup
         case 2: return max_wg_r0<2>();
         case 4: return max_wg_r0<4>();
         case 5: return max_wg_r0<5>();
@@ -155,9 +156,29 @@ int wfft_max_wg_per_cu(int R0) {
     return 1;
 }
 
+// R0 = 1 (n_frames <= 512): independent waves, 4 per workgroup; accg [4 nwg][1024]
+hipError_t launch_w1_accum(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
+                           const cd* tw, double* accg) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_w1_accum),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W1::kLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_w1_accum, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_pairs, tw, accg);
+    return hipGetLastError();
+}
+
+hipError_t launch_w1_bp(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_atoms, int D,
+                        const cd* tw, double* out, long ld) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_w1_bp),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W1::kLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_w1_bp, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_atoms, D, tw, out, ld);
+    return hipGetLastError();
+}
+
 hipError_t launch_wfft_accum(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
                              long n_pairs, const cd* tw, double* accg) {
     switch (R0) {
+        case 1: return launch_w1_accum(nwg, st, pm, pitch, T, n_pairs, tw, accg);
         case 2: return launch_accum_r0<2>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
         case 4: return launch_accum_r0<4>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
         case 5: return launch_accum_r0<5>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
@@ -178,6 +199,7 @@ hipError_t launch_wfft_sum_perm(const double* partial, int n_parts, int M, const
 hipError_t launch_wfft_by_particle(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
                                    long n_atoms, int D, const cd* tw, double* out, long ld) {
     switch (R0) {
+        case 1: return launch_w1_bp(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
         case 2: return launch_bp_r0<2>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
         case 4: return launch_bp_r0<4>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
         case 5: return launch_bp_r0<5>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);

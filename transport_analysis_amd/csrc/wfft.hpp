@@ -1103,4 +1103,137 @@ __global__ void __launch_bounds__(P::NT)
 #undef WF_STAMP
 }
 
+
+// ================================================================================================
+// n_frames <= 512 (M = 512, R0 = 1): the whole padded series is ONE sub-series, so a wave works
+// alone -- rows straight from global memory into the lane's eight registers, pass B's twist
+// W_1024^t from eight resident per-lane factors, both passes' sub-transforms interleaved in two
+// private 8 KiB LDS regions, no workgroup barrier anywhere.
+struct W1 {
+    static constexpr int NT = 256, NWV = 4, M = 512;
+    static constexpr size_t kLds = (size_t)NWV * 2 * 512 * sizeof(cd);  // two regions per wave
+};
+
+__device__ __forceinline__ void w1_two_passes(cd* __restrict__ regA, cd* __restrict__ regB, int lane,
+                                              const cd (&twa)[7], const cd (&twb)[7], const cd (&v)[8],
+                                              const cd (&tB)[8], double (&accA)[8], double (&accB)[8]) {
+    const WfSub w(lane);
+    cd a[8], b[8];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) {
+        a[n2] = v[n2];
+        b[n2] = cmul(v[n2], tB[n2]);
+    }
+    w.stage_a(regA, a, twa);
+    w.stage_a(regB, b, twa);
+    w.stage_b(regA, a, twb);
+    w.stage_b(regB, b, twb);
+    w.stage_c(a, accA);
+    w.stage_c(b, accB);
+}
+
+// lag sums: accg [gridDim.x * 4][1024], natural bin order (bin 2 s + B), one row per wave
+__global__ void __launch_bounds__(W1::NT)
+    k_w1_accum(const double* __restrict__ pm, long pitch, int T, long n_pairs,
+               const cd* __restrict__ tw2, double* __restrict__ accg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd* lds = reinterpret_cast<cd*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long gw = (long)blockIdx.x * W1::NWV + wave, nw = (long)gridDim.x * W1::NWV;
+    cd* regA = lds + wave * 1024;
+    cd* regB = regA + 512;
+    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cd*>(tw2), 0, (4 * W1::M + 14 * 64) * 16, 0x00020000);
+    cd twa[7], twb[7], tB[8];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+        twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * W1::M + a * 64) * 16u);
+        twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * W1::M + (7 + a) * 64) * 16u);
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) tB[n2] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(64 * n2) * 16u);  // W_1024^t
+    double accA[8], accB[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) accA[c] = accB[c] = 0.0;
+    for (long p = gw; p < n_pairs; p += nw) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double*>(pm + p * pitch * 2), 0, T * 16, 0x00020000);
+        cd v[8];
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) v[n2] = wf_load(rs, (unsigned)lane * 16u, (unsigned)(64 * n2) * 16u);
+        w1_two_passes(regA, regB, lane, twa, twb, v, tB, accA, accB);
+    }
+    double* out = accg + gw * 2 * W1::M;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int sb = (lane >> 3) + 8 * (lane & 7) + 64 * c;
+        out[2 * sb] = accA[c];
+        out[2 * sb + 1] = accB[c];
+    }
+}
+
+// by-particle: a wave takes whole atoms; out[atom * ld + lag] (atom-major, as k_wbp)
+__global__ void __launch_bounds__(W1::NT)
+    k_w1_bp(const double* __restrict__ pm, long pitch, int T, long n_atoms, int D,
+            const cd* __restrict__ tw2, double* __restrict__ out, long ld) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd* lds = reinterpret_cast<cd*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long gw = (long)blockIdx.x * W1::NWV + wave, nw = (long)gridDim.x * W1::NWV;
+    cd* regA = lds + wave * 1024;
+    cd* regB = regA + 512;
+    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cd*>(tw2), 0, (4 * W1::M + 14 * 64) * 16, 0x00020000);
+    cd twa[7], twb[7], tB[8];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+        twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * W1::M + a * 64) * 16u);
+        twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * W1::M + (7 + a) * 64) * 16u);
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < 8; ++n2) tB[n2] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(64 * n2) * 16u);
+    const int n_units = D == 3 ? 2 : 1;
+    for (long atom = gw; atom < n_atoms; atom += nw) {
+        double accA[8], accB[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) accA[c] = accB[c] = 0.0;
+        for (int k = 0; k < n_units; ++k) {
+            // units as in k_wbp: the atom's aligned column pair (kind 2) and/or a single column
+            const long c0 = atom * D;
+            long pair;
+            int kind;
+            if (D == 2) pair = atom, kind = 2;
+            else if (D == 1) pair = c0 >> 1, kind = (int)(c0 & 1);
+            else if ((c0 & 1) == 0) pair = (c0 >> 1) + k, kind = k == 0 ? 2 : 0;
+            else pair = (c0 >> 1) + k, kind = k == 0 ? 1 : 2;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<double*>(pm + pair * pitch * 2), 0, T * 16, 0x00020000);
+            cd v[8];
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) {
+                v[n2] = wf_load(rs, (unsigned)lane * 16u, (unsigned)(64 * n2) * 16u);
+                if (kind != 2) v[n2] = cd{kind ? v[n2].y : v[n2].x, 0.0};
+            }
+            w1_two_passes(regA, regB, lane, twa, twb, v, tB, accA, accB);
+        }
+        // lag values: transposed transform of P_A + i P_B (R0 = 1: its output IS Q in natural order)
+        cd v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = cd{accA[c], accB[c]};
+        const WfSubT wt(lane);
+        wt.run(regA, v, twa, twb);
+        double* o = out + atom * ld;
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) {
+            const int n = 64 * n2 + lane;
+            const cd q = regA[n], qm = regA[(W1::M - n) % W1::M];
+            const cd w = tB[n2];  // W_1024^n = cos - i sin
+            const double ar = 0.5 * (q.x + qm.x), br = 0.5 * (q.y + qm.y), bi = -0.5 * (q.x - qm.x);
+            const double L = ar + (w.x * br - w.y * bi);
+            if (n < T) o[n] = L / (2.0 * (double)W1::M * (double)(T - n));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace ta
