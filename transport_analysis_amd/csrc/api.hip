@@ -128,14 +128,6 @@ int get_wf_table(ta_ctx* ctx, int R0, cd** out) {
     return TA_OK;
 }
 
-const PlanEntry* find_plan(int64_t n_frames) {
-    const PlanEntry* best = nullptr;
-    for (const auto* tab : {&plans_pow2(), &plans_five()})
-        for (const auto& p : *tab)
-            if (p.M >= n_frames && (!best || p.M < best->M)) best = &p;
-    return best;
-}
-
 int get_tables(ta_ctx* ctx, int M, int R0, Tables* out) {
     auto it = ctx->tables.find(M);
     if (it != ctx->tables.end()) {
@@ -387,12 +379,7 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         }
         TA_HIP_TRY(ctx, launch_wfft_sum_perm((const double*)ctx->partial.p, (int)nwg, fin->M, tb.perm,
                                              (double*)ctx->spec.p, st));
-        FftArgs fa{};
-        fa.T = (int)T;
-        fa.tw2 = tb.tw2;
-        fa.spec = (const double*)ctx->spec.p;
-        fa.n_slices = 1;
-        fa.lagsum = d_lagsum;
+        FftArgs fa{(int)T, tb.tw2, (const double*)ctx->spec.p, 1, d_lagsum};
         TA_HIP_TRY(ctx, fin->finalize(st, fa));
         return TA_OK;
     }
@@ -416,71 +403,12 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)n_tiles, T, d_lagsum, st));
         return TA_OK;
     }
-    const PlanEntry* plan = find_plan(T);
+    // beyond the on-chip lengths: lag sums by the outer-radix path, anything else by the direct
+    // correlator (same quantity: velocityautocorr.py:217-238 == :208-215 mathematically)
     int long_M = 0, long_R = 0;
-    if (!plan && !d_bp && fft_long_choose((long)T, &long_M, &long_R))
+    if (!d_bp && fft_long_choose((long)T, &long_M, &long_R))
         return fft_long_impl(ctx, pm, pitch, T, A, D, d_lagsum, st, long_M, long_R);
-    if (!plan)
-        return direct_impl(ctx, MODE_VACF, pm, nullptr, nullptr, T, A, D, pitch, 1.0, d_lagsum, d_bp, ld_bp, st);
-    Tables tb;
-    if ((rc = get_tables(ctx, plan->M, plan->R_first, &tb))) return rc;
-    FftArgs a{};
-    a.vel = pm;
-    a.ld_row = 2;               // pair-major: rows of a pair are 2 elements apart,
-    a.pair_stride = 2 * pitch;  // pairs 2*pitch elements apart
-    a.flags = (int)ctx->opt_fft_debug;
-    a.T = (int)T;
-    a.n_cols = n_cols;
-    a.n_atoms = A;
-    a.D = D;
-    a.tw2 = tb.tw2;
-    const size_t acc_blk = (size_t)((plan->K_last * plan->R_last + 1) / 2) * 2 * plan->NT;
-    if (!d_bp) {
-        a.n_cols = 2 * n_pairs;  // every stored pair is complete (an odd last column sits next to zeros)
-        int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * plan->max_wg_per_cu(0);
-        nwg = std::max<int64_t>(1, std::min(nwg, n_pairs));
-        if (nwg >= 8) nwg -= nwg % 8;
-        const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * acc_blk;
-        if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
-        const int n_slices = (int)std::min<int64_t>(4, nwg);
-        if ((rc = ensure(ctx, ctx->spec, sizeof(double) * 2 * plan->M * n_slices))) return rc;
-        a.partial = (double*)ctx->partial.p;
-        TA_HIP_TRY(ctx, hipMemsetAsync(a.partial, 0, acc_bytes, st));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-        TA_HIP_TRY(ctx, plan->accum(true, (int)nwg, st, a));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-        TA_HIP_TRY(ctx, launch_sum_partials_perm(a.partial, (int)nwg, plan->M, plan->NT, plan->R_last,
-                                                 plan->K_last, plan->TASKS_last, (double*)ctx->spec.p,
-                                                 n_slices, st));
-        a.spec = (const double*)ctx->spec.p;
-        a.n_slices = n_slices;
-        a.lagsum = d_lagsum;
-        TA_HIP_TRY(ctx, plan->finalize(st, a));
-    } else {
-        int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * plan->max_wg_per_cu(2);
-        nwg = std::max<int64_t>(1, std::min(nwg, A));
-        if (nwg >= 8) nwg -= nwg % 8;
-        const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * acc_blk;
-        if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
-        // lag values leave the kernel atom-major (512-byte stores per wave); the transposition
-        // into the caller's (n_frames, ld_bp) array also adds up its 64 atoms per lag
-        const int64_t Tp = pm_pitch(T);
-        const int64_t n_tiles = (A + 63) / 64;
-        if ((rc = ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp))) return rc;
-        if ((rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T))) return rc;
-        a.partial = (double*)ctx->partial.p;
-        a.by_particle = (double*)ctx->bp_scratch.p;
-        a.ld_bp = Tp;
-        TA_HIP_TRY(ctx, hipMemsetAsync(a.partial, 0, acc_bytes, st));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-        TA_HIP_TRY(ctx, plan->by_particle((int)nwg, st, a));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-        TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp,
-                                            (double*)ctx->ts_partial.p, st));
-        // lag sums = sums over atoms of the by-particle values (velocityautocorr.py:214)
-        TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)n_tiles, T, d_lagsum, st));
-    }
-    return TA_OK;
+    return direct_impl(ctx, MODE_VACF, pm, nullptr, nullptr, T, A, D, pitch, 1.0, d_lagsum, d_bp, ld_bp, st);
 }
 
 // Helfand mean squared differences (viscosity.py:201-233); the "helfand_fft" option evaluates
@@ -731,9 +659,8 @@ int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_st
         if (n_stages) *n_stages = R0 == 1 ? 3 : 4;
         return TA_OK;
     }
-    const PlanEntry* p = find_plan(n_frames);
     int long_M = 0, long_R = 0;
-    if (!p && fft_long_choose((long)n_frames, &long_M, &long_R)) {
+    if (fft_long_choose((long)n_frames, &long_M, &long_R)) {
         // outer radix step + on-chip transform (lag sums only; fft_long.hip)
         const PlanEntry* q = plan_of_length(long_M);
         if (m_out) *m_out = (int64_t)long_M * long_R;
@@ -741,11 +668,7 @@ int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_st
         if (n_stages) *n_stages = q ? q->S + 1 : 0;
         return TA_OK;
     }
-    if (!p) return fail(nullptr, TA_E_UNSUPPORTED, "n_frames exceeds the largest FFT plan");
-    if (m_out) *m_out = p->M;
-    if (n_threads) *n_threads = p->NT;
-    if (n_stages) *n_stages = p->S;
-    return TA_OK;
+    return fail(nullptr, TA_E_UNSUPPORTED, "n_frames exceeds the largest FFT plan");
 }
 
 /* ------------------------------------------------------------------ staging */

@@ -17,40 +17,6 @@ __global__ void k_sum_partials(const double* __restrict__ partial, int n_parts, 
 }
 
 
-// Sum the per-workgroup accumulator blocks and restore the transform's bin order.
-// Block layout per pass: [quad][tid][2 doubles]; double index d = m*R + q of a thread sits
-// in quad d/2, component d%2.  spec[pass*M + u*R + q], u = tid + m*NT.
-__global__ void k_sum_partials_perm(const double* __restrict__ partial, int n_parts, int M, int NT,
-                                    int R, int K, int TASKS, double* __restrict__ spec) {
-    const int quads = (K * R + 1) / 2;
-    const long blk = (long)quads * 2 * NT;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // index within [2][blk]
-    if (i >= 2 * blk) return;
-    const int pass = (int)(i / blk);
-    const long r = i - pass * blk;
-    const int comp = (int)(r & 1);
-    const long qt = r >> 1;  // quad*NT + tid
-    const int tid = (int)(qt % NT);
-    const int d = 2 * (int)(qt / NT) + comp;
-    if (d >= K * R) return;
-    const int m = d / R, q = d % R;
-    const int u = tid + m * NT;
-    if (u >= TASKS) return;
-    // grid.y slices of the workgroup blocks: slice y sums blocks y, y + gridDim.y, ... into its
-    // own copy of the spectrum (k_fft_finalize adds the copies): fixed order, more parallelism
-    double s = 0.0;
-    for (int w = blockIdx.y; w < n_parts; w += gridDim.y) s += partial[(long)w * 2 * blk + i];
-    spec[(long)blockIdx.y * 2 * M + (long)pass * M + (long)u * R + q] = s;
-}
-
-hipError_t launch_sum_partials_perm(const double* partial, int n_parts, int M, int NT, int R, int K,
-                                    int TASKS, double* out, int n_slices, hipStream_t st) {
-    const int nt = 256;
-    const long n = 2L * ((K * R + 1) / 2) * 2 * NT;
-    hipLaunchKernelGGL(k_sum_partials_perm, dim3((unsigned)((n + nt - 1) / nt), n_slices), dim3(nt),
-                       0, st, partial, n_parts, M, NT, R, K, TASKS, out);
-    return hipGetLastError();
-}
 
 // compiled chunk sizes (lags per chunk); the launcher picks the one that fills the CU best
 #define TA_DIRECT_CHUNKS(X) X(8) X(10)

@@ -17,10 +17,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#ifndef TA_AGPR_FENCE_HOOK
-#define TA_AGPR_FENCE_HOOK()
-#endif
-
 namespace ta {
 
 struct cd {
@@ -203,14 +199,6 @@ struct Plan {
         return n;
     }
     static constexpr int lds_elems() { return (M + 15) / 16 * 16; }
-    static constexpr bool kLanding = false;  // see WithLanding
-};
-
-// The same plan run with the landing-zone software pipeline of k_fft_accum (fft_kernels.hpp):
-// a property of the kernel instantiation, not of the transform.
-template <class P>
-struct WithLanding : P {
-    static constexpr bool kLanding = true;
 };
 
 template <class P, int s>
@@ -262,16 +250,13 @@ __device__ __forceinline__ void inv_stage_lds(cd* __restrict__ lds, const cd* __
             const int base = blk * SI::N + b;
             const int sb = sw(base);
             cd v[SI::R];
-            TA_AGPR_FENCE_HOOK();
 #pragma unroll
             for (int q = 0; q < SI::R; ++q) v[q] = lds[sw_off(sb, q * SI::L)];
             if (SI::L > 1) {
 #pragma unroll
                 for (int q = 1; q < SI::R; ++q) v[q] = cmulc(v[q], tw2[q * b * SI::TWSTEP]);
             }
-            TA_AGPR_FENCE_HOOK();
             idft<SI::R>(v);
-            TA_AGPR_FENCE_HOOK();
 #pragma unroll
             for (int j = 0; j < SI::R; ++j) lds[sw_off(sb, j * SI::L)] = v[j];
         }
@@ -314,14 +299,11 @@ __device__ __forceinline__ void inv_stage_lds_fast(cd* __restrict__ lds,
             if (SI::TASKS % P::NT == 0 || u < SI::TASKS) {
                 const int sb = sw(u);
                 cd v[SI::R];
-                TA_AGPR_FENCE_HOOK();
 #pragma unroll
                 for (int q = 0; q < SI::R; ++q) v[q] = lds[sw_off(sb, q * SI::L)];
 #pragma unroll
                 for (int q = 1; q < SI::R; ++q) v[q] = cmulc(v[q], tw_lane(tbl, q * SI::L + u));
-                TA_AGPR_FENCE_HOOK();
                 idft<SI::R>(v);
-                TA_AGPR_FENCE_HOOK();
 #pragma unroll
                 for (int j = 0; j < SI::R; ++j) lds[sw_off(sb, j * SI::L)] = v[j];
             }
@@ -337,7 +319,6 @@ __device__ __forceinline__ void inv_stage_lds_fast(cd* __restrict__ lds,
                 const int base = blk * SI::N + b;
                 const int sb = sw(base);
                 cd v[SI::R];
-                TA_AGPR_FENCE_HOOK();
 #pragma unroll
                 for (int q = 0; q < SI::R; ++q) v[q] = lds[sw_off(sb, q * SI::L)];
                 cd wo = seed, we = seed2;  // seed^q for the current odd / even q
@@ -353,9 +334,7 @@ __device__ __forceinline__ void inv_stage_lds_fast(cd* __restrict__ lds,
                         v[q] = cmulc(v[q], we);
                     }
                 }
-                TA_AGPR_FENCE_HOOK();
                 idft<SI::R>(v);
-                TA_AGPR_FENCE_HOOK();
 #pragma unroll
                 for (int j = 0; j < SI::R; ++j) lds[sw_off(sb, j * SI::L)] = v[j];
             }
@@ -389,9 +368,7 @@ __device__ __forceinline__ void fwd_stage_lds_seeded(cd* __restrict__ lds, cd se
     // chain (R-1 complex values per stage) out of the pair loop and spill it; laundering
     // the seed keeps the chain where it is used.
     asm volatile("" : "+v"(seed.x), "+v"(seed.y));
-    // likewise the LDS addresses in the by-particle kernels (register file full: CSE across the
-    // passes spills them; measured -2 % there, +1 % on the landing kernels, which keep the CSE)
-    if constexpr (!P::kLanding) asm volatile("" : "+v"(tid));
+    asm volatile("" : "+v"(tid));  // likewise the LDS addresses
     const cd seed2 = cmul(seed, seed);
     const double c2 = 2.0 * seed2.x;
 #pragma unroll
@@ -404,9 +381,7 @@ __device__ __forceinline__ void fwd_stage_lds_seeded(cd* __restrict__ lds, cd se
             cd v[SI::R];
 #pragma unroll
             for (int j = 0; j < SI::R; ++j) v[j] = lds[sw_off(sb, j * SI::L)];
-            TA_AGPR_FENCE_HOOK();
             Dft<SI::R>::run(v);
-            TA_AGPR_FENCE_HOOK();
             // seed^q by the three-term recurrence w_{q+2} = 2 cos(2 theta) w_q - w_{q-2} (two
             // FMAs per power instead of a complex product; odd and even q are independent
             // chains; <= 7 steps each, error growth ~q^2 ulp: far inside the 1e-10 budget)
@@ -428,11 +403,9 @@ __device__ __forceinline__ void fwd_stage_lds_seeded(cd* __restrict__ lds, cd se
                     v[q] = cmul(v[q], we);
                 }
             }
-            TA_AGPR_FENCE_HOOK();
 #pragma unroll
             for (int q = 0; q < SI::R; ++q) lds[sw_off(sb, q * SI::L)] = v[q];
         }
-        TA_AGPR_FENCE_HOOK();
         // all lanes (also those without a butterfly in this round) run the hook
         __builtin_amdgcn_sched_barrier(0);
         after_task(m);

@@ -10,34 +10,21 @@
 
 namespace ta {
 
-struct FftArgs {
-    const double* vel;
-    long ld_row;
-    long pair_stride;  // accum: elements between consecutive column pairs (2 for a slab)
-    int flags;         // accum: timing diagnostics (0 in production)
+struct FftArgs {        // k_fft_finalize
     int T;
-    long n_cols;   // accum: columns of the shard (n_atoms * D)
-    long n_atoms;  // by_particle
-    int D;
-    const cd* tw2;        // [0,2M): W_{2M}^n; [2M,3M): first-stage table pass A; [3M,4M): pass B; [4M,4M+4): zeros
-    double* partial;      // accum: [nwg][2][quads*2*NT] float64, zeroed by the caller
-    const double* spec;   // finalize: [n_slices][2][M]
+    const cd* tw2;        // [0,2M): W_{2M}^n; [2M,3M): first-stage table [q][u] = W_M^{q u}; ...
+    const double* spec;   // [n_slices][2][M], the plan's digit-reversed bin order
     int n_slices;
-    double* lagsum;       // finalize: [T]
-    double* by_particle;  // by_particle: (T, ld_bp)
-    long ld_bp;
-    double* ts_partial;   // by_particle: [nwg][T]
+    double* lagsum;       // [T]
 };
 
+// An on-chip plan (M = 2^a or 5*2^a, 16..10240): today only its inverse transform is used
+// (k_fft_finalize: ONE per launch) plus, for M = 8192 / 10240, the outer-radix path's stages.
 struct PlanEntry {
     int M, NT, S;
-    int R_first;                     // first radix: layout of the first-stage twiddle tables
-    int R_last, TASKS_last, K_last;  // accumulator block per pass: [quads][NT] x 4 dwords
+    int R_first;                          // first radix: layout of the first-stage twiddle table
     size_t lds_bytes;
-    hipError_t (*accum)(bool vec, int nwg, hipStream_t st, const FftArgs& a);
     hipError_t (*finalize)(hipStream_t st, const FftArgs& a);
-    hipError_t (*by_particle)(int nwg, hipStream_t st, const FftArgs& a);
-    int (*max_wg_per_cu)(int which);  // 0 accum(vec) 1 accum(novec) 2 by_particle
     void (*perm)(std::vector<int>& out);  // output position -> frequency (digit reversal)
 };
 
@@ -58,9 +45,6 @@ hipError_t launch_row_sums(const double* bp, long n_rows, long n_cols, long ld, 
                            hipStream_t st);
 hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,
                                hipStream_t st);
-// spec[pass*M + u*R + q] = sum over workgroups of their accumulator (m, q), u = tid + m*NT
-hipError_t launch_sum_partials_perm(const double* partial, int n_parts, int M, int NT, int R, int K,
-                                    int TASKS, double* out, int n_slices, hipStream_t st);
 // fft_long.hip: FFT lag sums beyond the on-chip transform length (timeseries path)
 bool fft_long_choose(long n_frames, int* M, int* Rout);  // smallest M' = Rout*M >= n_frames
 void fft_long_perm(int M, std::vector<int>& perm);       // position -> frequency of plan M's output
