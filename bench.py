@@ -136,9 +136,11 @@ class Case:
     def kernel_name(self):
         if self.mode != "fft" and not (self.mode == "helfand" and self.helfand_fft):
             return "k_direct"
+        if self.T > 10240:
+            return "k_direct" if self.bp is not None else "k_fft_accum_long"
         if self.bp is not None:
-            return "k_fft_accum (by-particle mode)"
-        return "k_wsplit_accum" if 512 < self.T <= 10240 else ("k_fft_accum" if self.T <= 512 else "k_fft_accum_long")
+            return "k_wbp" if self.T > 512 else "k_w1_bp"
+        return "k_wsplit_accum" if self.T > 512 else "k_w1_accum"
 
 
 def timed(torch, dist, world, steps, warmup, fn):

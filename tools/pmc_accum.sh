@@ -12,13 +12,13 @@ import csv,glob,collections
 agg=collections.defaultdict(list); dur=[]
 for f in glob.glob("$OUT/s*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'k_fft_accum' in r['Kernel_Name']:
+        if 'accum' in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
 for f in glob.glob("$OUT/s1/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'k_fft_accum' in r['Kernel_Name']:
+        if 'accum' in r['Kernel_Name']:
             dur.append(int(r['End_Timestamp'])-int(r['Start_Timestamp']))
-print("k_fft_accum dur_us", [d/1e3 for d in dur])
+print("accumulate kernel dur_us", [d/1e3 for d in dur])
 for k in sorted(agg): print(f"{k:28s} {sum(agg[k])/len(agg[k]):.5g}")
 PY
 rm -rf $OUT
