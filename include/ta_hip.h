@@ -109,7 +109,12 @@ int ta_stage_free(ta_ctx *ctx);
  * (oracle/synth.py).  Asynchronous on `stream`.                                            */
 int ta_stage_synth(ta_ctx *ctx, int slab, uint64_t seed, int64_t col_offset, int64_t n_cols_total,
                    void *stream);
-/* release the context's cached workspaces (scratch slabs, partial-sum blocks, landing buffer) */
+/* Release the context's cached workspaces.  They are sized by the largest call so far and kept
+ * until this call or ta_ctx_destroy: per-workgroup spectra (<= 42 MB), the atom-major
+ * by-particle scratch (n_atoms * n_frames * 8 bytes), the pair-major copies of frame-major *_dev
+ * inputs (the input's size, twice for Helfand), the 64 MiB landing buffer of ta_stage_commit,
+ * the outer-radix path's scratch (n_workgroups * 4 * 2R * M * 16 bytes: 5.4 GB at R = 16,
+ * M = 10240) and the product slab of the "helfand_fft" option (the input's size).             */
 int ta_trim(ta_ctx *ctx);
 
 /* ---- compute on staged slabs (host-facing, blocking) -------------------

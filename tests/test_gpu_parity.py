@@ -807,3 +807,19 @@ def test_host_path_by_particle_in_atom_blocks(ctx, mode, D):
     assert bp.shape == (T, A)
     assert scale_rel_err(bp, want_bp) < TOL
     assert scale_rel_err(ts, want_ts) < TOL
+
+
+@pytest.mark.parametrize("T,A,D", [(513, 700, 3), (1100, 1301, 1), (2600, 333, 2), (5200, 257, 3), (9000, 301, 3),
+                                   (10240, 130, 1)])
+def test_vacf_fft_many_units_per_workgroup(ctx, T, A, D):
+    """Enough atoms that the persistent workgroups walk several pairs / atoms each (couples of the
+    pass-split kernel, atom loop of the by-particle kernel), odd pair counts, every dim."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(T, A, D, seed=4000 + T)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
+    ts, bp = run_vacf(ctx, v, True, True)
+    assert scale_rel_err(bp, want_bp) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL
+    ts2, _ = run_vacf(ctx, v, True, False)
+    assert scale_rel_err(ts2, want_ts) < TOL

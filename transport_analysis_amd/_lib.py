@@ -157,7 +157,7 @@ class Context:
 
     def close(self):
         if self._h:
-            self._slabs = []
+            self._drop_views()
             lib().ta_ctx_destroy(self._h)
             self._h = ctypes.c_void_p(None)
 
@@ -175,7 +175,7 @@ class Context:
         """Pinned host slabs (n_frames, n_atoms, dim) as NumPy views + device twins."""
         code = TA_F64 if np.dtype(dtype) == np.float64 else TA_F32
         ptrs = (ctypes.c_void_p * n_slabs)()
-        self._slabs = []
+        self._drop_views()
         self._check(lib().ta_stage_alloc(self._h, n_frames, n_atoms, dim, code, n_slabs, ptrs))
         ct = ctypes.c_double if code == TA_F64 else ctypes.c_float
         n = int(n_frames) * int(n_atoms) * int(dim)
@@ -192,7 +192,7 @@ class Context:
 
     def stage_alloc_device(self, n_frames, n_atoms, dim, n_slabs=1):
         """Device slabs only (pair-major), for data that is already on the GPU."""
-        self._slabs = []
+        self._drop_views()
         self._check(lib().ta_stage_alloc_device(self._h, n_frames, n_atoms, dim, n_slabs))
         self.shape = (int(n_frames), int(n_atoms), int(dim))
 
@@ -218,8 +218,18 @@ class Context:
     def trim(self):
         self._check(lib().ta_trim(self._h))
 
-    def stage_free(self):
+    def _drop_views(self):
+        # the pinned memory behind the NumPy views goes away with the slabs: writes through a
+        # stale view must not land in freed memory silently
+        for a in self._slabs:
+            try:
+                a.setflags(write=False)
+            except Exception:
+                pass
         self._slabs = []
+
+    def stage_free(self):
+        self._drop_views()
         self._check(lib().ta_stage_free(self._h))
 
     # -- host-facing compute -------------------------------------------
