@@ -748,6 +748,32 @@ def test_helfand_config4_full_per_gpu_share(ctx):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("T,A,D", [(600, 19, 1), (1000, 37, 3), (1030, 24, 2), (2100, 21, 3), (2560, 18, 1),
+                                   (3000, 17, 3), (4200, 16, 2), (6000, 13, 3), (8192, 12, 1), (10000, 11, 3)])
+@pytest.mark.parametrize("spec_atoms", [0, 6])
+def test_vacf_by_particle_two_kernel_path(ctx, T, A, D, spec_atoms):
+    """The by-particle FFT evaluation in two kernels (pass-split forward kernel leaving per-atom
+    power spectra, inverse kernel; blocks of `spec_atoms` atoms) for every first-stage radix and
+    every column-unit kind (D = 1: single columns of either half of a pair; D = 3: an aligned pair
+    plus a single column, alternating), against the oracle and against the one-kernel evaluation
+    (fft_debug 3).  velocityautocorr.py:196-215."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(T, A, D, seed=4000 + T)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
+    try:
+        ctx.set_option("bp_spec_atoms", spec_atoms)
+        ts, bp = run_vacf(ctx, v, True, True)
+        ctx.set_option("fft_debug", 3)
+        ts1, bp1 = run_vacf(ctx, v, True, True)
+    finally:
+        ctx.set_option("fft_debug", 0)
+        ctx.set_option("bp_spec_atoms", 0)
+    assert scale_rel_err(bp, want_bp) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL
+    assert scale_rel_err(bp, bp1) < TOL and scale_rel_err(ts, ts1) < TOL
+
+
 def test_vacf_by_particle_config2_full_size(ctx):
     """The reference's default output at BASELINE configs[2]'s size on one GPU: 10000 x 100000 x 3
     with the (n_frames, n_atoms) by-particle array (8 GB).  The mean over atoms of the array is

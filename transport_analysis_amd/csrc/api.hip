@@ -48,6 +48,7 @@ struct ta_ctx {
     DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, bounce, stage_buf, long_scratch, helf_p, helf_small;
     DevBuf pm_in[2];  // pair-major copies of frame-major *_dev inputs
     DevBuf bp_scratch;  // atom-major by-particle results before the transposition
+    DevBuf bp_spec;     // per-atom power spectra of one block of atoms (two-kernel by-particle path)
     // staging: pinned host slabs keep the reference's (n_frames, n_atoms, dim) layout, the
     // device slabs are pair-major (layout.hip) with st_pitch rows per column pair
     int64_t st_T = 0, st_A = 0, st_pitch = 0;
@@ -72,6 +73,8 @@ struct ta_ctx {
     int64_t opt_direct_chunk = 0;
     int64_t opt_helfand_fft = 0;
     int64_t opt_bp_block = 0;
+    int64_t opt_bp_spec_atoms = 0;
+    int64_t opt_bp_prefetch = 2;
 };
 
 namespace {
@@ -395,8 +398,30 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         if ((rc = ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp))) return rc;
         if ((rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T))) return rc;
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-        TA_HIP_TRY(ctx, launch_wfft_by_particle(R0, (int)nwg, st, pm, pitch, (int)T, A, D, tw,
-                                                (double*)ctx->bp_scratch.p, Tp));
+        // two kernels per block of atoms where a block fills the chip: the pass-split forward
+        // kernel (couples of workgroups share their rows through the XCD's L2; half the
+        // accumulators per thread, so rows are prefetched and sub-series interleaved as on the
+        // lag-sum path) leaves each atom's power spectrum in scratch, the inverse kernel turns
+        // it into the atom's lags.  Blocks start on an even atom, so on a pair boundary.
+        const int64_t fwd_wg = std::min<int64_t>((int64_t)ctx->n_cu * wfft_max_wg_per_cu(R0), 2 * A) / 16 * 16;
+        if (R0 > 1 && fwd_wg >= 16 && ctx->opt_fft_debug != 3) {
+            const size_t spec_per_atom = sizeof(double) * 2 * (size_t)R0 * 512;
+            const int64_t CA = std::min<int64_t>(A, ctx->opt_bp_spec_atoms > 0 ? (ctx->opt_bp_spec_atoms + 1) / 2 * 2 : 16384);
+            if ((rc = ensure(ctx, ctx->bp_spec, spec_per_atom * (size_t)CA))) return rc;
+            for (int64_t a0 = 0; a0 < A; a0 += CA) {
+                const int64_t ca = std::min(CA, A - a0);
+                const int64_t groups = D & 1 ? (ca + 1) / 2 : ca;  // a couple of workgroups per group of atoms
+                const int64_t fw = std::max<int64_t>(16, std::min<int64_t>(fwd_wg, 2 * groups) / 16 * 16);
+                TA_HIP_TRY(ctx, launch_wfft_by_particle2(R0, (int)fw, (int)std::min<int64_t>(nwg, ca), st,
+                                                         pm + (a0 * D / 2) * pitch * 2, pitch, (int)T, ca, D, tw,
+                                                         (double*)ctx->bp_spec.p,
+                                                         (double*)ctx->bp_scratch.p + a0 * Tp, Tp,
+                                                         (int)ctx->opt_bp_prefetch));
+            }
+        } else {
+            TA_HIP_TRY(ctx, launch_wfft_by_particle(R0, (int)nwg, st, pm, pitch, (int)T, A, D, tw,
+                                                    (double*)ctx->bp_scratch.p, Tp));
+        }
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
         TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp,
                                             (double*)ctx->ts_partial.p, st));
@@ -609,7 +634,7 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     }
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
                       &ctx->masses, &ctx->bounce, &ctx->stage_buf, &ctx->long_scratch, &ctx->helf_p,
-                      &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1], &ctx->bp_scratch})
+                      &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1], &ctx->bp_scratch, &ctx->bp_spec})
         if (b->p) hipFree(b->p);
     for (auto& q : ctx->ring)
         for (auto& ev : q)
@@ -627,7 +652,7 @@ int ta_trim(ta_ctx* ctx) {
     hipDeviceSynchronize();
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_bp, &ctx->bounce, &ctx->stage_buf,
                       &ctx->long_scratch, &ctx->helf_p, &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1],
-                      &ctx->bp_scratch})
+                      &ctx->bp_scratch, &ctx->bp_spec})
         if (b->p) {
             hipFree(b->p);
             b->p = nullptr;
@@ -646,6 +671,8 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "direct_chunk")) ctx->opt_direct_chunk = value;
     else if (!strcmp(key, "helfand_fft")) ctx->opt_helfand_fft = value;
     else if (!strcmp(key, "bp_block")) ctx->opt_bp_block = value;
+    else if (!strcmp(key, "bp_spec_atoms")) ctx->opt_bp_spec_atoms = value;
+    else if (!strcmp(key, "bp_prefetch")) ctx->opt_bp_prefetch = value;
     else return fail(ctx, TA_E_INVALID, std::string("unknown option ") + key);
     return TA_OK;
 }

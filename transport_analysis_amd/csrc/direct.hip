@@ -5,18 +5,32 @@
 
 namespace ta {
 
-// ---- cross-workgroup sum of the partial spectra -------------------------------
-// spec[i] = sum_w partial[w][i],  i < 2*M (pass A then pass B)
-__global__ void k_sum_partials(const double* __restrict__ partial, int n_parts, long n,
-                               double* __restrict__ spec) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int w = 0; w < n_parts; ++w) s += partial[(long)w * n + i];
-    spec[i] = s;
+// ---- sum of partial rows in a fixed order ------------------------------------
+// out[i] = sum_w partial[w][i], i < n.  A workgroup takes 16 adjacent elements (128-byte row
+// segments); thread (g, i) adds the rows w = g, g + 16, ... in two interleaved chains, then the
+// 16 group sums are added in a fixed tree: the result does not depend on the launch.
+__global__ void __launch_bounds__(256)
+    k_sum_partials(const double* __restrict__ partial, int n_parts, long n, double* __restrict__ out) {
+    __shared__ double red[16][17];
+    const int tid = threadIdx.x, g = tid >> 4, e = tid & 15;
+    const long i = (long)blockIdx.x * 16 + e;
+    double s0 = 0.0, s1 = 0.0;
+    if (i < n) {
+        int w = g;
+        for (; w + 16 < n_parts; w += 32) {
+            s0 += partial[(long)w * n + i];
+            s1 += partial[(long)(w + 16) * n + i];
+        }
+        if (w < n_parts) s0 += partial[(long)w * n + i];
+    }
+    red[g][e] = s0 + s1;
+    __syncthreads();
+    for (int h = 8; h > 0; h >>= 1) {
+        if (g < h) red[g][e] += red[g + h][e];
+        __syncthreads();
+    }
+    if (g == 0 && i < n) out[i] = red[0][e];
 }
-
-
 
 // compiled chunk sizes (lags per chunk); the launcher picks the one that fills the CU best
 #define TA_DIRECT_CHUNKS(X) X(8) X(10)
@@ -80,9 +94,7 @@ int direct_max_wg_per_cu(int mode, bool f32, int L, int nt, size_t lds_bytes, bo
 
 hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,
                                hipStream_t st) {
-    const int nt = 256;
-    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n + nt - 1) / nt)), dim3(nt), 0, st,
-                       partial, n_parts, n, out);
+    hipLaunchKernelGGL(k_sum_partials, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, partial, n_parts, n, out);
     return hipGetLastError();
 }
 

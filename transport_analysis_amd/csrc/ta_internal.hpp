@@ -92,6 +92,10 @@ hipError_t launch_wfft_accum(int R0, int nwg, hipStream_t st, const double* pm, 
 hipError_t launch_wfft_by_particle(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
                                    long n_atoms, int D, const cd* tw, double* out, long ld);
 // pass-split form: nwg a multiple of 16, accg [nwg/2][2M] (every element written by the launch)
+// two-kernel by-particle evaluation: spec holds n_atoms * 2 * R0 * 512 doubles of scratch
+hipError_t launch_wfft_by_particle2(int R0, int nwg_fwd, int nwg_inv, hipStream_t st, const double* pm,
+                                    long pitch, int T, long n_atoms, int D, const cd* tw, double* spec,
+                                    double* out, long ld, int prefetch);
 hipError_t launch_wfft_split(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
                              long n_pairs, const cd* tw, double* accg);
 hipError_t launch_wfft_finish(int R0, const double* partial, int n_parts, const cd* tw, int T,

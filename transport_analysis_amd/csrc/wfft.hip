@@ -33,7 +33,29 @@ hipError_t launch_split_r0(int nwg, hipStream_t st, const double* pm, long pitch
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_pairs, tw, accg, nullptr);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_pairs, tw, accg, nullptr, 0);
+    return hipGetLastError();
+}
+
+// by-particle, two kernels: the pass-split forward kernel leaves every atom's power spectrum in
+// `spec` ([atom][2][R0][8][64] doubles), the inverse kernel turns each into the atom's lags
+template <int R0>
+hipError_t launch_bp2_r0(int nwg_fwd, int nwg_inv, hipStream_t st, const double* pm, long pitch, int T,
+                         long n_atoms, int D, const cd* tw, double* spec, double* out, long ld, int pf) {
+    using P = WPlan<R0>;
+    constexpr int NSA = (R0 + P::NW - 1) / P::NW;
+    auto fwd = k_wsplit_accum<P, false, true, true>;
+    auto inv = pf <= 0 ? k_wbp_inverse<P, 0> : pf == 1 || NSA == 1 ? k_wbp_inverse<P, 1>
+               : pf == 2 || NSA == 2 ? k_wbp_inverse<P, (NSA < 2 ? NSA : 2)> : k_wbp_inverse<P, NSA>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(inv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)P::kLds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fwd, dim3(nwg_fwd), dim3(P::NT), P::kLds, st, pm, pitch, T, n_atoms, tw, spec, nullptr, D);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(inv, dim3(nwg_inv), dim3(P::NT), P::kLds, st, spec, T, n_atoms, tw, out, ld);
     return hipGetLastError();
 }
 
@@ -222,6 +244,22 @@ hipError_t launch_wfft_split(int R0, int nwg, hipStream_t st, const double* pm, 
         case 10: return launch_split_r0<10>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
         case 16: return launch_split_r0<16>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
         case 20: return launch_split_r0<20>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_wfft_by_particle2(int R0, int nwg_fwd, int nwg_inv, hipStream_t st, const double* pm,
+                                    long pitch, int T, long n_atoms, int D, const cd* tw, double* spec,
+                                    double* out, long ld, int pf) {
+    if (nwg_fwd < 16 || nwg_fwd % 16 || nwg_inv < 1) return hipErrorInvalidValue;
+    switch (R0) {
+        case 2: return launch_bp2_r0<2>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
+        case 4: return launch_bp2_r0<4>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
+        case 5: return launch_bp2_r0<5>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
+        case 8: return launch_bp2_r0<8>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
+        case 10: return launch_bp2_r0<10>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
+        case 16: return launch_bp2_r0<16>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
+        case 20: return launch_bp2_r0<20>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
     }
     return hipErrorInvalidValue;
 }

@@ -283,21 +283,6 @@ __device__ __forceinline__ void wf_sub512_x3(cd* __restrict__ reg0, cd* __restri
 #ifndef WF_SI
 #define WF_SI 1   // first-stage stores interleaved with the output twiddles
 #endif
-#ifndef WF_X3
-#define WF_X3 1     // split kernel: three sub-series in flight in the waves that own three
-#endif
-#ifndef WF_SPRE
-#define WF_SPRE 0   // split kernel: first-stage butterfly before the barrier that frees the LDS
-#endif
-#ifndef WF_TWRES
-#define WF_TWRES 1  // split kernel: stage twiddles resident in registers (1) or re-loaded per pair (0)
-#endif
-#ifndef WF_TW1
-#define WF_TW1 0    // first-stage output twiddles from the table (1) or by two product chains (0)
-#endif
-#ifndef WF_EARLY
-#define WF_EARLY 0  // next pair's rows requested before the last single sub-series of S2
-#endif
 #ifndef WF_INTER_DEFAULT
 #define WF_INTER_DEFAULT false
 #endif
@@ -484,18 +469,40 @@ __global__ void __launch_bounds__(P::NT)
 // XCD's L2 and every input byte leaves HBM once.  (k_wfft_accum reads a pair twice from one
 // compute unit, half a pair-period apart: with 32 compute units x 160 KiB in flight per 4 MiB
 // L2 the second read mostly misses -- measured 1.8x the algorithmic bytes at the L2's fabric
-// side.)  Half the accumulators per thread (one pass: 20 per lane instead of 40 at R0 = 20),
-// which is what lets the first-stage rows, the stage twiddles and two sub-series in flight fit
-// 256 registers without spilling.
+// side.)  Half the accumulators per thread (one pass: 24 per lane instead of 40 at R0 = 20),
+// which is what lets the first-stage rows, the RESIDENT stage twiddles and two or three
+// sub-series in flight fit 256 registers without spilling.
 //
-// grid: a multiple of 16 blocks; block b: pass B = (b >> 3) & 1, couple c = (b & 7) + 8 (b >> 4);
-// accg: [n_couples][2M] natural bin order, the A block writes the even bins of its couple's row,
-// the B block the odd ones.
-template <class P, bool STAMP = false, bool INTER = true>
+// grid: a multiple of 16 blocks; block b: pass B = (b >> 3) & 1, couple c = (b & 7) + 8 (b >> 4).
+// Lag-sum mode (BYP = false): units are the n_units column pairs of the slab; accg:
+//   [n_couples][2M] natural bin order, the A block writes the even bins of its couple's row, the
+//   B block the odd ones.
+// By-particle forward mode (BYP = true): units are the atoms' column units (wf_unit_of); a couple
+//   takes whole atoms (pairs of adjacent atoms when the number of columns per atom is odd), and
+//   after an atom's last unit the pass's accumulators -- the atom's power spectrum in this
+//   pass -- go to accg as [atom][pass][q][c][lane] (the order k_wbp_inverse reads them back in)
+//   and start again from zero.
+__device__ __forceinline__ void wf_unit_of(long atom, int k, int D, long* pair, int* kind) {
+    // kind 2 = both columns of the pair (complex series), 0 / 1 = only that half (real series)
+    const long c0 = atom * D;
+    if (D == 2) {
+        *pair = atom, *kind = 2;
+    } else if (D == 1) {
+        *pair = c0 >> 1, *kind = (int)(c0 & 1);
+    } else if ((c0 & 1) == 0) {  // even first column: (x, y) aligned, then z alone
+        *pair = (c0 >> 1) + k, *kind = k == 0 ? 2 : 0;
+    } else {                     // x alone (second half of a pair), then (y, z) aligned
+        *pair = (c0 >> 1) + k, *kind = k == 0 ? 1 : 2;
+    }
+}
+
+typedef unsigned int wf_u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned int))));
+
+template <class P, bool STAMP = false, bool INTER = true, bool BYP = false>
 __global__ void __launch_bounds__(P::NT)
-    k_wsplit_accum(const double* __restrict__ pm, long pitch, int T, long n_pairs,
+    k_wsplit_accum(const double* __restrict__ pm, long pitch, int T, long n_units,
                    const cd* __restrict__ tw2, double* __restrict__ accg,
-                   unsigned long long* __restrict__ stamps = nullptr) {
+                   unsigned long long* __restrict__ stamps = nullptr, int D = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
     constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW;
@@ -503,6 +510,11 @@ __global__ void __launch_bounds__(P::NT)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int passB = (blockIdx.x >> 3) & 1;
     const long couple = (blockIdx.x & 7) + 8 * (blockIdx.x >> 4), n_couples = gridDim.x / 2;
+    const int upa = BYP ? (D == 3 ? 2 : 1) : 1;  // units per atom (by-particle mode)
+    // with an odd number of columns per atom, atoms 2i and 2i + 1 share a column pair (the last
+    // column of one, the first of the other): a couple takes both, so the shared rows come from
+    // the L2 the second time
+    const int grp = BYP && (D & 1) ? 2 : 1;
 
     double acc[NS1][8];
 #pragma unroll
@@ -519,44 +531,49 @@ __global__ void __launch_bounds__(P::NT)
     }
     const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<cd*>(tw2), 0, (4 * P::M + 14 * 64) * 16, 0x00020000);
-    // this pass's first-stage output twiddles [q][u]: read from the table (L2 hits, issued
-    // before the butterfly, landed after it) instead of 19 complex products per butterfly
-    const unsigned tw1_off = (unsigned)(2 * P::M + 14 * 64 + passB * R0 * N1) * 16u;
-    auto rsrc_of = [&](long p) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + (p < n_pairs ? p : 0) * pitch * 2), 0,
-                                                 p < n_pairs ? T * 16 : 0, 0x00020000);
+    // the couple's units in order: lag-sum mode pairs couple + i n_couples; by-particle mode the
+    // units k < upa of atoms couple + a n_couples.  A unit past the end gets an empty buffer: its
+    // loads return zeros and are never used.
+    auto unit_rsrc = [&](long item, int k, int* kind) {
+        long pair = item;
+        const bool live = item < n_units;
+        *kind = 2;
+        if constexpr (BYP) wf_unit_of(live ? item : 0, k, D, &pair, kind);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + (live ? pair : 0) * pitch * 2), 0,
+                                                 live ? T * 16 : 0, 0x00020000);
     };
     cd x[R0];
-    auto issue_loads = [&](__amdgpu_buffer_rsrc_t rs) {
+    auto issue_loads = [&](__amdgpu_buffer_rsrc_t rs, int kd) {
+        if (!BYP || kd == 2) {
 #pragma unroll
-        for (int j = 0; j < R0; ++j) x[j] = wf_load(rs, (unsigned)tid * 16u, (unsigned)(N1 * j) * 16u);
+            for (int j = 0; j < R0; ++j) x[j] = wf_load(rs, (unsigned)tid * 16u, (unsigned)(N1 * j) * 16u);
+        } else {  // a single real column: that half of every row, imaginary part zero
+#pragma unroll
+            for (int j = 0; j < R0; ++j)
+                x[j] = cd{__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                                         rs, (unsigned)tid * 16u + (unsigned)kd * 8u,
+                                                         (unsigned)(N1 * j) * 16u, 0)),
+                          0.0};
+        }
     };
-    issue_loads(rsrc_of(couple));
-#if WF_TWRES
+    int kind = 2, nkind = 2;
+    {
+        const __amdgpu_buffer_rsrc_t rs0 = unit_rsrc(couple * grp, 0, &kind);
+        issue_loads(rs0, kind);
+    }
     // the wave-local stage twiddles stay in registers for the whole launch (one pass's
-    // accumulators leave room for them: 14 fewer loads per wave and pair)
+    // accumulators leave room for them: 14 fewer loads per wave and unit)
     cd twa[7], twb[7];
 #pragma unroll
     for (int a = 0; a < 7; ++a) {
         twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + a * 64) * 16u);
         twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + (7 + a) * 64) * 16u);
     }
-#endif
-
-    for (long p = couple; p < n_pairs; p += n_couples) {
-        // ---- S1: radix-R0 butterfly u = tid over rows u + 512 j (loaded during the previous S2)
-#if WF_TW1
-        // (two batches: all R0 of them next to the R0 rows and the butterfly's temporaries do
-        // not fit the register file at R0 = 20)
-        constexpr int QH = R0 > 10 ? R0 / 2 : R0;
-        cd t1[R0];
-#pragma unroll
-        for (int q = 0; q < QH; ++q) t1[q] = wf_load(twr, (unsigned)tid * 16u, tw1_off + (unsigned)(q * N1) * 16u);
-        __builtin_amdgcn_sched_barrier(0);
-#else
+    int k = 0;  // unit of the atom (by-particle mode)
+    for (long item = couple * grp; item < n_units;) {
+        // ---- S1: radix-R0 butterfly u = tid over rows u + 512 j (requested during the previous S2)
         const cd g = wf_load(twr, (unsigned)tid * 32u, 0u), g2 = wf_load(twr, (unsigned)tid * 64u, 0u),
                  h = wf_load(twr, (unsigned)tid * 16u, 0u);
-#endif
 #if WF_ABL != 2
         if (passB) {
             // pass B twist, lane-uniform part: W_{2 R0}^j = tw2[j * 512]
@@ -565,28 +582,10 @@ __global__ void __launch_bounds__(P::NT)
         }
         Dft<R0>::run(x);
 #endif
-#if WF_SPRE
-        // everything above is register work: it runs BEFORE the barrier that frees the LDS, so a
-        // wave that owns one sub-series fewer does its butterfly while the others finish
-        __syncthreads();
-#endif
-#if WF_TW1
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = QH; q < R0; ++q) t1[q] = wf_load(twr, (unsigned)tid * 16u, tw1_off + (unsigned)(q * N1) * 16u);
-        __builtin_amdgcn_sched_barrier(0);
-        // output q scaled by W_2M^{u(2q+B)} and stored at once (stores spread between products)
-        if (passB) x[0] = cmul(x[0], t1[0]);
-        lds[tid] = x[0];
-#pragma unroll
-        for (int q = 1; q < R0; ++q) {
-            x[q] = cmul(x[q], t1[q]);
-            lds[q * N1 + tid] = x[q];
-        }
-#else
         {
             // output twiddles W_2M^{u(2q+B)} = h^B g^q: two chains (even / odd q) by g^2, each
-            // output stored as soon as it is scaled
+            // output stored as soon as it is scaled (the 20 stores of a wave take ~260 LDS-path
+            // cycles: issued in one burst at the end they are fully exposed)
             cd te = passB ? h : cd{1.0, 0.0};
             cd to = passB ? cmul(h, g) : g;
             if (passB) x[0] = cmul(x[0], te);
@@ -607,27 +606,22 @@ __global__ void __launch_bounds__(P::NT)
                 lds[q * N1 + tid] = x[q];
             }
         }
-#endif
-#if !WF_TWRES
-        __builtin_amdgcn_sched_barrier(0);
-        cd twa[7], twb[7];
-#pragma unroll
-        for (int a = 0; a < 7; ++a) {
-            twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + a * 64) * 16u);
-            twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + (7 + a) * 64) * 16u);
-        }
-#endif
         WF_STAMP(0)
         __syncthreads();
-        // ---- S2: sub-series q = wave + 8 s; slots every wave owns go two at a time.  The next
-        // pair's rows are requested before the LAST slot when that one is a single sub-series
-        // (registers allow it there), i.e. about one sub-series time before the barrier.
-        const __amdgpu_buffer_rsrc_t nrs = rsrc_of(p + n_couples);
+        // ---- S2: sub-series q = wave + 8 s, two or three in flight per wave; the next unit's
+        // rows are requested after the last one (before the barrier)
+        const bool last_of_item = !BYP || k == upa - 1;
+        long nitem = item;
+        if (last_of_item) {
+            if (BYP && grp == 2 && (item & 1) == 0 && item + 1 < n_units) nitem = item + 1;
+            else nitem = (item & ~(long)(grp - 1)) + grp * n_couples;
+        }
+        const int nk = last_of_item ? 0 : k + 1;
+        const __amdgpu_buffer_rsrc_t nrs = unit_rsrc(nitem, nk, &nkind);
 #if WF_ABL == 1
         if (T < 0)
 #endif
-#if WF_X3
-        if constexpr (NS1 == 3 && NW * 2 + NW - 1 >= R0 && NW * 1 + NW - 1 < R0) {
+        if constexpr (INTER && NS1 == 3 && NW * 2 + NW - 1 >= R0 && NW * 1 + NW - 1 < R0) {
             // two full slots and a partial third: the waves that own three sub-series take them
             // three at a time, the others two at a time
             if (wave + 2 * NW < R0)
@@ -635,51 +629,63 @@ __global__ void __launch_bounds__(P::NT)
                              acc[0], acc[1], acc[2]);
             else
                 wf_sub512_x2(lds + wave * N1, lds + (wave + NW) * N1, lane, twa, twb, acc[0], acc[1]);
-            __builtin_amdgcn_sched_barrier(0);
-#if WF_ABL != 3
-            issue_loads(nrs);
-#endif
-        } else
-#endif
-        {
-        static_for_range<0, NS1>([&](auto ss) {
-            constexpr int s = decltype(ss)::value;
-            constexpr bool full = NW * s + NW - 1 < R0;             // every wave has this slot
-            constexpr bool nfull = NW * (s + 1) + NW - 1 < R0;      // ... and the next one
-            constexpr bool pfull = s > 0 && NW * (s - 1) + NW - 1 < R0;
-            constexpr bool head = INTER && full && nfull && (s % 2 == 0);
-            constexpr bool tail = INTER && full && pfull && (s % 2 == 1);
-            const int q = wave + NW * s;
-            if constexpr (head) {
-                wf_sub512_x2(lds + q * N1, lds + (q + NW) * N1, lane, twa, twb, acc[s], acc[s + 1]);
-            } else if constexpr (!tail) {
-                if constexpr (s == NS1 - 1 && WF_EARLY) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_loads(nrs);
-                    __builtin_amdgcn_sched_barrier(0);
+        } else {
+            static_for_range<0, NS1>([&](auto ss) {
+                constexpr int s = decltype(ss)::value;
+                constexpr bool full = NW * s + NW - 1 < R0;             // every wave has this slot
+                constexpr bool nfull = NW * (s + 1) + NW - 1 < R0;      // ... and the next one
+                constexpr bool pfull = s > 0 && NW * (s - 1) + NW - 1 < R0;
+                constexpr bool head = INTER && full && nfull && (s % 2 == 0);
+                constexpr bool tail = INTER && full && pfull && (s % 2 == 1);
+                const int q = wave + NW * s;
+                if constexpr (head) {
+                    wf_sub512_x2(lds + q * N1, lds + (q + NW) * N1, lane, twa, twb, acc[s], acc[s + 1]);
+                } else if constexpr (!tail) {
+                    if (full || q < R0) wf_sub512(lds + q * N1, lane, twa, twb, acc[s]);
                 }
-                if (full || q < R0) wf_sub512(lds + q * N1, lane, twa, twb, acc[s]);
-            }
-            if constexpr (s == NS1 - 1 && (head || tail || !WF_EARLY)) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue_loads(nrs);
-            }
-        });
+            });
         }
-        WF_STAMP(1)
-#if !WF_SPRE
-        __syncthreads();
+        if constexpr (BYP) {
+            if (last_of_item) {
+                // the atom's power spectrum in this pass: [atom][pass][q][c][lane], then from zero
+                const long atom = item;
+                const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+                    accg + ((atom * 2 + passB) * R0) * (8 * 64), 0, R0 * 512 * 8, 0x00020000);
+                const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+                for (int s = 0; s < NS1; ++s) {
+                    const int q = wv + NW * s;
+                    if (NW * s + NW - 1 < R0 || q < R0) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wf_u32x2, acc[s][c]), sr,
+                                                                  (unsigned)lane * 8u, (unsigned)((q * 8 + c) * 64) * 8u,
+                                                                  0);
+                            acc[s][c] = 0.0;
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#if WF_ABL != 3
+        issue_loads(nrs, nkind);
 #endif
+        kind = nkind, item = nitem, k = nk;
+        WF_STAMP(1)
+        __syncthreads();
     }
-    double* out = accg + couple * 2 * P::M;
+    if constexpr (!BYP) {
+        double* out = accg + couple * 2 * P::M;
 #pragma unroll
-    for (int s = 0; s < NS1; ++s) {
-        const int q = wave + NW * s;
-        if (q < R0) {
+        for (int s = 0; s < NS1; ++s) {
+            const int q = wave + NW * s;
+            if (q < R0) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int sb = (lane >> 3) + 8 * (lane & 7) + 64 * c;
-                out[2 * (q + R0 * sb) + passB] = acc[s][c];
+                for (int c = 0; c < 8; ++c) {
+                    const int sb = (lane >> 3) + 8 * (lane & 7) + 64 * c;
+                    out[2 * (q + R0 * sb) + passB] = acc[s][c];
+                }
             }
         }
     }
@@ -1103,6 +1109,124 @@ __global__ void __launch_bounds__(P::NT)
 #undef WF_STAMP
 }
 
+
+// By-particle inverse: a workgroup per atom (grid-stride).  spec: [atom][2][R0][8][64] from
+// k_wsplit_accum<BYP>; out[atom * ld + lag], atom-major.  The transposed transform of
+// P_A + i P_B as in k_wbp (which see), with registers to spare: two sub-series in flight.
+template <class P, int PF = 0, int ABL = 0>
+__global__ void __launch_bounds__(P::NT)
+    k_wbp_inverse(const double* __restrict__ spec, int T, long n_atoms, const cd* __restrict__ tw2,
+                  double* __restrict__ out, long ld) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cd* lds = reinterpret_cast<cd*>(smem_raw);
+    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW, M = P::M;
+    constexpr int NSA = (R0 + NW - 1) / NW;
+    int tid = threadIdx.x, lane = tid & 63;
+    const int wave = tid >> 6;
+    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cd*>(tw2), 0, (4 * M + 14 * 64) * 16, 0x00020000);
+    // the spectra of the first PF of this wave's sub-series are requested an atom ahead (during
+    // the previous atom's first stage and untangling); the rest when their turn comes
+    cd v[NSA][8];
+    auto load_spec = [&](long atom, int s) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int q = wv + NW * s;
+        const bool live = atom < n_atoms && q < R0 && ABL != 5;
+        const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double*>(spec + ((live ? atom : 0) * 2 * R0) * (8 * 64)), 0, live ? 2 * R0 * 512 * 8 : 0,
+            0x00020000);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            v[s][c].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                                       sr, (unsigned)lane * 8u, (unsigned)((q * 8 + c) * 64) * 8u, 0));
+            v[s][c].y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                                       sr, (unsigned)lane * 8u,
+                                                       (unsigned)(((R0 + q) * 8 + c) * 64) * 8u, 0));
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) load_spec(blockIdx.x, s);
+    for (long atom = blockIdx.x; atom < n_atoms; atom += gridDim.x) {
+        // per-thread offsets and LDS addresses are re-formed per atom: hoisted out of the loop
+        // they would be spilled
+        asm volatile("" : "+v"(tid), "+v"(lane));
+        {
+            cd twa[7], twb[7];
+#pragma unroll
+            for (int a = 0; a < 7; ++a) {
+                twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * M + a * 64) * 16u);
+                twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * M + (7 + a) * 64) * 16u);
+            }
+#pragma unroll
+            for (int s = PF; s < NSA; ++s) load_spec(atom, s);
+            const WfSubT wt(lane);
+#pragma unroll
+            for (int s = 0; s < NSA; ++s) {
+                const int q = wave + NW * s;
+                if (NW * s + NW - 1 < R0 || q < R0) {
+                    if constexpr (ABL == 1) {  // ablation: no sub-transforms
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) lds[q * N1 + 64 * c + lane] = v[s][c];
+                    } else {
+                        wt.run(lds + q * N1, v[s], twa, twb);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < PF; ++s) load_spec(atom + gridDim.x, s);
+        __builtin_amdgcn_sched_barrier(0);
+        cd x[R0];
+        const cd g = wf_load(twr, (unsigned)tid * 32u, 0u), g2 = wf_load(twr, (unsigned)tid * 64u, 0u),
+                 h = wf_load(twr, (unsigned)tid * 16u, 0u);
+#pragma unroll
+        for (int q = 0; q < R0; ++q) x[q] = lds[q * N1 + tid];
+        if constexpr (ABL != 2) {
+            cd te = cd{1.0, 0.0}, to = g;
+            if constexpr (R0 > 1) x[1] = cmul(x[1], to);
+#pragma unroll
+            for (int q = 2; q < R0; ++q) {
+                if (q & 1) {
+                    to = cmul(to, g2);
+                    x[q] = cmul(x[q], to);
+                } else {
+                    te = cmul(te, g2);
+                    x[q] = cmul(x[q], te);
+                }
+            }
+        }
+        if constexpr (ABL != 2) Dft<R0>::run(x);  // x[j'] = Q[tid + 512 j']
+        __syncthreads();  // every thread has read its G values: LDS free for Q in natural order
+#pragma unroll
+        for (int j = 0; j < R0; ++j) lds[tid + N1 * j] = x[j];
+        __syncthreads();
+        {
+            double* o = out + atom * ld;
+            const int mu = tid == 0 ? 0 : N1 - tid;
+#pragma unroll
+            for (int j = 0; j < R0; ++j) {
+                const int n = tid + N1 * j;
+                if constexpr (ABL == 3) {  // ablation: no untangling
+                    if (n < T) o[n] = x[j].x;
+                    continue;
+                }
+                const int jm = tid == 0 ? (R0 - j) % R0 : R0 - 1 - j;
+                const cd qm = lds[mu + N1 * jm];
+                const cd w = j == 0 ? h : cmul(h, tw_uniform(tw2, j * N1));  // W_2M^n = cos - i sin
+                const double ar = 0.5 * (x[j].x + qm.x), br = 0.5 * (x[j].y + qm.y), bi = -0.5 * (x[j].x - qm.x);
+                const double L = ar + (w.x * br - w.y * bi);
+                if constexpr (ABL == 4) {  // ablation: no division
+                    if (n < T) o[n] = L * (2.0 * (double)M * (double)(T - n));
+                    continue;
+                }
+                if (n < T) o[n] = L / (2.0 * (double)M * (double)(T - n));  // 2M(T-n) < 2^53: exact product
+            }
+        }
+        __syncthreads();  // Q consumed before the next atom's sub-series overwrite the LDS
+    }
+}
 
 // ================================================================================================
 // n_frames <= 512 (M = 512, R0 = 1): the whole padded series is ONE sub-series, so a wave works
