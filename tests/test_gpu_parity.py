@@ -285,8 +285,9 @@ def test_cabi_error_behaviour(ctx):
 
 @pytest.mark.parametrize("fft", [True, False])
 def test_vacf_long_trajectory(ctx, fft):
-    """n_frames beyond the on-chip limits (FFT plans stop at 10240, an LDS-resident column at
-    16376): the direct correlator with the column staged in global memory takes over."""
+    """n_frames beyond the on-chip limits (one on-chip transform stops at 10240 frames, an
+    LDS-resident column of the direct correlator at 16376): outer radix for the FFT, the column
+    staged in global memory for the direct correlator."""
     from oracle import numpy_oracle as orc
 
     v = orc.synthetic_velocities(17001, 3, 3, seed=17)
@@ -299,18 +300,21 @@ def test_vacf_long_trajectory(ctx, fft):
 @pytest.mark.parametrize("T,A,D", [(10241, 3, 3), (12000, 5, 3), (12000, 7, 3), (20000, 11, 2), (16385, 2, 2), (20000, 4, 3),
                                    (20481, 3, 1), (33000, 2, 3), (50000, 1, 3), (70000, 1, 2),
                                    (90000, 1, 1), (140000, 1, 2), (163840, 1, 1)])
-def test_vacf_fft_long_trajectory_timeseries(ctx, T, A, D):
-    """fft=True, lag sums only, n_frames beyond the largest on-chip transform: outer radix
-    2/4/8/16 step on the fly + on-chip 8192/10240-point transforms (csrc/fft_long.hip); covers
-    both on-chip plans, an odd column count (unpaired last column), rows past the end, and work
-    units of four adjacent pairs gathered 64 bytes per row (full units plus a ragged last one)."""
+def test_vacf_fft_long_trajectory(ctx, T, A, D):
+    """fft=True with n_frames beyond the largest on-chip transform: outer radix 2/4/8/16 while the
+    rows are read + on-chip transforms per pass (csrc/wfft.hpp), lag sums and the by-particle
+    array; covers every outer radix, an odd column count (unpaired last column), single-column
+    units in either half of a pair, rows past the end."""
     from oracle import numpy_oracle as orc
 
     v = orc.synthetic_velocities(T, A, D, seed=T % 1000 + A)
-    _, want_ts = orc.vacf_fft_batched(v)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
     ts, bp = run_vacf(ctx, v, True, False)
     assert bp is None
     assert ts.shape == want_ts.shape
+    assert scale_rel_err(ts, want_ts) < TOL
+    ts, bp = run_vacf(ctx, v, True, True)
+    assert scale_rel_err(bp, want_bp) < TOL
     assert scale_rel_err(ts, want_ts) < TOL
 
 
@@ -549,7 +553,7 @@ def test_helfand_fft_option_vs_oracle(ctx, T, A, D):
     assert scale_rel_err(ts, want_ts) < TOL
     ctx.set_option("helfand_fft", 1)
     try:
-        ts, bp = run_helfand(ctx, v, x, m, scale, True)  # per atom (direct fallback past 10240)
+        ts, bp = run_helfand(ctx, v, x, m, scale, True)  # per atom
     finally:
         ctx.set_option("helfand_fft", 0)
     assert np.all(bp[0] == 0.0)
@@ -749,14 +753,14 @@ def test_helfand_config4_full_per_gpu_share(ctx):
 
 
 @pytest.mark.parametrize("T,A,D", [(600, 19, 1), (1000, 37, 3), (1030, 24, 2), (2100, 21, 3), (2560, 18, 1),
-                                   (3000, 17, 3), (4200, 16, 2), (6000, 13, 3), (8192, 12, 1), (10000, 11, 3)])
+                                   (3000, 17, 3), (4200, 16, 2), (6000, 13, 3), (8192, 12, 1), (10000, 11, 3),
+                                   (12000, 9, 3), (20000, 11, 1), (20480, 8, 2), (33000, 5, 3), (50000, 4, 1)])
 @pytest.mark.parametrize("spec_atoms", [0, 6])
-def test_vacf_by_particle_two_kernel_path(ctx, T, A, D, spec_atoms):
-    """The by-particle FFT evaluation in two kernels (pass-split forward kernel leaving per-atom
-    power spectra, inverse kernel; blocks of `spec_atoms` atoms) for every first-stage radix and
+def test_vacf_by_particle_blocks_of_atoms(ctx, T, A, D, spec_atoms):
+    """The by-particle FFT evaluation (forward kernel leaving per-atom power spectra, inverse
+    kernel; blocks of `spec_atoms` atoms) for every first-stage radix, outer radices 1, 2, 4, 8 and
     every column-unit kind (D = 1: single columns of either half of a pair; D = 3: an aligned pair
-    plus a single column, alternating), against the oracle and against the one-kernel evaluation
-    (fft_debug 3).  velocityautocorr.py:196-215."""
+    plus a single column, alternating), against the oracle.  velocityautocorr.py:196-215."""
     from oracle import numpy_oracle as orc
 
     v = orc.synthetic_velocities(T, A, D, seed=4000 + T)
@@ -764,14 +768,10 @@ def test_vacf_by_particle_two_kernel_path(ctx, T, A, D, spec_atoms):
     try:
         ctx.set_option("bp_spec_atoms", spec_atoms)
         ts, bp = run_vacf(ctx, v, True, True)
-        ctx.set_option("fft_debug", 3)
-        ts1, bp1 = run_vacf(ctx, v, True, True)
     finally:
-        ctx.set_option("fft_debug", 0)
         ctx.set_option("bp_spec_atoms", 0)
     assert scale_rel_err(bp, want_bp) < TOL
     assert scale_rel_err(ts, want_ts) < TOL
-    assert scale_rel_err(bp, bp1) < TOL and scale_rel_err(ts, ts1) < TOL
 
 
 def test_vacf_by_particle_config2_full_size(ctx):

@@ -19,16 +19,6 @@ namespace {
 
 thread_local std::string g_tls_error;
 
-struct Tables {
-    cd* tw2 = nullptr;    // W_{2M}^n = exp(-i pi n / M), n < 2M
-    int* perm = nullptr;  // the plan's output position -> frequency (made on first use)
-};
-
-struct LongTables {     // fft_long.hip
-    cd* twL = nullptr;  // W_{2M'}^n, n < 2M'
-    int* perm = nullptr;  // plan M's output position -> frequency
-};
-
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -42,10 +32,8 @@ struct ta_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // device->host copies of by-particle blocks (host_compute)
     std::string err;
-    std::map<int, Tables> tables;
-    std::map<long, LongTables> long_tables;  // keyed by M'
-    std::map<int, cd*> wf_tables;            // wfft.hip tables, keyed by R0
-    DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, bounce, stage_buf, long_scratch, helf_p, helf_small;
+    std::map<int, cd*> wf_tables;  // wfft.hip twiddle tables, keyed by 64 * R0 + R
+    DevBuf partial, spec, ts_partial, out_lagsum, out_bp, masses, bounce, stage_buf, helf_p, helf_small;
     DevBuf pm_in[2];  // pair-major copies of frame-major *_dev inputs
     DevBuf bp_scratch;  // atom-major by-particle results before the transposition
     DevBuf bp_spec;     // per-atom power spectra of one block of atoms (two-kernel by-particle path)
@@ -111,14 +99,15 @@ inline size_t pm_bytes(int64_t n_frames, int64_t n_cols) {
     return (size_t)((n_cols + 1) / 2) * (size_t)pm_pitch(n_frames) * 16;
 }
 
-int get_wf_table(ta_ctx* ctx, int R0, cd** out) {
-    auto it = ctx->wf_tables.find(R0);
+int get_wf_table(ta_ctx* ctx, int R0, int R, cd** out) {
+    const int key = 64 * R0 + R;
+    auto it = ctx->wf_tables.find(key);
     if (it != ctx->wf_tables.end()) {
         *out = it->second;
         return TA_OK;
     }
-    std::vector<cd> a(wfft_table_elems(R0));
-    wfft_fill_table(R0, a.data());
+    std::vector<cd> a(wfft_table_elems(R0, R));
+    wfft_fill_table(R0, R, a.data());
     cd* d = nullptr;
     TA_HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(cd) * a.size()));
     hipError_t e = hipMemcpy(d, a.data(), sizeof(cd) * a.size(), hipMemcpyHostToDevice);
@@ -126,122 +115,8 @@ int get_wf_table(ta_ctx* ctx, int R0, cd** out) {
         hipFree(d);
         return fail(ctx, TA_E_HIP, std::string("twiddle table upload: ") + hipGetErrorString(e));
     }
-    ctx->wf_tables[R0] = d;
+    ctx->wf_tables[key] = d;
     *out = d;
-    return TA_OK;
-}
-
-int get_tables(ta_ctx* ctx, int M, int R0, Tables* out) {
-    auto it = ctx->tables.find(M);
-    if (it != ctx->tables.end()) {
-        *out = it->second;
-        return TA_OK;
-    }
-    // [0,2M): W_2M^n.  [2M,3M) and [3M,4M): the first-stage twiddles of pass A and pass B,
-    // W_2M^{u(2q+B)} stored [q][u] (u < M/R0) so that a wave's 64 consecutive butterflies read
-    // 1 KB contiguous (from the main table the same values sit 2q+B elements apart: one L2
-    // request per lane).  [4M,4M+4): zeros.
-    std::vector<cd> a(4 * (size_t)M + 4, cd{0.0, 0.0});  // + 64 zero bytes: the gathers' padding rows
-    const long double pi = 3.141592653589793238462643383279502884L;
-    auto w2m = [&](long n) {
-        n %= 2L * M;
-        if (n == 0) return cd{1.0, 0.0};
-        if (n == M) return cd{-1.0, 0.0};
-        if (2 * n == M) return cd{0.0, -1.0};
-        if (2 * n == 3L * M) return cd{0.0, 1.0};
-        long double h = pi * (long double)n / (long double)M;
-        return cd{(double)cosl(h), (double)-sinl(h)};
-    };
-    for (long n = 0; n < 2L * M; ++n) a[n] = w2m(n);
-    const long L0 = M / R0;
-    for (int B = 0; B < 2; ++B)
-        for (long q = 0; q < R0; ++q)
-            for (long u = 0; u < L0; ++u) a[(2 + B) * (size_t)M + q * L0 + u] = w2m(u * (2 * q + B));
-    Tables t;
-    TA_HIP_TRY(ctx, hipMalloc((void**)&t.tw2, sizeof(cd) * (4 * (size_t)M + 4)));
-    hipError_t e = hipMemcpy(t.tw2, a.data(), sizeof(cd) * (4 * (size_t)M + 4), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        hipFree(t.tw2);
-        return fail(ctx, TA_E_HIP, std::string("twiddle table upload: ") + hipGetErrorString(e));
-    }
-    ctx->tables[M] = t;
-    *out = t;
-    return TA_OK;
-}
-
-int get_long_tables(ta_ctx* ctx, int M, int Rout, LongTables* out) {
-    const long Mp = (long)M * Rout;
-    auto it = ctx->long_tables.find(Mp);
-    if (it != ctx->long_tables.end()) {
-        *out = it->second;
-        return TA_OK;
-    }
-    std::vector<cd> a(2 * (size_t)Mp);
-    const long double pi = 3.141592653589793238462643383279502884L;
-    for (long n = 0; n < 2 * Mp; ++n) {
-        if (n == 0) a[n] = cd{1.0, 0.0};
-        else if (n == Mp) a[n] = cd{-1.0, 0.0};
-        else if (2 * n == Mp) a[n] = cd{0.0, -1.0};
-        else if (2 * n == 3 * Mp) a[n] = cd{0.0, 1.0};
-        else {
-            const long double h = pi * (long double)n / (long double)Mp;
-            a[n] = cd{(double)cosl(h), (double)-sinl(h)};
-        }
-    }
-    std::vector<int> perm;
-    fft_long_perm(M, perm);
-    LongTables t;
-    hipError_t e = hipMalloc((void**)&t.twL, sizeof(cd) * a.size());
-    if (e == hipSuccess) e = hipMalloc((void**)&t.perm, sizeof(int) * perm.size());
-    if (e == hipSuccess) e = hipMemcpy(t.twL, a.data(), sizeof(cd) * a.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(t.perm, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        if (t.twL) hipFree(t.twL);
-        if (t.perm) hipFree(t.perm);
-        return fail(ctx, e == hipErrorOutOfMemory ? TA_E_NOMEM : TA_E_HIP,
-                    std::string("long-transform tables: ") + hipGetErrorString(e));
-    }
-    ctx->long_tables[Mp] = t;
-    *out = t;
-    return TA_OK;
-}
-
-const PlanEntry* plan_of_length(int M) {
-    for (const auto* tab : {&plans_pow2(), &plans_five()})
-        for (const auto& p : *tab)
-            if (p.M == M) return &p;
-    return nullptr;
-}
-
-// FFT lag sums for n_frames beyond the largest on-chip plan (fft_long.hip); timeseries only.
-int fft_long_impl(ta_ctx* ctx, const double* d_pm, int64_t pitch, int64_t T, int64_t A, int D,
-                  double* d_lagsum, hipStream_t st, int M, int Rout) {
-    const PlanEntry* plan = plan_of_length(M);
-    if (!plan) return fail(ctx, TA_E_INVALID, "no on-chip plan for the long transform");
-    int rc;
-    Tables tb;
-    LongTables lt;
-    if ((rc = get_tables(ctx, M, plan->R_first, &tb))) return rc;
-    if ((rc = get_long_tables(ctx, M, Rout, &lt))) return rc;
-    const int64_t n_quads = ((A * D + 1) / 2 + 3) / 4;  // a workgroup takes four adjacent pairs
-    int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu;
-    nwg = std::max<int64_t>(1, std::min(nwg, n_quads));
-    if (nwg >= 8) nwg -= nwg % 8;  // XCD-aware walk
-    const size_t blk = fft_long_acc_block(M);
-    const size_t acc_bytes = sizeof(double) * (size_t)nwg * 2 * Rout * blk;
-    if ((rc = ensure(ctx, ctx->partial, acc_bytes))) return rc;
-    if ((rc = ensure(ctx, ctx->spec, sizeof(double) * 2 * (size_t)Rout * M))) return rc;
-    if ((rc = ensure(ctx, ctx->long_scratch, sizeof(cd) * (size_t)nwg * 4 * 2 * Rout * M))) return rc;
-    TA_HIP_TRY(ctx, hipMemsetAsync(ctx->partial.p, 0, acc_bytes, st));
-    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    // pair-major slab: rows 2 elements apart, pairs 2*pitch apart, every pair complete (an odd
-    // last column is stored next to zeros)
-    TA_HIP_TRY(ctx, launch_fft_long_accum(M, (int)nwg, st, d_pm, 2, 2 * pitch, (int)T, 2 * ((A * D + 1) / 2),
-                                          Rout, tb.tw2, lt.twL, (double*)ctx->partial.p,
-                                          (cd*)ctx->long_scratch.p));
-    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-    TA_HIP_TRY(ctx, launch_fft_long_finish(M, Rout, (const double*)ctx->partial.p, (int)nwg, lt.perm,
-                                           lt.twL, (int)T, (double*)ctx->spec.p, d_lagsum, st));
     return TA_OK;
 }
 
@@ -325,115 +200,87 @@ int direct_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos,
 
 
 // ---- compute on pair-major slabs (every entry point ends up here) --------------------------
-// FFT VACF.  Lag sums only (d_bp == NULL): T <= 512 the small on-chip plans, T <= 10240 the
-// wave-local kernels of wfft.hpp, T <= 163840 the outer-radix path; with a by-particle array
-// the on-chip plans up to 10240 frames; everything else the direct correlator (same quantity:
-// velocityautocorr.py:217-238 == :208-215 mathematically).
+// FFT VACF (wfft.hpp): n_frames <= 512 the wave-independent 512-point kernels; up to 10240 frames
+// one on-chip transform per pass (R = 1), up to 163840 frames an outer radix R <= 16 in front of
+// it; beyond that the direct correlator (same quantity: velocityautocorr.py:217-238 == :208-215
+// mathematically).  Lag sums: forward kernel -> partial spectra per tuple of workgroups -> their
+// sum -> ONE inverse transform.  By-particle array: per block of atoms, forward kernel -> the
+// atoms' power spectra in scratch -> inverse kernel -> atom-major lags; then the transposition
+// into the caller's (n_frames, ld_bp) array, which also adds up its 64 atoms per lag.
 int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A, int D,
              double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st) {
     int rc;
     const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2;
-    int R0 = 0;
-    if (!d_bp && wfft_choose((long)T, &R0)) {
-        cd* tw = nullptr;
-        if ((rc = get_wf_table(ctx, R0, &tw))) return rc;
-        const int L2 = 2 * R0 * 512;
-        int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * wfft_max_wg_per_cu(R0);
-        // pass-split form (one pass per workgroup, the two workgroups of a couple share an
-        // XCD's L2: every input byte leaves HBM once) whenever 16 workgroups have work
-        const bool split = R0 > 1 && std::min<int64_t>(nwg, 2 * n_pairs) >= 16 && ctx->opt_fft_debug != 2;
-        if (split) nwg = std::min<int64_t>(nwg, 2 * n_pairs) / 16 * 16;
-        else if (R0 == 1) nwg = std::max<int64_t>(1, std::min(nwg, (n_pairs + 3) / 4));  // a wave per pair
-        else nwg = std::max<int64_t>(1, std::min(nwg, n_pairs));
-        int n_parts = (int)(split ? nwg / 2 : R0 == 1 ? 4 * nwg : nwg);
-        if ((rc = ensure(ctx, ctx->partial, sizeof(double) * (size_t)n_parts * L2))) return rc;
-        if ((rc = ensure(ctx, ctx->spec, sizeof(double) * (size_t)L2))) return rc;
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-        if (split)
-            TA_HIP_TRY(ctx, launch_wfft_split(R0, (int)nwg, st, pm, pitch, (int)T, n_pairs, tw,
-                                              (double*)ctx->partial.p));
-        else
-            TA_HIP_TRY(ctx, launch_wfft_accum(R0, (int)nwg, st, pm, pitch, (int)T, n_pairs, tw,
-                                              (double*)ctx->partial.p));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-        nwg = n_parts;
-        // the summed spectrum -> lag sums: ONE inverse transform per launch, run by the on-chip
-        // plan of the same length (its finalize kernel consumes the digit-reversed order, which
-        // the sum over workgroups produces on the way)
-        const PlanEntry* fin = plan_of_length(R0 * 512);
-        if (!fin) {
-            TA_HIP_TRY(ctx, launch_wfft_finish(R0, (const double*)ctx->partial.p, (int)nwg, tw, (int)T,
+    int R0 = 0, R = 1;
+    if (!wfft_choose((long)T, &R0, &R))
+        return direct_impl(ctx, MODE_VACF, pm, nullptr, nullptr, T, A, D, pitch, 1.0, d_lagsum, d_bp, ld_bp, st);
+    cd* tw = nullptr;
+    if ((rc = get_wf_table(ctx, R0, R, &tw))) return rc;
+    const int64_t Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
+    const int64_t L = 2L * R * R0 * 512;  // doubles per spectrum
+    const int64_t cap = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * wfft_max_wg_per_cu(R0);
+    // forward grid: whole tuples of 2R workgroups on each of the 8 XCDs, no more tuples than groups of units
+    auto forward_grid = [&](int64_t n_groups) {
+        const int64_t gran = 16 * R;
+        return std::max<int64_t>(gran, std::min<int64_t>(cap, 2 * R * n_groups) / gran * gran);
+    };
+    if (d_bp) {
+        if ((rc = ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp))) return rc;
+        if ((rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T))) return rc;
+    }
+    if (R0 == 1) {
+        if (!d_bp) {
+            const int64_t nwg = std::max<int64_t>(1, std::min(cap, (n_pairs + 3) / 4));  // a wave per pair
+            const int n_parts = (int)(4 * nwg);
+            if ((rc = ensure(ctx, ctx->partial, sizeof(double) * (size_t)n_parts * L))) return rc;
+            if ((rc = ensure(ctx, ctx->spec, sizeof(double) * (size_t)L))) return rc;
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+            TA_HIP_TRY(ctx, launch_w1_accum((int)nwg, st, pm, pitch, (int)T, n_pairs, tw, (double*)ctx->partial.p));
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+            TA_HIP_TRY(ctx, launch_wfft_finish(R0, (const double*)ctx->partial.p, n_parts, tw, (int)T,
                                                (double*)ctx->spec.p, d_lagsum, st));
             return TA_OK;
         }
-        Tables tb;
-        if ((rc = get_tables(ctx, fin->M, fin->R_first, &tb))) return rc;
-        if (!tb.perm) {
-            std::vector<int> perm;
-            fin->perm(perm);
-            int* d = nullptr;
-            TA_HIP_TRY(ctx, hipMalloc((void**)&d, sizeof(int) * perm.size()));
-            hipError_t e = hipMemcpy(d, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                hipFree(d);
-                return fail(ctx, TA_E_HIP, std::string("permutation upload: ") + hipGetErrorString(e));
-            }
-            ctx->tables[fin->M].perm = tb.perm = d;
-        }
-        TA_HIP_TRY(ctx, launch_wfft_sum_perm((const double*)ctx->partial.p, (int)nwg, fin->M, tb.perm,
-                                             (double*)ctx->spec.p, st));
-        FftArgs fa{(int)T, tb.tw2, (const double*)ctx->spec.p, 1, d_lagsum};
-        TA_HIP_TRY(ctx, fin->finalize(st, fa));
-        return TA_OK;
-    }
-    if (d_bp && wfft_choose((long)T, &R0)) {
-        // by-particle mode on the wave-local machinery (k_wbp): per-atom lag values to an
-        // atom-major scratch (512-byte stores), then the transposition into the caller's
-        // (n_frames, ld_bp) array, which also adds up its 64 atoms per lag
-        cd* tw = nullptr;
-        if ((rc = get_wf_table(ctx, R0, &tw))) return rc;
-        const int64_t Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
-        int64_t nwg = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * wfft_max_wg_per_cu(R0);
-        nwg = std::max<int64_t>(1, std::min(nwg, R0 == 1 ? (A + 3) / 4 : A));
-        if ((rc = ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp))) return rc;
-        if ((rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T))) return rc;
+        const int64_t nwg = std::max<int64_t>(1, std::min(cap, (A + 3) / 4));  // a wave per atom
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-        // two kernels per block of atoms where a block fills the chip: the pass-split forward
-        // kernel (couples of workgroups share their rows through the XCD's L2; half the
-        // accumulators per thread, so rows are prefetched and sub-series interleaved as on the
-        // lag-sum path) leaves each atom's power spectrum in scratch, the inverse kernel turns
-        // it into the atom's lags.  Blocks start on an even atom, so on a pair boundary.
-        const int64_t fwd_wg = std::min<int64_t>((int64_t)ctx->n_cu * wfft_max_wg_per_cu(R0), 2 * A) / 16 * 16;
-        if (R0 > 1 && fwd_wg >= 16 && ctx->opt_fft_debug != 3) {
-            const size_t spec_per_atom = sizeof(double) * 2 * (size_t)R0 * 512;
-            const int64_t CA = std::min<int64_t>(A, ctx->opt_bp_spec_atoms > 0 ? (ctx->opt_bp_spec_atoms + 1) / 2 * 2 : 16384);
-            if ((rc = ensure(ctx, ctx->bp_spec, spec_per_atom * (size_t)CA))) return rc;
-            for (int64_t a0 = 0; a0 < A; a0 += CA) {
-                const int64_t ca = std::min(CA, A - a0);
-                const int64_t groups = D & 1 ? (ca + 1) / 2 : ca;  // a couple of workgroups per group of atoms
-                const int64_t fw = std::max<int64_t>(16, std::min<int64_t>(fwd_wg, 2 * groups) / 16 * 16);
-                TA_HIP_TRY(ctx, launch_wfft_by_particle2(R0, (int)fw, (int)std::min<int64_t>(nwg, ca), st,
-                                                         pm + (a0 * D / 2) * pitch * 2, pitch, (int)T, ca, D, tw,
-                                                         (double*)ctx->bp_spec.p,
-                                                         (double*)ctx->bp_scratch.p + a0 * Tp, Tp,
-                                                         (int)ctx->opt_bp_prefetch));
-            }
-        } else {
-            TA_HIP_TRY(ctx, launch_wfft_by_particle(R0, (int)nwg, st, pm, pitch, (int)T, A, D, tw,
-                                                    (double*)ctx->bp_scratch.p, Tp));
+        TA_HIP_TRY(ctx, launch_w1_bp((int)nwg, st, pm, pitch, (int)T, A, D, tw, (double*)ctx->bp_scratch.p, Tp));
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+    } else if (!d_bp) {
+        const int64_t nwg = forward_grid(n_pairs), n_tuples = nwg / (2 * R);
+        if ((rc = ensure(ctx, ctx->partial, sizeof(double) * (size_t)n_tuples * L))) return rc;
+        if ((rc = ensure(ctx, ctx->spec, sizeof(double) * (size_t)L))) return rc;
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+        TA_HIP_TRY(ctx, launch_wfft_forward(R0, R, false, (int)nwg, st, pm, pitch, (int)T, n_pairs, D, tw,
+                                            (double*)ctx->partial.p));
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+        // the summed spectrum -> lag sums: ONE inverse transform per launch
+        TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->partial.p, (int)n_tuples, L, (double*)ctx->spec.p, st));
+        TA_HIP_TRY(ctx, launch_wfft_inverse(R0, R, 1, st, (const double*)ctx->spec.p, (int)T, 1, tw, d_lagsum, 0, 0));
+        return TA_OK;
+    } else {
+        // blocks of atoms sized by the spectrum scratch (2.5 GiB unless the bp_spec_atoms option
+        // says otherwise); a block starts on an even atom, so on a column-pair boundary
+        const size_t spec_bytes = sizeof(double) * (size_t)L;
+        int64_t CA = ctx->opt_bp_spec_atoms > 0 ? ctx->opt_bp_spec_atoms : (int64_t)(((size_t)5 << 29) / spec_bytes);
+        CA = std::min<int64_t>(A, std::max<int64_t>(2, (CA + 1) / 2 * 2));
+        if ((rc = ensure(ctx, ctx->bp_spec, spec_bytes * (size_t)CA))) return rc;
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+        for (int64_t a0 = 0; a0 < A; a0 += CA) {
+            const int64_t ca = std::min(CA, A - a0);
+            const int64_t groups = D & 1 ? (ca + 1) / 2 : ca;  // a tuple of workgroups per group of atoms
+            TA_HIP_TRY(ctx, launch_wfft_forward(R0, R, true, (int)forward_grid(groups), st,
+                                                pm + (a0 * D / 2) * pitch * 2, pitch, (int)T, ca, D, tw,
+                                                (double*)ctx->bp_spec.p));
+            TA_HIP_TRY(ctx, launch_wfft_inverse(R0, R, (int)std::min<int64_t>(cap, ca), st,
+                                                (const double*)ctx->bp_spec.p, (int)T, ca, tw,
+                                                (double*)ctx->bp_scratch.p + a0 * Tp, Tp, (int)ctx->opt_bp_prefetch));
         }
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-        TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp,
-                                            (double*)ctx->ts_partial.p, st));
-        TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)n_tiles, T, d_lagsum, st));
-        return TA_OK;
     }
-    // beyond the on-chip lengths: lag sums by the outer-radix path, anything else by the direct
-    // correlator (same quantity: velocityautocorr.py:217-238 == :208-215 mathematically)
-    int long_M = 0, long_R = 0;
-    if (!d_bp && fft_long_choose((long)T, &long_M, &long_R))
-        return fft_long_impl(ctx, pm, pitch, T, A, D, d_lagsum, st, long_M, long_R);
-    return direct_impl(ctx, MODE_VACF, pm, nullptr, nullptr, T, A, D, pitch, 1.0, d_lagsum, d_bp, ld_bp, st);
+    TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp,
+                                        (double*)ctx->ts_partial.p, st));
+    TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)n_tiles, T, d_lagsum, st));
+    return TA_OK;
 }
 
 // Helfand mean squared differences (viscosity.py:201-233); the "helfand_fft" option evaluates
@@ -444,9 +291,9 @@ int helfand_impl(ta_ctx* ctx, const double* pm_vel, const double* pm_pos, const 
     int rc;
     const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2;
     const bool fft_ok = ctx->opt_helfand_fft && T >= 2;
-    int r0 = 0, lm = 0, lr = 0;
-    const bool has_fft_ts = wfft_choose((long)T, &r0) || fft_long_choose((long)T, &lm, &lr);
-    if (fft_ok && !d_bp && has_fft_ts) {
+    int r0 = 0, ro = 0;
+    const bool has_fft = wfft_choose((long)T, &r0, &ro);
+    if (fft_ok && !d_bp && has_fft) {
         const int n_parts = (int)std::min<int64_t>(1024, n_pairs);
         if ((rc = ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)))) return rc;
         if ((rc = ensure(ctx, ctx->helf_small, sizeof(double) * ((size_t)n_parts * T + 3 * (size_t)T + 1)))) return rc;
@@ -462,7 +309,7 @@ int helfand_impl(ta_ctx* ctx, const double* pm_vel, const double* pm_pos, const 
         TA_HIP_TRY(ctx, launch_helfand_combine(Q, S2, C, (int)T, scale / (double)D, d_lagsum, st));
         return TA_OK;
     }
-    if (fft_ok && d_bp && wfft_choose((long)T, &r0)) {
+    if (fft_ok && d_bp && has_fft) {
         if ((rc = ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)))) return rc;
         if ((rc = ensure(ctx, ctx->helf_small, sizeof(double) * ((size_t)T + 1) * A))) return rc;
         double* P = (double*)ctx->helf_p.p;
@@ -623,17 +470,9 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ta_stage_free(ctx);
-    for (auto& kv : ctx->tables) {
-        hipFree(kv.second.tw2);
-        if (kv.second.perm) hipFree(kv.second.perm);
-    }
     for (auto& kv : ctx->wf_tables) hipFree(kv.second);
-    for (auto& kv : ctx->long_tables) {
-        hipFree(kv.second.twL);
-        hipFree(kv.second.perm);
-    }
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
-                      &ctx->masses, &ctx->bounce, &ctx->stage_buf, &ctx->long_scratch, &ctx->helf_p,
+                      &ctx->masses, &ctx->bounce, &ctx->stage_buf, &ctx->helf_p,
                       &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1], &ctx->bp_scratch, &ctx->bp_spec})
         if (b->p) hipFree(b->p);
     for (auto& q : ctx->ring)
@@ -651,7 +490,7 @@ int ta_trim(ta_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_bp, &ctx->bounce, &ctx->stage_buf,
-                      &ctx->long_scratch, &ctx->helf_p, &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1],
+                      &ctx->helf_p, &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1],
                       &ctx->bp_scratch, &ctx->bp_spec})
         if (b->p) {
             hipFree(b->p);
@@ -678,24 +517,15 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
 }
 
 int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_stages) {
-    int R0 = 0;
-    if (wfft_choose((long)n_frames, &R0)) {
-        // first-stage radix R0 (none up to 512 frames), then one wave per 512-point sub-series (8 x 8 x 8)
-        if (m_out) *m_out = (int64_t)R0 * 512;
-        if (n_threads) *n_threads = R0 == 1 ? 64 : 512;
-        if (n_stages) *n_stages = R0 == 1 ? 3 : 4;
-        return TA_OK;
-    }
-    int long_M = 0, long_R = 0;
-    if (fft_long_choose((long)n_frames, &long_M, &long_R)) {
-        // outer radix step + on-chip transform (lag sums only; fft_long.hip)
-        const PlanEntry* q = plan_of_length(long_M);
-        if (m_out) *m_out = (int64_t)long_M * long_R;
-        if (n_threads) *n_threads = q ? q->NT : 0;
-        if (n_stages) *n_stages = q ? q->S + 1 : 0;
-        return TA_OK;
-    }
-    return fail(nullptr, TA_E_UNSUPPORTED, "n_frames exceeds the largest FFT plan");
+    int R0 = 0, R = 1;
+    if (!wfft_choose((long)n_frames, &R0, &R))
+        return fail(nullptr, TA_E_UNSUPPORTED, "n_frames exceeds the largest FFT plan");
+    // [outer radix R while the rows are read,] first-stage radix R0 (none up to 512 frames), then
+    // one wave per 512-point sub-series (8 x 8 x 8)
+    if (m_out) *m_out = (int64_t)R * R0 * 512;
+    if (n_threads) *n_threads = R0 == 1 ? 64 : 512;
+    if (n_stages) *n_stages = (R0 == 1 ? 3 : 4) + (R > 1 ? 1 : 0);
+    return TA_OK;
 }
 
 /* ------------------------------------------------------------------ staging */

@@ -1,6 +1,6 @@
 // direct.hip — launchers for the all-lag direct correlators and small helpers.
 #include "direct_kernels.hpp"
-#include "fft_kernels.hpp"
+#include "fft_engine.hpp"
 #include "ta_internal.hpp"
 
 namespace ta {

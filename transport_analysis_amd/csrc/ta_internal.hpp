@@ -10,27 +10,6 @@
 
 namespace ta {
 
-struct FftArgs {        // k_fft_finalize
-    int T;
-    const cd* tw2;        // [0,2M): W_{2M}^n; [2M,3M): first-stage table [q][u] = W_M^{q u}; ...
-    const double* spec;   // [n_slices][2][M], the plan's digit-reversed bin order
-    int n_slices;
-    double* lagsum;       // [T]
-};
-
-// An on-chip plan (M = 2^a or 5*2^a, 16..10240): today only its inverse transform is used
-// (k_fft_finalize: ONE per launch) plus, for M = 8192 / 10240, the outer-radix path's stages.
-struct PlanEntry {
-    int M, NT, S;
-    int R_first;                          // first radix: layout of the first-stage twiddle table
-    size_t lds_bytes;
-    hipError_t (*finalize)(hipStream_t st, const FftArgs& a);
-    void (*perm)(std::vector<int>& out);  // output position -> frequency (digit reversal)
-};
-
-const std::vector<PlanEntry>& plans_pow2();
-const std::vector<PlanEntry>& plans_five();
-
 // direct.hip
 // vel / pos: pair-major slabs (layout.hip) of `pitch` rows per pair
 hipError_t launch_direct(int mode, bool f32, int L, const double* vel, const double* pos,
@@ -45,16 +24,6 @@ hipError_t launch_row_sums(const double* bp, long n_rows, long n_cols, long ld, 
                            hipStream_t st);
 hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,
                                hipStream_t st);
-// fft_long.hip: FFT lag sums beyond the on-chip transform length (timeseries path)
-bool fft_long_choose(long n_frames, int* M, int* Rout);  // smallest M' = Rout*M >= n_frames
-void fft_long_perm(int M, std::vector<int>& perm);       // position -> frequency of plan M's output
-size_t fft_long_acc_block(int M);                        // doubles per workgroup and pass
-hipError_t launch_fft_long_accum(int M, int nwg, hipStream_t st, const double* vel, long ld_row, long pair_stride, int T,
-                                 long n_cols, int Rout, const cd* tw2, const cd* twL, double* accg,
-                                 cd* scratch /* [nwg][4][2*Rout][M] */);
-hipError_t launch_fft_long_finish(int M, int Rout, const double* partial, int n_parts, const int* perm,
-                                  const cd* twL, int T, double* spec, double* lagsum, hipStream_t st);
-
 // helfand_fft.hip: optional FFT evaluation of the Helfand lag sums
 // pair-major slabs in, product slab P out in the same layout; Qpart [n_parts][T] zeroed by caller
 hipError_t launch_helfand_product(const double* vel, const double* pos, const double* masses,
@@ -81,28 +50,25 @@ hipError_t launch_bp_transpose(const double* src, long src_ld, long n_atoms, lon
 hipError_t launch_synth(double* pm, long pitch, long n_cols, long T, unsigned long long seed,
                         long col_offset, long n_cols_total, hipStream_t st);
 
-// wfft.hip: power-spectrum accumulation on pair-major slabs, M = R0 * 512
-bool wfft_choose(long n_frames, int* R0);
-size_t wfft_table_elems(int R0);
-void wfft_fill_table(int R0, cd* table);
+// wfft.hip: FFT evaluation on pair-major slabs, padded length L = 2 R R0 512 (wfft.hpp)
+bool wfft_choose(long n_frames, int* R0, int* R);  // smallest R R0 512 >= n_frames
+size_t wfft_table_elems(int R0, int R);
+void wfft_fill_table(int R0, int R, cd* table);
 int wfft_max_wg_per_cu(int R0);
-hipError_t launch_wfft_accum(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
-                             long n_pairs, const cd* tw, double* accg /* [nwg][2M], natural order */);
-// by-particle mode (k_wbp): lag values of every atom, atom-major out[atom * ld + lag]
-hipError_t launch_wfft_by_particle(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
-                                   long n_atoms, int D, const cd* tw, double* out, long ld);
-// pass-split form: nwg a multiple of 16, accg [nwg/2][2M] (every element written by the launch)
-// two-kernel by-particle evaluation: spec holds n_atoms * 2 * R0 * 512 doubles of scratch
-hipError_t launch_wfft_by_particle2(int R0, int nwg_fwd, int nwg_inv, hipStream_t st, const double* pm,
-                                    long pitch, int T, long n_atoms, int D, const cd* tw, double* spec,
-                                    double* out, long ld, int prefetch);
-hipError_t launch_wfft_split(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
-                             long n_pairs, const cd* tw, double* accg);
+// forward kernel (R0 > 1), nwg a multiple of 16 R: lag-sum mode n_units column pairs ->
+// accg [nwg / 2R][L] partial spectra; by-particle mode n_units atoms -> accg [n_units][L]
+hipError_t launch_wfft_forward(int R0, int R, bool by_particle, int nwg, hipStream_t st, const double* pm,
+                               long pitch, int T, long n_units, int D, const cd* tw, double* accg);
+// inverse kernel (R0 > 1): lag values of n_items spectra, out[item * ld + lag]
+hipError_t launch_wfft_inverse(int R0, int R, int nwg, hipStream_t st, const double* spec, int T, long n_items,
+                               const cd* tw, double* out, long ld, int prefetch);
+// n_frames <= 512 (R0 = 1): lag-sum kernel (accg [4 nwg][1024], natural bin order) with its
+// finish (sum, cosine sums), and the fused by-particle kernel (atom-major out[atom * ld + lag])
+hipError_t launch_w1_accum(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
+                           const cd* tw, double* accg);
+hipError_t launch_w1_bp(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_atoms, int D,
+                        const cd* tw, double* out, long ld);
 hipError_t launch_wfft_finish(int R0, const double* partial, int n_parts, const cd* tw, int T,
                               double* spec /* [2M] */, double* lagsum, hipStream_t st);
-// spec[pass*M + p] = sum over workgroups of bin 2*perm[p] + pass: the natural-order blocks summed
-// into the [2][M] digit-reversed layout that the on-chip plan's k_fft_finalize consumes
-hipError_t launch_wfft_sum_perm(const double* partial, int n_parts, int M, const int* perm, double* spec,
-                                hipStream_t st);
 
 }  // namespace ta

@@ -11,72 +11,47 @@ namespace ta {
 namespace {
 
 constexpr int kR0s[] = {1, 2, 4, 5, 8, 10, 16, 20};
+constexpr int kOuter[] = {1, 2, 4, 8, 16};
 
-template <int R0>
-hipError_t launch_accum_r0(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
-                           const cd* tw, double* accg) {
-    using P = WPlan<R0>;
-    auto kern = k_wfft_accum<P, false, WF_TOUCH_DEFAULT, WF_INTER_DEFAULT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_pairs, tw, accg, nullptr);
-    return hipGetLastError();
+template <class K>
+hipError_t set_lds(K kern, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
 }
 
-// pass-split kernel (one pass per workgroup, couples b / b + 8): grid a multiple of 16
 template <int R0>
-hipError_t launch_split_r0(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
-                           const cd* tw, double* accg) {
+hipError_t launch_forward_r0(int R, bool byp, int nwg, hipStream_t st, const double* pm, long pitch, int T,
+                             long n_units, int D, const cd* tw, double* accg) {
     using P = WPlan<R0>;
-    auto kern = k_wsplit_accum<P, false, true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds);
+    auto kern = byp ? (R > 1 ? k_wsplit_accum<P, true, true> : k_wsplit_accum<P, true, false>)
+                    : (R > 1 ? k_wsplit_accum<P, false, true> : k_wsplit_accum<P, false, false>);
+    hipError_t e = set_lds(kern, P::kLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_pairs, tw, accg, nullptr, 0);
-    return hipGetLastError();
-}
-
-// by-particle, two kernels: the pass-split forward kernel leaves every atom's power spectrum in
-// `spec` ([atom][2][R0][8][64] doubles), the inverse kernel turns each into the atom's lags
-template <int R0>
-hipError_t launch_bp2_r0(int nwg_fwd, int nwg_inv, hipStream_t st, const double* pm, long pitch, int T,
-                         long n_atoms, int D, const cd* tw, double* spec, double* out, long ld, int pf) {
-    using P = WPlan<R0>;
-    constexpr int NSA = (R0 + P::NW - 1) / P::NW;
-    auto fwd = k_wsplit_accum<P, false, true, true>;
-    auto inv = pf <= 0 ? k_wbp_inverse<P, 0> : pf == 1 || NSA == 1 ? k_wbp_inverse<P, 1>
-               : pf == 2 || NSA == 2 ? k_wbp_inverse<P, (NSA < 2 ? NSA : 2)> : k_wbp_inverse<P, NSA>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(inv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)P::kLds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fwd, dim3(nwg_fwd), dim3(P::NT), P::kLds, st, pm, pitch, T, n_atoms, tw, spec, nullptr, D);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(inv, dim3(nwg_inv), dim3(P::NT), P::kLds, st, spec, T, n_atoms, tw, out, ld);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_units, tw, accg, D, R, nullptr);
     return hipGetLastError();
 }
 
 template <int R0>
-hipError_t launch_bp_r0(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_atoms, int D,
-                        const cd* tw, double* out, long ld) {
+hipError_t launch_inverse_r0(int R, int nwg, hipStream_t st, const double* spec, int T, long n_items, const cd* tw,
+                             double* out, long ld, int pf) {
     using P = WPlan<R0>;
-    auto kern = k_wbp<P, false>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds);
+    constexpr int NSA = P::NS1;
+    auto kern = R > 1    ? k_winverse<P, true, 0>
+                : pf <= 0 ? k_winverse<P, false, 0>
+                : pf == 1 ? k_winverse<P, false, 1>
+                : pf == 2 ? k_winverse<P, false, (NSA < 2 ? NSA : 2)>
+                          : k_winverse<P, false, NSA>;
+    hipError_t e = set_lds(kern, P::kLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_atoms, D, tw, out, ld, nullptr);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, spec, T, n_items, tw, out, ld, R);
     return hipGetLastError();
 }
 
 template <int R0>
 int max_wg_r0() {
     using P = WPlan<R0>;
-    auto kern = k_wfft_accum<P, false, WF_TOUCH_DEFAULT, WF_INTER_DEFAULT>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)P::kLds);
+    auto kern = k_wsplit_accum<P, false, false>;
+    (void)set_lds(kern, P::kLds);
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, P::NT, P::kLds) != hipSuccess || n < 1) n = 1;
     return n;
@@ -97,25 +72,6 @@ __global__ void __launch_bounds__(256)
     }
     for (; w < n_parts; ++w) s0 += partial[(long)w * L2 + k];
     spec[k] = (s0 + s1) + (s2 + s3);
-}
-
-__global__ void __launch_bounds__(256)
-    k_wf_sum_perm(const double* __restrict__ partial, int n_parts, int M, const int* __restrict__ perm,
-                  double* __restrict__ spec) {
-    const int i = blockIdx.x * 256 + threadIdx.x;  // pass*M + p
-    if (i >= 2 * M) return;
-    const int pass = i / M, p = i - pass * M;
-    const long k = 2L * perm[p] + pass;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int w = 0;
-    for (; w + 3 < n_parts; w += 4) {
-        s0 += partial[(long)w * 2 * M + k];
-        s1 += partial[(long)(w + 1) * 2 * M + k];
-        s2 += partial[(long)(w + 2) * 2 * M + k];
-        s3 += partial[(long)(w + 3) * 2 * M + k];
-    }
-    for (; w < n_parts; ++w) s0 += partial[(long)w * 2 * M + k];
-    spec[i] = (s0 + s1) + (s2 + s3);
 }
 
 // The lag sums are the real part of the inverse transform of the (real) summed spectrum:
@@ -151,18 +107,21 @@ __global__ void __launch_bounds__(256)
 
 }  // namespace
 
-bool wfft_choose(long n_frames, int* R0) {
-    for (int r : kR0s)
-        if ((long)r * 512 >= n_frames) {
-            *R0 = r;
-            return true;
+// smallest L/2 = R * R0 * 512 >= n_frames, the smaller outer radix among equals
+bool wfft_choose(long n_frames, int* R0, int* R) {
+    long best = 0;
+    for (int ro : kOuter)
+        for (int r : kR0s) {
+            if (r == 1 && ro > 1) continue;  // the 512-point kernels have no outer radix
+            const long m = (long)ro * r * 512;
+            if (m >= n_frames && (!best || m < best)) best = m, *R0 = r, *R = ro;
         }
-    return false;
+    return best != 0;
 }
 
-size_t wfft_table_elems(int R0) { return wf_table_elems(R0); }
+size_t wfft_table_elems(int R0, int R) { return wf_table_elems(R0, R); }
 
-void wfft_fill_table(int R0, cd* a) { wf_fill_table(R0, a); }
+void wfft_fill_table(int R0, int R, cd* a) { wf_fill_table(R0, R, a); }
 
 int wfft_max_wg_per_cu(int R0) {
     switch (R0) {
@@ -181,8 +140,7 @@ int wfft_max_wg_per_cu(int R0) {
 // R0 = 1 (n_frames <= 512): independent waves, 4 per workgroup; accg [4 nwg][1024]
 hipError_t launch_w1_accum(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
                            const cd* tw, double* accg) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_w1_accum),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W1::kLds);
+    hipError_t e = set_lds(k_w1_accum, W1::kLds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_w1_accum, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_pairs, tw, accg);
     return hipGetLastError();
@@ -190,80 +148,47 @@ hipError_t launch_w1_accum(int nwg, hipStream_t st, const double* pm, long pitch
 
 hipError_t launch_w1_bp(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_atoms, int D,
                         const cd* tw, double* out, long ld) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_w1_bp),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W1::kLds);
+    hipError_t e = set_lds(k_w1_bp, W1::kLds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_w1_bp, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_atoms, D, tw, out, ld);
     return hipGetLastError();
 }
 
-hipError_t launch_wfft_accum(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
-                             long n_pairs, const cd* tw, double* accg) {
+// Forward kernel (R0 > 1): nwg a multiple of 16 R.  Lag-sum mode (by_particle false): n_units
+// column pairs, accg [nwg / 2R][L] partial spectra; by-particle mode: n_units atoms of D columns,
+// accg [n_units][L].  L = 2 R R0 512 doubles per spectrum.
+hipError_t launch_wfft_forward(int R0, int R, bool by_particle, int nwg, hipStream_t st, const double* pm,
+                               long pitch, int T, long n_units, int D, const cd* tw, double* accg) {
+    if (R < 1 || nwg < 16 * R || nwg % (16 * R)) return hipErrorInvalidValue;
     switch (R0) {
-        case 1: return launch_w1_accum(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 2: return launch_accum_r0<2>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 4: return launch_accum_r0<4>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 5: return launch_accum_r0<5>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 8: return launch_accum_r0<8>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 10: return launch_accum_r0<10>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 16: return launch_accum_r0<16>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 20: return launch_accum_r0<20>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
+        case 2: return launch_forward_r0<2>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 4: return launch_forward_r0<4>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 5: return launch_forward_r0<5>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 8: return launch_forward_r0<8>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 10: return launch_forward_r0<10>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 16: return launch_forward_r0<16>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 20: return launch_forward_r0<20>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_wfft_sum_perm(const double* partial, int n_parts, int M, const int* perm, double* spec,
-                                hipStream_t st) {
-    hipLaunchKernelGGL(k_wf_sum_perm, dim3((2 * M + 255) / 256), dim3(256), 0, st, partial, n_parts, M, perm, spec);
-    return hipGetLastError();
-}
-
-hipError_t launch_wfft_by_particle(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
-                                   long n_atoms, int D, const cd* tw, double* out, long ld) {
+// Inverse kernel (R0 > 1): the lag values of n_items spectra, out[item * ld + lag].
+hipError_t launch_wfft_inverse(int R0, int R, int nwg, hipStream_t st, const double* spec, int T, long n_items,
+                               const cd* tw, double* out, long ld, int prefetch) {
+    if (R < 1 || nwg < 1) return hipErrorInvalidValue;
     switch (R0) {
-        case 1: return launch_w1_bp(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
-        case 2: return launch_bp_r0<2>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
-        case 4: return launch_bp_r0<4>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
-        case 5: return launch_bp_r0<5>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
-        case 8: return launch_bp_r0<8>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
-        case 10: return launch_bp_r0<10>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
-        case 16: return launch_bp_r0<16>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
-        case 20: return launch_bp_r0<20>(nwg, st, pm, pitch, T, n_atoms, D, tw, out, ld);
+        case 2: return launch_inverse_r0<2>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 4: return launch_inverse_r0<4>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 5: return launch_inverse_r0<5>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 8: return launch_inverse_r0<8>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 10: return launch_inverse_r0<10>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 16: return launch_inverse_r0<16>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 20: return launch_inverse_r0<20>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_wfft_split(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
-                             long n_pairs, const cd* tw, double* accg) {
-    if (nwg < 16 || nwg % 16) return hipErrorInvalidValue;
-    switch (R0) {
-        case 2: return launch_split_r0<2>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 4: return launch_split_r0<4>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 5: return launch_split_r0<5>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 8: return launch_split_r0<8>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 10: return launch_split_r0<10>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 16: return launch_split_r0<16>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-        case 20: return launch_split_r0<20>(nwg, st, pm, pitch, T, n_pairs, tw, accg);
-    }
-    return hipErrorInvalidValue;
-}
-
-hipError_t launch_wfft_by_particle2(int R0, int nwg_fwd, int nwg_inv, hipStream_t st, const double* pm,
-                                    long pitch, int T, long n_atoms, int D, const cd* tw, double* spec,
-                                    double* out, long ld, int pf) {
-    if (nwg_fwd < 16 || nwg_fwd % 16 || nwg_inv < 1) return hipErrorInvalidValue;
-    switch (R0) {
-        case 2: return launch_bp2_r0<2>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
-        case 4: return launch_bp2_r0<4>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
-        case 5: return launch_bp2_r0<5>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
-        case 8: return launch_bp2_r0<8>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
-        case 10: return launch_bp2_r0<10>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
-        case 16: return launch_bp2_r0<16>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
-        case 20: return launch_bp2_r0<20>(nwg_fwd, nwg_inv, st, pm, pitch, T, n_atoms, D, tw, spec, out, ld, pf);
-    }
-    return hipErrorInvalidValue;
-}
-
+// R0 = 1 lag sums: the 1024 summed bins -> lag sums by the cosine sum (T <= 512 lags)
 hipError_t launch_wfft_finish(int R0, const double* partial, int n_parts, const cd* tw, int T,
                               double* spec, double* lagsum, hipStream_t st) {
     const int L2 = 2 * R0 * 512;

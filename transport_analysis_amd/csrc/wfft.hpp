@@ -1,25 +1,31 @@
-// wfft.hpp — power-spectrum accumulation over column pairs, pair-major slabs (gfx950).
+// wfft.hpp — per-wave FFT kernels on pair-major slabs (gfx950): power spectra of column pairs
+// (forward kernel) and the lag values of a power spectrum (inverse kernel).
 //
 // Replaces the per-atom tidynamics.acf loop of VelocityAutocorr._conclude_fft
-// (/root/reference/transport_analysis/velocityautocorr.py:208-215) on the timeseries path.
+// (/root/reference/transport_analysis/velocityautocorr.py:208-215): both the mean over atoms
+// (results.timeseries) and the per-atom array (results.vacf_by_particle).
 //
 // Input layout ("pair-major", produced by ta_stage_commit / ta_relayout_dev): column pair p
 // (columns 2p, 2p+1 of the (n_atoms*dim) columns) is one contiguous array of `pitch` rows of
-// 16 bytes, row t = (x[t], y[t]) = the complex sample z[t] = x[t] + i y[t].  A workgroup reads
-// a pair as 1 KiB-per-wave coalesced loads, every byte exactly once from HBM (the second pass
-// re-reads it while it is still in the XCD's L2).
+// 16 bytes, row t = (x[t], y[t]) = the complex sample z[t] = x[t] + i y[t].  A wave reads 1 KiB
+// of consecutive rows per load instruction; rows past n_frames read as zero through the buffer
+// descriptor's bounds check, which IS the zero padding.
 //
-// Transform.  The 2M-point transform of the zero-padded series (M = R0 * 512 >= n_frames) is
-// split into pass A (even bins, FFT_M(z)) and pass B (odd bins, FFT_M(z W_2M^t)); each pass is
-//   S1  one radix-R0 butterfly per thread (thread u: rows u + 512 j), output q scaled by
-//       W_2M^{u (2q + B)} and written to LDS as sub-series q (512 values, 8 KiB);
+// Transform.  The series is padded to L = 2 R M points, M = R0 * 512 the on-chip length
+// (R0 in {2, 4, 5, 8, 10, 16, 20}) and R the outer radix (1 up to 10240 frames, then 2, 4, 8, 16).
+// Bin k = 2R s + c of the L-point transform is output s of an M-point transform ("pass" c < 2R):
+//     Z[2R s + c] = FFT_M(u_c)[s],   u_c[t] = W_L^{c t} sum_{jo < R} z[t + M jo] W_2R^{c jo},  t < M
+// (R = 1: pass A = even bins of the zero-padded series, pass B = odd bins).  A pass is
+//   S1  one radix-R0 butterfly per thread (thread u: rows u + 512 j of u_c, formed while the
+//       rows are read), output q scaled by W_L^{u (2R q + c)} and written to LDS as sub-series q
+//       (512 values, 8 KiB);
 //   S2  512-point transforms of the R0 sub-series, ONE WAVE each, radix 8 x 8 x 8 with the data
 //       of a lane in registers and two exchanges through the sub-series' own 8 KiB of LDS: no
 //       workgroup barrier inside S2, so the waves of a SIMD drift apart and the LDS stores of
 //       one hide under the arithmetic of the other; the last radix-8 stage adds |.|^2 into the
-//       wave's register accumulators (bin k = 2 (q + R0 s) + B, s = a + 8 b + 64 c).
-// Sub-transform i = B*R0 + q belongs to wave i % 8, so with R0 = 20 every wave owns exactly
-// five (pass, q) slots and 40 accumulators per lane.
+//       wave's register accumulators (bin s = q + R0 (a + 8 b + 64 cc) of the pass).
+// A workgroup runs ONE pass; the 2R workgroups of a "tuple" (same XCD) walk the same units.
+// n_frames <= 512 has its own wave-independent kernels (end of this file).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -81,34 +87,29 @@ struct Dft<20> {
     }
 };
 
-// Twiddle table of plan R0 (host side; shared by the library and tools/wfft):
-//   [0, 2M)                      W_2M^n = exp(-i pi n / M)
-//   [2M, 2M + 896)               wave-local stage twiddles [14][64]: rows 0..6 W_512^{lane (r+1)},
-//                                rows 7..13 W_64^{(lane & 7) (r-6)}
-//   [2M + 896, 4M + 896)         first-stage output twiddles [B][q][u] = W_2M^{u (2q + B)}
-inline size_t wf_table_elems(int R0) { return 4 * (size_t)R0 * 512 + 14 * 64; }
-inline void wf_fill_table(int R0, cd* a) {
-    const long M = (long)R0 * 512;
+// Twiddle table of plan (R0, R) (host side; shared by the library and tools/wfft), L = 2 R M:
+//   [0, L)            W_L^n = exp(-2 pi i n / L)
+//   [L, L + 896)      wave-local stage twiddles [14][64]: rows 0..6 W_512^{lane (r+1)},
+//                     rows 7..13 W_64^{(lane & 7) (r-6)}
+inline size_t wf_table_elems(int R0, int R) { return 2 * (size_t)R * R0 * 512 + 14 * 64; }
+inline void wf_fill_table(int R0, int R, cd* a) {
+    const long L = 2L * R * R0 * 512;
     const long double pi = 3.141592653589793238462643383279502884L;
-    for (long n = 0; n < 2 * M; ++n) {
+    for (long n = 0; n < L; ++n) {
         if (n == 0) a[n] = cd{1.0, 0.0};
-        else if (n == M) a[n] = cd{-1.0, 0.0};
-        else if (2 * n == M) a[n] = cd{0.0, -1.0};
-        else if (2 * n == 3 * M) a[n] = cd{0.0, 1.0};
+        else if (2 * n == L) a[n] = cd{-1.0, 0.0};
+        else if (4 * n == L) a[n] = cd{0.0, -1.0};
+        else if (4 * n == 3 * L) a[n] = cd{0.0, 1.0};
         else {
-            const long double h = pi * (long double)n / (long double)M;
+            const long double h = 2.0L * pi * (long double)n / (long double)L;
             a[n] = cd{(double)cosl(h), (double)-sinl(h)};
         }
     }
     for (int r = 1; r < 8; ++r)
         for (int l = 0; l < 64; ++l) {
-            a[2 * M + (r - 1) * 64 + l] = a[2 * R0 * l * r];
-            a[2 * M + (6 + r) * 64 + l] = a[16 * R0 * (l & 7) * r];
+            a[L + (r - 1) * 64 + l] = a[(L / 512) * l * r];       // W_512^{l r}
+            a[L + (6 + r) * 64 + l] = a[(L / 64) * (l & 7) * r];  // W_64^{(l & 7) r}
         }
-    for (int B = 0; B < 2; ++B)
-        for (long q = 0; q < R0; ++q)
-            for (long u = 0; u < 512; ++u)
-                a[2 * M + 896 + (B * R0 + q) * 512 + u] = a[(u * (2 * q + B)) % (2 * M)];
 }
 
 template <int R0_>
@@ -118,26 +119,8 @@ struct WPlan {
     static constexpr int NT = 512;          // threads: one first-stage butterfly each
     static constexpr int NW = NT / 64;
     static constexpr int M = R0 * N1;
-    static constexpr int NS = (2 * R0 + NW - 1) / NW;  // (pass, q) slots per wave
+    static constexpr int NS1 = (R0 + NW - 1) / NW;  // sub-series per wave: q = wave + 8 s
     static constexpr size_t kLds = (size_t)M * sizeof(cd);
-    // slots a pass can touch (over all waves): i = wave + NW*s in [B R0, (B+1) R0)
-    static constexpr int slot_lo(int B) { return B * R0 < NW ? 0 : (B * R0 - (NW - 1) + NW - 1) / NW; }
-    static constexpr int slot_hi(int B) { return ((B + 1) * R0 - 1) / NW; }
-    // waves that own no sub-series in the pass's conditional slot (a contiguous range)
-    static constexpr int idle_first(int B) {
-        for (int w = 0; w < NW; ++w)
-            if (!wave_has(B, w, slot_lo(B)) || !wave_has(B, w, slot_hi(B))) return w;
-        return 0;
-    }
-    static constexpr int idle_waves(int B) {
-        int n = 0;
-        for (int w = 0; w < NW; ++w)
-            if (!wave_has(B, w, slot_lo(B)) || !wave_has(B, w, slot_hi(B))) ++n;
-        return n == NW ? 0 : n;
-    }
-    static constexpr bool wave_has(int B, int w, int s) { return w + NW * s >= B * R0 && w + NW * s < (B + 1) * R0; }
-    // slot s belongs to pass B for every wave
-    static constexpr bool slot_always(int B, int s) { return NW * s >= B * R0 && NW - 1 + NW * s < (B + 1) * R0; }
 };
 
 __device__ __forceinline__ cd wf_load(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uni_off) {
@@ -274,214 +257,27 @@ __device__ __forceinline__ void wf_sub512_x3(cd* __restrict__ reg0, cd* __restri
 // it: a first-stage butterfly's 80 data registers, the 80 accumulator registers and the 56
 // twiddle registers do not fit 256 together.
 // what the library instantiates (measured per build on the GPU: tools/wfft/wfft_test)
-#ifndef WF_TOUCH_DEFAULT
-#define WF_TOUCH_DEFAULT false
-#endif
-#ifndef WF_PRE
-#define WF_PRE 0  // first-stage butterfly before the barrier that frees the LDS (measured: 3-7 % slower)
-#endif
-#ifndef WF_SI
-#define WF_SI 1   // first-stage stores interleaved with the output twiddles
-#endif
-#ifndef WF_INTER_DEFAULT
-#define WF_INTER_DEFAULT false
-#endif
-template <class P, bool STAMP = false, bool TOUCH = WF_TOUCH_DEFAULT, bool INTER = WF_INTER_DEFAULT>
-__global__ void __launch_bounds__(P::NT)
-    k_wfft_accum(const double* __restrict__ pm, long pitch, int T, long n_pairs,
-                 const cd* __restrict__ tw2, double* __restrict__ accg,
-                 unsigned long long* __restrict__ stamps = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cd* lds = reinterpret_cast<cd*>(smem_raw);
-    constexpr int R0 = P::R0, N1 = P::N1, NS = P::NS, NW = P::NW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    double acc[NS][8];
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[s][c] = 0.0;
-
-    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
-    if constexpr (STAMP) st_prev = __builtin_amdgcn_s_memtime();
-#define WF_STAMP(i)                                                   \
-    if constexpr (STAMP) {                                            \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        st_acc[i] += now_ - st_prev;                                  \
-        st_prev = now_;                                               \
-    }
-
-    auto rsrc_of = [&](long p) {
-        // a pair past the end gets an empty buffer: its loads return zeros and are never used
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + (p < n_pairs ? p : 0) * pitch * 2), 0,
-                                                 p < n_pairs ? T * 16 : 0, 0x00020000);
-    };
-    // x: the rows of a first-stage butterfly; g = W_2M^{2u}, g2 = g^2, h = W_2M^{u}: seeds of
-    // its output twiddles (per-thread constants, re-loaded with the rows rather than held
-    // across S2, where the registers are short)
-    // (table reads as buffer loads: lane offset in one VGPR, row offset in an SGPR: no per-load
-    // address registers for the compiler to hoist out of the loop and spill)
-    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<cd*>(tw2), 0, (2 * P::M + 14 * 64) * 16, 0x00020000);
-    cd x[R0], g, g2, h;
-    auto issue_loads = [&](__amdgpu_buffer_rsrc_t rs) {
-#pragma unroll
-        for (int j = 0; j < R0; ++j) x[j] = wf_load(rs, (unsigned)tid * 16u, (unsigned)(N1 * j) * 16u);
-        g = wf_load(twr, (unsigned)tid * 32u, 0u);
-        g2 = wf_load(twr, (unsigned)tid * 64u, 0u);
-        h = wf_load(twr, (unsigned)tid * 16u, 0u);
-    };
-    issue_loads(rsrc_of(blockIdx.x));
-
-    for (long p = blockIdx.x; p < n_pairs; p += gridDim.x) {
-        auto one_pass = [&](auto BB) {
-            constexpr int B = decltype(BB)::value;
-            // ---- S1: radix-R0 butterfly u = tid over rows u + 512 j (loaded one pass ahead)
-            if constexpr (B == 1) {
-                // pass B twist, lane-uniform part: W_{2 R0}^j = tw2[j * 512]
-#pragma unroll
-                for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
-            }
-            Dft<R0>::run(x);
-            // Everything above touches registers only, so it may run BEFORE the barrier that
-            // ends the previous pass's S2 (WF_PRE): a wave that owns one sub-series fewer in
-            // that pass does its butterfly while the others finish theirs.
-            WF_STAMP(2 * B)
-#if WF_PRE
-            __syncthreads();  // every wave has read the previous pass's sub-series: LDS is free
-#endif
-            {
-                // output twiddles W_2M^{u(2q+B)} = h^B g^q: two chains (even / odd q) by g^2;
-                // WF_SI: each output is stored as soon as it is scaled
-                const cd gg = g, gg2 = g2, hh = h;
-                cd te = B ? hh : cd{1.0, 0.0};
-                cd to = B ? cmul(hh, gg) : gg;
-                if constexpr (B == 1) x[0] = cmul(x[0], te);
-                if (WF_SI) lds[tid] = x[0];
-                if constexpr (R0 > 1) {
-                    x[1] = cmul(x[1], to);
-                    if (WF_SI) lds[N1 + tid] = x[1];
-                }
-#pragma unroll
-                for (int q = 2; q < R0; ++q) {
-                    if (q & 1) {
-                        to = cmul(to, gg2);
-                        x[q] = cmul(x[q], to);
-                    } else {
-                        te = cmul(te, gg2);
-                        x[q] = cmul(x[q], te);
-                    }
-                    if (WF_SI) lds[q * N1 + tid] = x[q];
-                }
-                if (!WF_SI) {
-#pragma unroll
-                    for (int q = 0; q < R0; ++q) lds[q * N1 + tid] = x[q];
-                }
-            }
-            // this wave's stage twiddles for S2 (dead during S1); the scheduling barriers keep
-            // the loads from being hoisted over the code before them (which would make their
-            // destination registers live there)
-            __builtin_amdgcn_sched_barrier(0);
-            cd twa[7], twb[7];
-#pragma unroll
-            for (int a = 0; a < 7; ++a) {
-                twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + a * 64) * 16u);
-                twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + (7 + a) * 64) * 16u);
-            }
-            __syncthreads();  // the sub-series are complete
-            // ---- S2: this wave's sub-series of the pass
-            static_for_range<P::slot_lo(B), P::slot_hi(B) + 1>([&](auto ss) {
-                constexpr int s = decltype(ss)::value;
-                constexpr int lo_s = P::slot_lo(B);
-                // slots that every wave owns in this pass are taken two at a time
-                constexpr int first_all = P::slot_always(B, lo_s) ? lo_s : lo_s + 1;
-                constexpr bool in_pair_run = P::slot_always(B, s) && s >= first_all;
-                constexpr int k = s - first_all;  // position inside the run of always-slots
-                constexpr bool pair_head = INTER && in_pair_run && k % 2 == 0 && s + 1 <= P::slot_hi(B) && P::slot_always(B, s + 1);
-                constexpr bool pair_tail = INTER && in_pair_run && k % 2 == 1 && P::slot_always(B, s - 1);
-                const int i = wave + NW * s;
-                if constexpr (pair_head) {
-                    wf_sub512_x2(lds + (i - B * R0) * N1, lds + (i + NW - B * R0) * N1, lane, twa, twb, acc[s],
-                                 acc[s + 1]);
-                } else if constexpr (!pair_tail) {
-                    if (P::slot_always(B, s) || (i >= B * R0 && i < (B + 1) * R0))
-                        wf_sub512(lds + (i - B * R0) * N1, lane, twa, twb, acc[s]);
-                }
-            });
-            // rows of the next pass: the same pair again (pass B), or the next pair
-            __builtin_amdgcn_sched_barrier(0);
-            const __amdgpu_buffer_rsrc_t nrs = rsrc_of(B == 0 ? p : p + gridDim.x);
-            if constexpr (B == 1 && TOUCH && P::idle_waves(B) > 0) {
-                // The waves that own one sub-series fewer in this pass are done early: they
-                // pull the next pair's lines into L2 (one dword per 128-byte line), so that the
-                // row loads issued below by the late waves do not wait for HBM.
-                constexpr int NI = P::idle_waves(B), KT = (P::M * 16 / 128 + NI * 64 - 1) / (NI * 64);
-                const int rank = wave - P::idle_first(B);
-                if (rank >= 0 && rank < NI) {
-                    unsigned t[KT];
-#pragma unroll
-                    for (int k = 0; k < KT; ++k)
-                        t[k] = __builtin_amdgcn_raw_buffer_load_b32(nrs, (unsigned)(rank * 64 + lane) * 128u,
-                                                                    (unsigned)(k * NI * 64) * 128u, 0);
-                    issue_loads(nrs);
-#pragma unroll
-                    for (int k = 0; k < KT; ++k) asm volatile("" ::"v"(t[k]));
-                } else {
-                    issue_loads(nrs);
-                }
-            } else {
-                issue_loads(nrs);
-            }
-            WF_STAMP(2 * B + 1)
-#if !WF_PRE
-            __syncthreads();
-#endif
-        };
-        one_pass(std::integral_constant<int, 0>{});
-        one_pass(std::integral_constant<int, 1>{});
-    }
-    // accumulators -> natural bin order
-    double* out = accg + (long)blockIdx.x * 2 * P::M;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int i = wave + NW * s;
-        if (i < 2 * R0) {
-            const int B = i / R0, q = i - B * R0;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int sb = (lane >> 3) + 8 * (lane & 7) + 64 * c;
-                out[2 * (q + R0 * sb) + B] = acc[s][c];
-            }
-        }
-    }
-    if constexpr (STAMP) {
-        if (lane == 0 && (wave == 0 || wave == 4))
-            for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + (wave / 4) * 4 + i] = st_acc[i];
-    }
-#undef WF_STAMP
-}
-
-
 // ================================================================================================
-// Pass-split variant: a workgroup does ONE pass (A: even bins, B: odd bins) of every pair of its
-// couple; blocks b and b + 8 (same XCD under round-robin placement, speed only) form a couple
-// and walk the same pair list at the same pace, so the second reader of a pair finds it in the
-// XCD's L2 and every input byte leaves HBM once.  (k_wfft_accum reads a pair twice from one
-// compute unit, half a pair-period apart: with 32 compute units x 160 KiB in flight per 4 MiB
-// L2 the second read mostly misses -- measured 1.8x the algorithmic bytes at the L2's fabric
-// side.)  Half the accumulators per thread (one pass: 24 per lane instead of 40 at R0 = 20),
-// which is what lets the first-stage rows, the RESIDENT stage twiddles and two or three
-// sub-series in flight fit 256 registers without spilling.
+// Forward kernel: |transform|^2 of column units, accumulated per pass in registers.
 //
-// grid: a multiple of 16 blocks; block b: pass B = (b >> 3) & 1, couple c = (b & 7) + 8 (b >> 4).
-// Lag-sum mode (BYP = false): units are the n_units column pairs of the slab; accg:
-//   [n_couples][2M] natural bin order, the A block writes the even bins of its couple's row, the
-//   B block the odd ones.
-// By-particle forward mode (BYP = true): units are the atoms' column units (wf_unit_of); a couple
-//   takes whole atoms (pairs of adjacent atoms when the number of columns per atom is odd), and
-//   after an atom's last unit the pass's accumulators -- the atom's power spectrum in this
-//   pass -- go to accg as [atom][pass][q][c][lane] (the order k_wbp_inverse reads them back in)
-//   and start again from zero.
+// grid: a multiple of 16 R blocks, all resident.  Block b: XCD x = b & 7 (round-robin placement,
+// speed only), i = b >> 3, pass c = i mod 2R, tuple (b & 7) + 8 (i / 2R).  The 2R blocks of a tuple
+// sit on one XCD and walk the same units at the same pace, so the later readers of a row find it
+// in that XCD's L2 and every input byte leaves HBM once.  (Both passes in one workgroup would
+// read a pair twice half a pair-period apart: with 32 compute units x 160 KiB in flight per
+// 4 MiB L2 the second read mostly misses -- measured 1.8x the algorithmic bytes.)  One pass per
+// workgroup also halves the accumulators per thread (24 per lane at R0 = 20), which is what lets
+// the next unit's rows, the RESIDENT stage twiddles and two or three sub-series in flight fit
+// 256 registers without spilling.
+//
+// Lag-sum mode (BYP = false): units are the n_units column pairs of the slab, tuple t takes pairs
+//   t, t + n_tuples, ...; at the end the pass's accumulators go to accg[t][c][q][cc][lane]
+//   (a row of L doubles per tuple, summed over tuples afterwards).
+// By-particle mode (BYP = true): units are the atoms' column units (wf_unit_of); a tuple takes
+//   whole atoms (pairs of adjacent atoms when the number of columns per atom is odd), and after
+//   an atom's last unit the pass's accumulators -- the atom's power spectrum in this pass -- go
+//   to accg[atom][c][q][cc][lane] and start again from zero.
+// Either way a spectrum is L doubles in the order k_winverse reads them back in.
 __device__ __forceinline__ void wf_unit_of(long atom, int k, int D, long* pair, int* kind) {
     // kind 2 = both columns of the pair (complex series), 0 / 1 = only that half (real series)
     const long c0 = atom * D;
@@ -498,21 +294,26 @@ __device__ __forceinline__ void wf_unit_of(long atom, int k, int D, long* pair, 
 
 typedef unsigned int wf_u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned int))));
 
-template <class P, bool STAMP = false, bool INTER = true, bool BYP = false>
+__device__ __forceinline__ cd wf_cfma(cd acc, cd a, cd b) {  // acc + a b
+    return {acc.x + (a.x * b.x - a.y * b.y), acc.y + (a.x * b.y + a.y * b.x)};
+}
+
+template <class P, bool BYP = false, bool LONG = false, bool STAMP = false>
 __global__ void __launch_bounds__(P::NT)
     k_wsplit_accum(const double* __restrict__ pm, long pitch, int T, long n_units,
-                   const cd* __restrict__ tw2, double* __restrict__ accg,
-                   unsigned long long* __restrict__ stamps = nullptr, int D = 0) {
+                   const cd* __restrict__ tw2, double* __restrict__ accg, int D, int R_arg,
+                   unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
-    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW;
-    constexpr int NS1 = (R0 + NW - 1) / NW;  // sub-series per wave: q = wave + 8 s
+    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW, NS1 = P::NS1, M = P::M;
+    const int R = LONG ? R_arg : 1, npass = 2 * R, L = npass * M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int passB = (blockIdx.x >> 3) & 1;
-    const long couple = (blockIdx.x & 7) + 8 * (blockIdx.x >> 4), n_couples = gridDim.x / 2;
+    const int bi = blockIdx.x >> 3;
+    const int pass = bi % npass;
+    const long tuple = (blockIdx.x & 7) + 8 * (bi / npass), n_tuples = gridDim.x / npass;
     const int upa = BYP ? (D == 3 ? 2 : 1) : 1;  // units per atom (by-particle mode)
     // with an odd number of columns per atom, atoms 2i and 2i + 1 share a column pair (the last
-    // column of one, the first of the other): a couple takes both, so the shared rows come from
+    // column of one, the first of the other): a tuple takes both, so the shared rows come from
     // the L2 the second time
     const int grp = BYP && (D & 1) ? 2 : 1;
 
@@ -529,11 +330,11 @@ __global__ void __launch_bounds__(P::NT)
         st_acc[i] += now_ - st_prev;                                  \
         st_prev = now_;                                               \
     }
-    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<cd*>(tw2), 0, (4 * P::M + 14 * 64) * 16, 0x00020000);
-    // the couple's units in order: lag-sum mode pairs couple + i n_couples; by-particle mode the
-    // units k < upa of atoms couple + a n_couples.  A unit past the end gets an empty buffer: its
-    // loads return zeros and are never used.
+    const __amdgpu_buffer_rsrc_t twr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<cd*>(tw2), 0, (L + 14 * 64) * 16, 0x00020000);
+    // the tuple's units in order: lag-sum mode pairs tuple + i n_tuples; by-particle mode the
+    // units k < upa of its atoms.  A unit past the end gets an empty buffer: its loads return
+    // zeros and are never used.
     auto unit_rsrc = [&](long item, int k, int* kind) {
         long pair = item;
         const bool live = item < n_units;
@@ -542,40 +343,69 @@ __global__ void __launch_bounds__(P::NT)
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + (live ? pair : 0) * pitch * 2), 0,
                                                  live ? T * 16 : 0, 0x00020000);
     };
+    // row u + 512 j + M jo of the unit (a single real column: that half of the row, imaginary part 0)
+    auto load_row = [&](__amdgpu_buffer_rsrc_t rs, int kd, unsigned row_off) {
+        if (!BYP || kd == 2) return wf_load(rs, (unsigned)tid * 16u, row_off * 16u);
+        return cd{__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                                 rs, (unsigned)tid * 16u + (unsigned)kd * 8u, row_off * 16u, 0)),
+                  0.0};
+    };
     cd x[R0];
     auto issue_loads = [&](__amdgpu_buffer_rsrc_t rs, int kd) {
         if (!BYP || kd == 2) {
 #pragma unroll
-            for (int j = 0; j < R0; ++j) x[j] = wf_load(rs, (unsigned)tid * 16u, (unsigned)(N1 * j) * 16u);
-        } else {  // a single real column: that half of every row, imaginary part zero
+            for (int j = 0; j < R0; ++j) x[j] = load_row(rs, 2, (unsigned)(N1 * j));
+        } else {
 #pragma unroll
-            for (int j = 0; j < R0; ++j)
-                x[j] = cd{__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                                         rs, (unsigned)tid * 16u + (unsigned)kd * 8u,
-                                                         (unsigned)(N1 * j) * 16u, 0)),
-                          0.0};
+            for (int j = 0; j < R0; ++j) x[j] = load_row(rs, kd, (unsigned)(N1 * j));
         }
     };
     int kind = 2, nkind = 2;
-    {
-        const __amdgpu_buffer_rsrc_t rs0 = unit_rsrc(couple * grp, 0, &kind);
-        issue_loads(rs0, kind);
-    }
+    __amdgpu_buffer_rsrc_t crs = unit_rsrc(tuple * grp, 0, &kind);
+    issue_loads(crs, kind);
     // the wave-local stage twiddles stay in registers for the whole launch (one pass's
     // accumulators leave room for them: 14 fewer loads per wave and unit)
     cd twa[7], twb[7];
 #pragma unroll
     for (int a = 0; a < 7; ++a) {
-        twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + a * 64) * 16u);
-        twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + (7 + a) * 64) * 16u);
+        twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + a * 64) * 16u);
+        twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + (7 + a) * 64) * 16u);
     }
     int k = 0;  // unit of the atom (by-particle mode)
-    for (long item = couple * grp; item < n_units;) {
-        // ---- S1: radix-R0 butterfly u = tid over rows u + 512 j (requested during the previous S2)
-        const cd g = wf_load(twr, (unsigned)tid * 32u, 0u), g2 = wf_load(twr, (unsigned)tid * 64u, 0u),
-                 h = wf_load(twr, (unsigned)tid * 16u, 0u);
+    for (long item = tuple * grp; item < n_units;) {
+        // ---- S1: radix-R0 butterfly u = tid over rows u + 512 j of u_c (jo = 0 requested during
+        // the previous S2); g = W_M^u, h = W_L^{c u}
+        const cd g = wf_load(twr, (unsigned)(tid * R) * 32u, 0u), g2 = wf_load(twr, (unsigned)(tid * R) * 64u, 0u),
+                 h = wf_load(twr, (unsigned)(tid * pass) * 16u, 0u);
 #if WF_ABL != 2
-        if (passB) {
+        if constexpr (LONG) {
+            // u_c[u + 512 j] = sum_jo z[u + 512 j + M jo] U(j, jo), U = W_L^{c (512 j + M jo)} lane-uniform,
+            // its index advanced by c 512 per j and c M per jo (mod L: one conditional subtraction)
+            const int sj = pass * N1, so = pass * M;
+            if (pass) {
+                int idx = 0;
+#pragma unroll
+                for (int j = 1; j < R0; ++j) {
+                    idx += sj;
+                    idx -= idx >= L ? L : 0;
+                    x[j] = cmul(x[j], tw_uniform(tw2, idx));
+                }
+            }
+            int base = 0;
+            for (int jo = 1; jo < R; ++jo) {
+                base += so;
+                base -= base >= L ? L : 0;
+                if (jo * M >= T) break;  // nothing but padding from here on
+                int idx = base;
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    const cd z = load_row(crs, kind, (unsigned)(N1 * j + M * jo));
+                    x[j] = wf_cfma(x[j], z, tw_uniform(tw2, idx));
+                    idx += sj;
+                    idx -= idx >= L ? L : 0;
+                }
+            }
+        } else if (pass) {
             // pass B twist, lane-uniform part: W_{2 R0}^j = tw2[j * 512]
 #pragma unroll
             for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
@@ -583,12 +413,12 @@ __global__ void __launch_bounds__(P::NT)
         Dft<R0>::run(x);
 #endif
         {
-            // output twiddles W_2M^{u(2q+B)} = h^B g^q: two chains (even / odd q) by g^2, each
+            // output twiddles W_L^{u (2R q + c)} = h g^q: two chains (even / odd q) by g^2, each
             // output stored as soon as it is scaled (the 20 stores of a wave take ~260 LDS-path
             // cycles: issued in one burst at the end they are fully exposed)
-            cd te = passB ? h : cd{1.0, 0.0};
-            cd to = passB ? cmul(h, g) : g;
-            if (passB) x[0] = cmul(x[0], te);
+            cd te = pass ? h : cd{1.0, 0.0};
+            cd to = pass ? cmul(h, g) : g;
+            if (pass) x[0] = cmul(x[0], te);
             lds[tid] = x[0];
             if constexpr (R0 > 1) {
                 x[1] = cmul(x[1], to);
@@ -614,14 +444,14 @@ __global__ void __launch_bounds__(P::NT)
         long nitem = item;
         if (last_of_item) {
             if (BYP && grp == 2 && (item & 1) == 0 && item + 1 < n_units) nitem = item + 1;
-            else nitem = (item & ~(long)(grp - 1)) + grp * n_couples;
+            else nitem = (item & ~(long)(grp - 1)) + grp * n_tuples;
         }
         const int nk = last_of_item ? 0 : k + 1;
         const __amdgpu_buffer_rsrc_t nrs = unit_rsrc(nitem, nk, &nkind);
 #if WF_ABL == 1
         if (T < 0)
 #endif
-        if constexpr (INTER && NS1 == 3 && NW * 2 + NW - 1 >= R0 && NW * 1 + NW - 1 < R0) {
+        if constexpr (NS1 == 3 && NW * 2 + NW - 1 >= R0 && NW * 1 + NW - 1 < R0) {
             // two full slots and a partial third: the waves that own three sub-series take them
             // three at a time, the others two at a time
             if (wave + 2 * NW < R0)
@@ -635,8 +465,8 @@ __global__ void __launch_bounds__(P::NT)
                 constexpr bool full = NW * s + NW - 1 < R0;             // every wave has this slot
                 constexpr bool nfull = NW * (s + 1) + NW - 1 < R0;      // ... and the next one
                 constexpr bool pfull = s > 0 && NW * (s - 1) + NW - 1 < R0;
-                constexpr bool head = INTER && full && nfull && (s % 2 == 0);
-                constexpr bool tail = INTER && full && pfull && (s % 2 == 1);
+                constexpr bool head = full && nfull && (s % 2 == 0);
+                constexpr bool tail = full && pfull && (s % 2 == 1);
                 const int q = wave + NW * s;
                 if constexpr (head) {
                     wf_sub512_x2(lds + q * N1, lds + (q + NW) * N1, lane, twa, twb, acc[s], acc[s + 1]);
@@ -645,46 +475,50 @@ __global__ void __launch_bounds__(P::NT)
                 }
             });
         }
-        if constexpr (BYP) {
-            if (last_of_item) {
-                // the atom's power spectrum in this pass: [atom][pass][q][c][lane], then from zero
-                const long atom = item;
-                const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
-                    accg + ((atom * 2 + passB) * R0) * (8 * 64), 0, R0 * 512 * 8, 0x00020000);
-                const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        auto store_acc = [&](long row) {  // accg[row][pass][q][cc][lane]
+            const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+                accg + (row * npass + pass) * (long)M, 0, M * 8, 0x00020000);
 #pragma unroll
-                for (int s = 0; s < NS1; ++s) {
-                    const int q = wv + NW * s;
-                    if (NW * s + NW - 1 < R0 || q < R0) {
+            for (int s = 0; s < NS1; ++s) {
+                const int q = wv + NW * s;
+                if (NW * s + NW - 1 < R0 || q < R0) {
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wf_u32x2, acc[s][c]), sr,
-                                                                  (unsigned)lane * 8u, (unsigned)((q * 8 + c) * 64) * 8u,
-                                                                  0);
-                            acc[s][c] = 0.0;
-                        }
+                    for (int c = 0; c < 8; ++c) {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wf_u32x2, acc[s][c]), sr,
+                                                              (unsigned)lane * 8u, (unsigned)((q * 8 + c) * 64) * 8u, 0);
+                        acc[s][c] = 0.0;
                     }
                 }
             }
+        };
+        if constexpr (BYP) {
+            if (last_of_item) store_acc(item);  // the atom's power spectrum in this pass, then from zero
+        } else {
+            if (nitem >= n_units) store_acc(tuple);
         }
         __builtin_amdgcn_sched_barrier(0);
 #if WF_ABL != 3
         issue_loads(nrs, nkind);
 #endif
-        kind = nkind, item = nitem, k = nk;
+        kind = nkind, item = nitem, k = nk, crs = nrs;
         WF_STAMP(1)
         __syncthreads();
     }
     if constexpr (!BYP) {
-        double* out = accg + couple * 2 * P::M;
+        // a tuple without units still owes its (zero) row of the partial spectra
+        if (tuple * grp >= n_units) {
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+                accg + (tuple * npass + pass) * (long)M, 0, M * 8, 0x00020000);
 #pragma unroll
-        for (int s = 0; s < NS1; ++s) {
-            const int q = wave + NW * s;
-            if (q < R0) {
+            for (int s = 0; s < NS1; ++s) {
+                const int q = wv + NW * s;
+                if (q < R0) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int sb = (lane >> 3) + 8 * (lane & 7) + 64 * c;
-                    out[2 * (q + R0 * sb) + passB] = acc[s][c];
+                    for (int c = 0; c < 8; ++c)
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wf_u32x2, 0.0), sr, (unsigned)lane * 8u,
+                                                              (unsigned)((q * 8 + c) * 64) * 8u, 0);
                 }
             }
         }
@@ -697,188 +531,26 @@ __global__ void __launch_bounds__(P::NT)
 }
 
 // ================================================================================================
-// M = 10240, two workgroups per compute unit ("half passes").
+// Inverse kernel: the lag values of power spectra (one per atom for results.vacf_by_particle,
+// velocityautocorr.py:145-147, 210-214; the spectrum summed over atoms for results.timeseries).
 //
-// k_wfft_accum holds a whole pass (160 KiB) in LDS, so a compute unit runs ONE workgroup whose
-// waves move through the phases together: the first stage (vector-arithmetic bound) and the
-// sub-series transforms (LDS bound) never overlap.  Here a workgroup is 256 threads with 80 KiB
-// of LDS and does ONE pass (A: even bins or B: odd bins, by block index) in two halves: half H
-// holds the ten sub-series q = H, H+2, ..., H+18 (the prime-factor 4 x 5 butterfly splits by
-// q mod 4 in {H, H+2} at no extra arithmetic: a DFT4 needs 4 of its 8 additions for two of
-// its outputs).  Two such workgroups share a compute unit and drift apart, so one's first
-// stage runs under the other's exchanges.  The price: a pair's rows are read four times (twice
-// per pass), three of them from L2; the A and B workgroups of a couple (blocks b and b + 8:
-// same XCD under round-robin placement) walk the same pair list at the same pace.
-template <int H>
-__device__ __forceinline__ void dft20_half(const cd (&x)[20], cd (&y)[10]) {
-    cd s0[5], s1[5];  // outputs k1 = H and H + 2 of the five DFT4 (over j1), indexed by j2
-#pragma unroll
-    for (int j2 = 0; j2 < 5; ++j2) {
-        const cd a0 = x[(4 * j2) % 20], a1 = x[(5 + 4 * j2) % 20], a2 = x[(10 + 4 * j2) % 20],
-                 a3 = x[(15 + 4 * j2) % 20];
-        if constexpr (H == 0) {
-            const cd t0 = a0 + a2, t2 = a1 + a3;
-            s0[j2] = t0 + t2;
-            s1[j2] = t0 - t2;
-        } else {
-            const cd t1 = a0 - a2, t3 = mul_mi(a1 - a3);
-            s0[j2] = t1 + t3;
-            s1[j2] = t1 - t3;
-        }
-    }
-    Dft<5>::run(s0);
-    Dft<5>::run(s1);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const int q = 2 * r + H;
-        y[r] = (q % 4 == H) ? s0[q % 5] : s1[q % 5];
-    }
-}
-
-struct WHalf {
-    static constexpr int R0 = 20, N1 = 512, NT = 256, NW = 4, M = R0 * N1, NSUB = 10, NS = 5;
-    static constexpr size_t kLds = (size_t)NSUB * N1 * sizeof(cd);
-    // sub-series i = 10 H + r of a pass belongs to wave i % 4, slot i / 4
-    static constexpr int slot_lo(int H) { return H * NSUB < NW ? 0 : (H * NSUB - (NW - 1) + NW - 1) / NW; }
-    static constexpr int slot_hi(int H) { return ((H + 1) * NSUB - 1) / NW; }
-};
-
-// grid: a multiple of 16 blocks; block b: pass B = (b >> 3) & 1, couple c = (b & 7) + 8 (b >> 4);
-// accg: [n_couples][2M], the A block writes the even bins of its couple's row, the B block the odd.
-template <bool STAMP = false>
-__global__ void __launch_bounds__(256, 2)
-    k_whalf_accum(const double* __restrict__ pm, long pitch, int T, long n_pairs,
-                  const cd* __restrict__ tw2, double* __restrict__ accg,
-                  unsigned long long* __restrict__ stamps = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cd* lds = reinterpret_cast<cd*>(smem_raw);
-    using P = WHalf;
-    constexpr int N1 = P::N1, NS = P::NS, NW = P::NW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int passB = (blockIdx.x >> 3) & 1;
-    const long couple = (blockIdx.x & 7) + 8 * (blockIdx.x >> 4), n_couples = gridDim.x / 2;
-
-    double acc[NS][8];
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[s][c] = 0.0;
-    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
-    if constexpr (STAMP) st_prev = __builtin_amdgcn_s_memtime();
-#define WF_STAMP(i)                                                   \
-    if constexpr (STAMP) {                                            \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        st_acc[i] += now_ - st_prev;                                  \
-        st_prev = now_;                                               \
-    }
-    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<cd*>(tw2), 0, (2 * P::M + 14 * 64) * 16, 0x00020000);
-    auto rsrc_of = [&](long p) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + (p < n_pairs ? p : 0) * pitch * 2), 0,
-                                                 p < n_pairs ? T * 16 : 0, 0x00020000);
-    };
-    // rows of butterfly u and the seeds of its output twiddles: g = W_2M^{2u}, g2 = g^2, h = W_2M^u
-    cd x[20], g, g2, h;
-    auto issue_loads = [&](__amdgpu_buffer_rsrc_t rs, int u) {
-#pragma unroll
-        for (int j = 0; j < 20; ++j) x[j] = wf_load(rs, (unsigned)u * 16u, (unsigned)(N1 * j) * 16u);
-        g = wf_load(twr, (unsigned)u * 32u, 0u);
-        g2 = wf_load(twr, (unsigned)u * 64u, 0u);
-        h = wf_load(twr, (unsigned)u * 16u, 0u);
-    };
-    issue_loads(rsrc_of(couple), tid);
-
-    for (long p = couple; p < n_pairs; p += n_couples) {
-        const __amdgpu_buffer_rsrc_t rs = rsrc_of(p);
-        auto one_half = [&](auto HH) {
-            constexpr int H = decltype(HH)::value;
-            // ---- S1: two butterflies per thread (u = tid, tid + 256), ten outputs each
-#pragma unroll
-            for (int rep = 0; rep < 2; ++rep) {
-                const int u = tid + 256 * rep;
-                if (rep == 1) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_loads(rs, u);
-                }
-                if (passB) {
-                    // pass B twist, lane-uniform part: W_40^j = tw2[j * 512]
-#pragma unroll
-                    for (int j = 1; j < 20; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
-                }
-                cd y[10];
-                dft20_half<H>(x, y);
-                // output twiddles W_2M^{u (2q + B)}, q = 2r + H: start h^B g^H, step g^2
-                cd w = passB ? h : cd{1.0, 0.0};
-                if constexpr (H == 1) w = passB ? cmul(w, g) : g;
-#pragma unroll
-                for (int r = 0; r < 10; ++r) {
-                    if (r > 0) w = cmul(w, g2);
-                    if (r > 0 || H == 1 || passB) y[r] = cmul(y[r], w);
-                    lds[r * N1 + u] = y[r];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            cd twa[7], twb[7];
-#pragma unroll
-            for (int a = 0; a < 7; ++a) {
-                twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + a * 64) * 16u);
-                twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * P::M + (7 + a) * 64) * 16u);
-            }
-            WF_STAMP(2 * H)
-            __syncthreads();
-            // ---- S2: this wave's sub-series of the half
-            static_for_range<P::slot_lo(H), P::slot_hi(H) + 1>([&](auto ss) {
-                constexpr int s = decltype(ss)::value;
-                const int i = wave + NW * s;
-                if (i >= H * P::NSUB && i < (H + 1) * P::NSUB)
-                    wf_sub512(lds + (i - H * P::NSUB) * N1, lane, twa, twb, acc[s]);
-            });
-            // first butterfly of the next half: the same pair again, or the next pair
-            __builtin_amdgcn_sched_barrier(0);
-            issue_loads(H == 0 ? rs : rsrc_of(p + n_couples), tid);
-            WF_STAMP(2 * H + 1)
-            __syncthreads();
-        };
-        one_half(std::integral_constant<int, 0>{});
-        one_half(std::integral_constant<int, 1>{});
-    }
-    // accumulators -> natural bin order: bin 2 (q + 20 sb) + B, q = 2r + H, i = 10 H + r
-    double* out = accg + couple * 2 * P::M;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int i = wave + NW * s;
-        const int H = i / P::NSUB, r = i - H * P::NSUB, q = 2 * r + H;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int sb = (lane >> 3) + 8 * (lane & 7) + 64 * c;
-            out[2 * (q + 20 * sb) + passB] = acc[s][c];
-        }
-    }
-    if constexpr (STAMP) {
-        if (lane == 0 && wave == 0)
-            for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + i] = st_acc[i];
-    }
-#undef WF_STAMP
-}
-
-
-// ================================================================================================
-// By-particle mode: results.vacf_by_particle (velocityautocorr.py:145-147, 210-214).
-//
-// A workgroup takes whole atoms.  An atom's columns are transformed as one or two UNITS (its
-// 16-byte aligned column pair as a complex series, a single column as a real one), both passes
-// each, and |.|^2 is accumulated in registers as in the lag-sum kernels -- sub-series q of BOTH
-// passes belongs to wave q % 8, so a lane holds P_A[j] and P_B[j] of the same bins j.  After the
-// atom's last unit those accumulators ARE its power spectrum; its lag values are one M-point
-// transform of P_A + i P_B, run by the TRANSPOSE of the forward algorithm (the DFT matrix is
-// symmetric): input in the accumulators' own bin order, output in natural order:
-//   sub-series q (registers c = 0..7 of lane 8a + b: bin a + 8b + 64c)
-//     -> DFT8 over c, x W_64^{b n0} -> exchange -> DFT8 over b -> exchange, x W_512^{l a}
+// A workgroup takes whole spectra (grid-stride).  With P real,
+//     lag[n] = (1 / (L (T - n))) Re sum_k P[k] W_L^{k n},   k = 2R s + c:
+//     lag[n] = (1 / (L (T - n))) Re sum_{c < 2R} W_L^{c n} Q_c[n mod M],   Q_c = FFT_M(P_c).
+// Two passes share one complex M-point transform, Q = FFT_M(P_c + i P_c'), run by the TRANSPOSE
+// of the forward algorithm (the DFT matrix is symmetric) -- input in the accumulators' own bin
+// order, output in natural order:
+//   sub-series q (registers cc = 0..7 of lane 8a + b: bin a + 8b + 64cc)
+//     -> DFT8 over cc, x W_64^{b n0} -> exchange -> DFT8 over b -> exchange, x W_512^{l a}
 //     -> DFT8 over a -> G_q[64 n2 + l] to LDS           (same exchange layouts as forward)
 //   thread u: Q[u + 512 j'] = DFT_R0 over q of G_q[u] W_M^{uq}
-// and with Qm[n] = Q[M - n] (one more trip through LDS, natural order):
-//   lag[n] = ( Re(Q+Qm)/2 + cos(pi n/M) Im(Q+Qm)/2 - sin(pi n/M) Re(Q-Qm)/2 ) / (2M (T - n)).
-// Output: atom-major scratch out[atom * ld + n] (512-byte stores), transposed afterwards.
+// and with Qm[n] = Q[M - n] (one more trip through LDS, natural order) the two are separated:
+//     Q_c = (Q + conj Qm) / 2,   Q_c' = (Q - conj Qm) / (2i).
+// R = 1: lag[n] = ( Re(Q+Qm)/2 + cos(pi n/M) Im(Q+Qm)/2 - sin(pi n/M) Re(Q-Qm)/2 ) / (2M (T - n)).
+// R > 1: the R transforms of a spectrum run one after the other, each adding its two passes'
+// terms to the spectrum's output row (read-modify-write by the thread that owns the lag).
+// Output: out[item * ld + n], atom-major (512-byte stores), transposed afterwards for the
+// by-particle array.
 struct WfSubT {
     int lane, hi, lo;
     __device__ __forceinline__ explicit WfSubT(int lane_) : lane(lane_) {
@@ -919,312 +591,139 @@ struct WfSubT {
     }
 };
 
-// pm: pair-major slab of the shard (n_atoms * D columns); out: [n_atoms][ld] atom-major lags.
-template <class P, bool STAMP = false>
+
+template <class P, bool LONG = false, int PF = 0>
 __global__ void __launch_bounds__(P::NT)
-    k_wbp(const double* __restrict__ pm, long pitch, int T, long n_atoms, int D,
-          const cd* __restrict__ tw2, double* __restrict__ out, long ld,
-          unsigned long long* __restrict__ stamps = nullptr) {
+    k_winverse(const double* __restrict__ spec, int T, long n_items, const cd* __restrict__ tw2,
+               double* __restrict__ out, long ld, int R_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
-    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW, M = P::M;
-    constexpr int NSA = (R0 + NW - 1) / NW;  // sub-series per wave and pass: q = wave + 8 s
+    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW, M = P::M, NSA = P::NS1;
+    static_assert(!LONG || PF == 0, "the spectrum prefetch is for the single-transform case");
+    const int R = LONG ? R_arg : 1, L = 2 * R * M;
     int tid = threadIdx.x, lane = tid & 63;
     const int wave = tid >> 6;
-    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<cd*>(tw2), 0, (4 * M + 14 * 64) * 16, 0x00020000);
-    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
-    if constexpr (STAMP) st_prev = __builtin_amdgcn_s_memtime();
-#define WF_STAMP(i)                                                   \
-    if constexpr (STAMP) {                                            \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        st_acc[i] += now_ - st_prev;                                  \
-        st_prev = now_;                                               \
-    }
-    // units of an atom: (pair index, kind) with kind 2 = both columns of the pair (complex
-    // series), 0 / 1 = only that half (real series)
-    const int n_units = D == 3 ? 2 : 1;
-    auto unit_of = [&](long atom, int k, long* pair, int* kind) {
-        const long c0 = atom * D;
-        if (D == 2) {
-            *pair = atom, *kind = 2;
-        } else if (D == 1) {
-            *pair = c0 >> 1, *kind = (int)(c0 & 1);
-        } else if ((c0 & 1) == 0) {  // even first column: (x, y) aligned, z alone
-            if (k == 0) *pair = c0 >> 1, *kind = 2;
-            else *pair = (c0 >> 1) + 1, *kind = 0;
-        } else {                     // x alone (second half of a pair), (y, z) aligned
-            if (k == 0) *pair = c0 >> 1, *kind = 1;
-            else *pair = (c0 >> 1) + 1, *kind = 2;
-        }
-    };
-    cd x[R0], g, g2, h;
-    auto issue_loads = [&](long pair) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<double*>(pm + pair * pitch * 2), 0, T * 16, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < R0; ++j) x[j] = wf_load(rs, (unsigned)tid * 16u, (unsigned)(N1 * j) * 16u);
-    };
-    auto load_seeds = [&]() {  // after the butterfly: its temporaries are dead by then
-        g = wf_load(twr, (unsigned)tid * 32u, 0u);
-        g2 = wf_load(twr, (unsigned)tid * 64u, 0u);
-        h = wf_load(twr, (unsigned)tid * 16u, 0u);
-    };
-    auto load_stage_tw = [&](cd (&twa)[7], cd (&twb)[7]) {
-#pragma unroll
-        for (int a = 0; a < 7; ++a) {
-            twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * M + a * 64) * 16u);
-            twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * M + (7 + a) * 64) * 16u);
-        }
-    };
-
-    for (long atom = blockIdx.x; atom < n_atoms; atom += gridDim.x) {
-        double accA[NSA][8], accB[NSA][8];
-#pragma unroll
-        for (int s = 0; s < NSA; ++s)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) accA[s][c] = accB[s][c] = 0.0;
-        for (int k = 0; k < n_units; ++k) {
-            long pair;
-            int kind;
-            unit_of(atom, k, &pair, &kind);
-            auto one_pass = [&](auto BB, double (&acc)[NSA][8]) {
-                constexpr int B = decltype(BB)::value;
-                // per-thread offsets and LDS addresses are re-formed per pass: hoisted out of the
-                // atom loop they would be spilled
-                asm volatile("" : "+v"(tid), "+v"(lane));
-                // (requesting the rows a pass ahead costs more in scratch traffic than the
-                // latency it hides here: measured 24.7 -> 31.2 ms at 10000 x 100000 x 3)
-                issue_loads(pair);
-                if (kind != 2) {  // a single real column: the other half of the rows is not ours
-#pragma unroll
-                    for (int j = 0; j < R0; ++j) x[j] = cd{kind ? x[j].y : x[j].x, 0.0};
-                }
-                if constexpr (B == 1) {
-#pragma unroll
-                    for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], tw_uniform(tw2, j * N1));
-                }
-                Dft<R0>::run(x);
-                __builtin_amdgcn_sched_barrier(0);
-                load_seeds();
-                {
-                    cd te = B ? h : cd{1.0, 0.0};
-                    cd to = B ? cmul(h, g) : g;
-                    if constexpr (B == 1) x[0] = cmul(x[0], te);
-                    lds[tid] = x[0];
-                    if constexpr (R0 > 1) {
-                        x[1] = cmul(x[1], to);
-                        lds[N1 + tid] = x[1];
-                    }
-#pragma unroll
-                    for (int q = 2; q < R0; ++q) {
-                        if (q & 1) {
-                            to = cmul(to, g2);
-                            x[q] = cmul(x[q], to);
-                        } else {
-                            te = cmul(te, g2);
-                            x[q] = cmul(x[q], te);
-                        }
-                        lds[q * N1 + tid] = x[q];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                cd twa[7], twb[7];
-                load_stage_tw(twa, twb);
-                WF_STAMP(0)
-                __syncthreads();
-#pragma unroll
-                for (int s = 0; s < NSA; ++s) {
-                    const int q = wave + NW * s;
-                    if (NW * s + NW - 1 < R0 || q < R0) wf_sub512(lds + q * N1, lane, twa, twb, acc[s]);
-                }
-                WF_STAMP(1)
-                __syncthreads();
-            };
-            one_pass(std::integral_constant<int, 0>{}, accA);
-            one_pass(std::integral_constant<int, 1>{}, accB);
-        }
-        // ---- the atom's lag values: transposed transform of P_A + i P_B
-        asm volatile("" : "+v"(tid), "+v"(lane));
-        {
-            cd twa[7], twb[7];
-            load_stage_tw(twa, twb);
-            const WfSubT wt(lane);
-#pragma unroll
-            for (int s = 0; s < NSA; ++s) {
-                const int q = wave + NW * s;
-                if (NW * s + NW - 1 < R0 || q < R0) {
-                    cd v[8];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) v[c] = cd{accA[s][c], accB[s][c]};
-                    wt.run(lds + q * N1, v, twa, twb);
-                }
-            }
-        }
-        __syncthreads();
-        {
-            load_seeds();  // g = W_M^u
-#pragma unroll
-            for (int q = 0; q < R0; ++q) x[q] = lds[q * N1 + tid];
-            cd te = cd{1.0, 0.0}, to = g;
-            if constexpr (R0 > 1) x[1] = cmul(x[1], to);
-#pragma unroll
-            for (int q = 2; q < R0; ++q) {
-                if (q & 1) {
-                    to = cmul(to, g2);
-                    x[q] = cmul(x[q], to);
-                } else {
-                    te = cmul(te, g2);
-                    x[q] = cmul(x[q], te);
-                }
-            }
-            Dft<R0>::run(x);  // x[j'] = Q[tid + 512 j']
-        }
-        __syncthreads();  // every thread has read its G values: LDS free for Q in natural order
-#pragma unroll
-        for (int j = 0; j < R0; ++j) lds[tid + N1 * j] = x[j];
-        __syncthreads();
-        {
-            double* o = out + atom * ld;
-            // Q[M - n] for n = u + 512 j: element (512 - u) + 512 (R0 - 1 - j), u > 0
-            const int mu = tid == 0 ? 0 : N1 - tid;
-#pragma unroll
-            for (int j = 0; j < R0; ++j) {
-                const int n = tid + N1 * j;
-                const int jm = tid == 0 ? (R0 - j) % R0 : R0 - 1 - j;
-                const cd qm = lds[mu + N1 * jm];
-                // W_2M^n = W_2M^u * W_{2 R0}^j = cos - i sin (the second factor lane-uniform)
-                const cd w = j == 0 ? h : cmul(h, tw_uniform(tw2, j * N1));
-                const double ar = 0.5 * (x[j].x + qm.x), br = 0.5 * (x[j].y + qm.y), bi = -0.5 * (x[j].x - qm.x);
-                const double L = ar + (w.x * br - w.y * bi);
-                if (n < T) o[n] = L / (2.0 * (double)M * (double)(T - n));  // 2M(T-n) < 2^53: exact product
-            }
-        }
-        __syncthreads();  // Q consumed before the next atom's first stage overwrites the LDS
-    }
-    if constexpr (STAMP) {
-        if (lane == 0 && wave == 0)
-            for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + i] = st_acc[i];
-    }
-#undef WF_STAMP
-}
-
-
-// By-particle inverse: a workgroup per atom (grid-stride).  spec: [atom][2][R0][8][64] from
-// k_wsplit_accum<BYP>; out[atom * ld + lag], atom-major.  The transposed transform of
-// P_A + i P_B as in k_wbp (which see), with registers to spare: two sub-series in flight.
-template <class P, int PF = 0, int ABL = 0>
-__global__ void __launch_bounds__(P::NT)
-    k_wbp_inverse(const double* __restrict__ spec, int T, long n_atoms, const cd* __restrict__ tw2,
-                  double* __restrict__ out, long ld) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cd* lds = reinterpret_cast<cd*>(smem_raw);
-    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW, M = P::M;
-    constexpr int NSA = (R0 + NW - 1) / NW;
-    int tid = threadIdx.x, lane = tid & 63;
-    const int wave = tid >> 6;
-    const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<cd*>(tw2), 0, (4 * M + 14 * 64) * 16, 0x00020000);
-    // the spectra of the first PF of this wave's sub-series are requested an atom ahead (during
-    // the previous atom's first stage and untangling); the rest when their turn comes
+    const __amdgpu_buffer_rsrc_t twr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<cd*>(tw2), 0, (L + 14 * 64) * 16, 0x00020000);
+    // the spectra of the first PF of this wave's sub-series are requested an item ahead (during
+    // the previous item's first stage and untangling); the rest when their turn comes
     cd v[NSA][8];
-    auto load_spec = [&](long atom, int s) {
+    auto load_spec = [&](long item, int cp, int s) {
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const int q = wv + NW * s;
-        const bool live = atom < n_atoms && q < R0 && ABL != 5;
+        const bool live = item < n_items && q < R0;
         const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<double*>(spec + ((live ? atom : 0) * 2 * R0) * (8 * 64)), 0, live ? 2 * R0 * 512 * 8 : 0,
+            const_cast<double*>(spec + (live ? item : 0) * (long)L + (long)(2 * cp) * M), 0, live ? 2 * M * 8 : 0,
             0x00020000);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             v[s][c].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
                                                        sr, (unsigned)lane * 8u, (unsigned)((q * 8 + c) * 64) * 8u, 0));
             v[s][c].y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                                       sr, (unsigned)lane * 8u,
-                                                       (unsigned)(((R0 + q) * 8 + c) * 64) * 8u, 0));
+                                                       sr, (unsigned)lane * 8u, (unsigned)(M + (q * 8 + c) * 64) * 8u, 0));
         }
     };
 #pragma unroll
-    for (int s = 0; s < PF; ++s) load_spec(blockIdx.x, s);
-    for (long atom = blockIdx.x; atom < n_atoms; atom += gridDim.x) {
-        // per-thread offsets and LDS addresses are re-formed per atom: hoisted out of the loop
-        // they would be spilled
-        asm volatile("" : "+v"(tid), "+v"(lane));
-        {
-            cd twa[7], twb[7];
+    for (int s = 0; s < PF; ++s) load_spec(blockIdx.x, 0, s);
+    for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        for (int cp = 0; cp < R; ++cp) {
+            // per-thread offsets and LDS addresses are re-formed per transform: hoisted out of the
+            // loops they would be spilled
+            asm volatile("" : "+v"(tid), "+v"(lane));
+            {
+                cd twa[7], twb[7];
 #pragma unroll
-            for (int a = 0; a < 7; ++a) {
-                twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * M + a * 64) * 16u);
-                twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(2 * M + (7 + a) * 64) * 16u);
+                for (int a = 0; a < 7; ++a) {
+                    twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + a * 64) * 16u);
+                    twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + (7 + a) * 64) * 16u);
+                }
+#pragma unroll
+                for (int s = PF; s < NSA; ++s) load_spec(item, cp, s);
+                const WfSubT wt(lane);
+#pragma unroll
+                for (int s = 0; s < NSA; ++s) {
+                    const int q = wave + NW * s;
+                    if (NW * s + NW - 1 < R0 || q < R0) wt.run(lds + q * N1, v[s], twa, twb);
+                }
             }
+            __syncthreads();
+            if constexpr (PF > 0) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = PF; s < NSA; ++s) load_spec(atom, s);
-            const WfSubT wt(lane);
+                for (int s = 0; s < PF; ++s) load_spec(item + gridDim.x, 0, s);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cd x[R0];
+            const cd g = wf_load(twr, (unsigned)(tid * R) * 32u, 0u), g2 = wf_load(twr, (unsigned)(tid * R) * 64u, 0u);
 #pragma unroll
-            for (int s = 0; s < NSA; ++s) {
-                const int q = wave + NW * s;
-                if (NW * s + NW - 1 < R0 || q < R0) {
-                    if constexpr (ABL == 1) {  // ablation: no sub-transforms
+            for (int q = 0; q < R0; ++q) x[q] = lds[q * N1 + tid];
+            {
+                cd te = cd{1.0, 0.0}, to = g;
+                if constexpr (R0 > 1) x[1] = cmul(x[1], to);
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) lds[q * N1 + 64 * c + lane] = v[s][c];
+                for (int q = 2; q < R0; ++q) {
+                    if (q & 1) {
+                        to = cmul(to, g2);
+                        x[q] = cmul(x[q], to);
                     } else {
-                        wt.run(lds + q * N1, v[s], twa, twb);
+                        te = cmul(te, g2);
+                        x[q] = cmul(x[q], te);
                     }
                 }
             }
-        }
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
+            Dft<R0>::run(x);  // x[j'] = Q[tid + 512 j']
+            __syncthreads();  // every thread has read its G values: LDS free for Q in natural order
 #pragma unroll
-        for (int s = 0; s < PF; ++s) load_spec(atom + gridDim.x, s);
-        __builtin_amdgcn_sched_barrier(0);
-        cd x[R0];
-        const cd g = wf_load(twr, (unsigned)tid * 32u, 0u), g2 = wf_load(twr, (unsigned)tid * 64u, 0u),
-                 h = wf_load(twr, (unsigned)tid * 16u, 0u);
-#pragma unroll
-        for (int q = 0; q < R0; ++q) x[q] = lds[q * N1 + tid];
-        if constexpr (ABL != 2) {
-            cd te = cd{1.0, 0.0}, to = g;
-            if constexpr (R0 > 1) x[1] = cmul(x[1], to);
-#pragma unroll
-            for (int q = 2; q < R0; ++q) {
-                if (q & 1) {
-                    to = cmul(to, g2);
-                    x[q] = cmul(x[q], to);
-                } else {
-                    te = cmul(te, g2);
-                    x[q] = cmul(x[q], te);
-                }
-            }
-        }
-        if constexpr (ABL != 2) Dft<R0>::run(x);  // x[j'] = Q[tid + 512 j']
-        __syncthreads();  // every thread has read its G values: LDS free for Q in natural order
-#pragma unroll
-        for (int j = 0; j < R0; ++j) lds[tid + N1 * j] = x[j];
-        __syncthreads();
-        {
-            double* o = out + atom * ld;
+            for (int j = 0; j < R0; ++j) lds[tid + N1 * j] = x[j];
+            __syncthreads();
+            double* o = out + item * ld;
+            // Q[M - n] for n = u + 512 j: element (512 - u) + 512 (R0 - 1 - j), u > 0
             const int mu = tid == 0 ? 0 : N1 - tid;
+            if constexpr (!LONG) {
+                const cd h = wf_load(twr, (unsigned)tid * 16u, 0u);
 #pragma unroll
-            for (int j = 0; j < R0; ++j) {
-                const int n = tid + N1 * j;
-                if constexpr (ABL == 3) {  // ablation: no untangling
-                    if (n < T) o[n] = x[j].x;
-                    continue;
+                for (int j = 0; j < R0; ++j) {
+                    const int n = tid + N1 * j;
+                    const int jm = tid == 0 ? (R0 - j) % R0 : R0 - 1 - j;
+                    const cd qm = lds[mu + N1 * jm];
+                    // W_2M^n = W_2M^u * W_{2 R0}^j = cos - i sin (the second factor lane-uniform)
+                    const cd w = j == 0 ? h : cmul(h, tw_uniform(tw2, j * N1));
+                    const double ar = 0.5 * (x[j].x + qm.x), br = 0.5 * (x[j].y + qm.y), bi = -0.5 * (x[j].x - qm.x);
+                    const double lagv = ar + (w.x * br - w.y * bi);
+                    if (n < T) o[n] = lagv / (2.0 * (double)M * (double)(T - n));  // 2M(T-n) < 2^53: exact product
                 }
-                const int jm = tid == 0 ? (R0 - j) % R0 : R0 - 1 - j;
-                const cd qm = lds[mu + N1 * jm];
-                const cd w = j == 0 ? h : cmul(h, tw_uniform(tw2, j * N1));  // W_2M^n = cos - i sin
-                const double ar = 0.5 * (x[j].x + qm.x), br = 0.5 * (x[j].y + qm.y), bi = -0.5 * (x[j].x - qm.x);
-                const double L = ar + (w.x * br - w.y * bi);
-                if constexpr (ABL == 4) {  // ablation: no division
-                    if (n < T) o[n] = L * (2.0 * (double)M * (double)(T - n));
-                    continue;
+            } else {
+                // passes c0 = 2 cp (real parts of the input) and c1 = c0 + 1 (imaginary parts):
+                // lag[n] += Re(W_L^{c0 n} Q_c0[n0]) + Re(W_L^{c1 n} Q_c1[n0]), n = n0 + M jo,
+                // W_L^{c n} = W_L^{c u} (per thread) x W_L^{c (512 j + M jo)} (lane-uniform, index mod L)
+                const int c0 = 2 * cp, c1 = c0 + 1;
+                const cd h0 = wf_load(twr, (unsigned)(tid * c0) * 16u, 0u), h1 = wf_load(twr, (unsigned)(tid * c1) * 16u, 0u);
+                const bool first = cp == 0, last = cp == R - 1;
+                int j0 = 0, j1 = 0;  // c (512 j) mod L
+#pragma unroll
+                for (int j = 0; j < R0; ++j) {
+                    const int jm = tid == 0 ? (R0 - j) % R0 : R0 - 1 - j;
+                    const cd qm = lds[mu + N1 * jm];
+                    const cd qa = cd{0.5 * (x[j].x + qm.x), 0.5 * (x[j].y - qm.y)};
+                    const cd qb = cd{0.5 * (x[j].y + qm.y), -0.5 * (x[j].x - qm.x)};
+                    int i0 = j0, i1 = j1;
+                    for (int jo = 0; jo < R; ++jo) {
+                        const int n = tid + N1 * j + M * jo;
+                        const cd w0 = cmul(h0, tw_uniform(tw2, i0)), w1 = cmul(h1, tw_uniform(tw2, i1));
+                        double a = (w0.x * qa.x - w0.y * qa.y) + (w1.x * qb.x - w1.y * qb.y);
+                        if (n < T) {
+                            if (!first) a += o[n];
+                            o[n] = last ? a / ((double)L * (double)(T - n)) : a;  // L (T-n) < 2^53: exact product
+                        }
+                        i0 += c0 * M, i0 -= i0 >= L ? L : 0;
+                        i1 += c1 * M, i1 -= i1 >= L ? L : 0;
+                    }
+                    j0 += c0 * N1, j0 -= j0 >= L ? L : 0;
+                    j1 += c1 * N1, j1 -= j1 >= L ? L : 0;
                 }
-                if (n < T) o[n] = L / (2.0 * (double)M * (double)(T - n));  // 2M(T-n) < 2^53: exact product
             }
+            __syncthreads();  // Q consumed before the next transform's sub-series overwrite the LDS
         }
-        __syncthreads();  // Q consumed before the next atom's sub-series overwrite the LDS
     }
 }
 
@@ -1267,7 +766,7 @@ __global__ void __launch_bounds__(W1::NT)
     cd* regA = lds + wave * 1024;
     cd* regB = regA + 512;
     const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<cd*>(tw2), 0, (4 * W1::M + 14 * 64) * 16, 0x00020000);
+        const_cast<cd*>(tw2), 0, (2 * W1::M + 14 * 64) * 16, 0x00020000);
     cd twa[7], twb[7], tB[8];
 #pragma unroll
     for (int a = 0; a < 7; ++a) {
@@ -1307,7 +806,7 @@ __global__ void __launch_bounds__(W1::NT)
     cd* regA = lds + wave * 1024;
     cd* regB = regA + 512;
     const __amdgpu_buffer_rsrc_t twr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<cd*>(tw2), 0, (4 * W1::M + 14 * 64) * 16, 0x00020000);
+        const_cast<cd*>(tw2), 0, (2 * W1::M + 14 * 64) * 16, 0x00020000);
     cd twa[7], twb[7], tB[8];
 #pragma unroll
     for (int a = 0; a < 7; ++a) {
@@ -1361,3 +860,4 @@ __global__ void __launch_bounds__(W1::NT)
 }
 
 }  // namespace ta
+
