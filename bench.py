@@ -136,11 +136,11 @@ class Case:
     def kernel_name(self):
         if self.mode != "fft" and not (self.mode == "helfand" and self.helfand_fft):
             return "k_direct"
-        if self.T > 10240:
-            return "k_direct" if self.bp is not None else "k_fft_accum_long"
-        if self.bp is not None:
-            return "k_wbp" if self.T > 512 else "k_w1_bp"
-        return "k_wsplit_accum" if self.T > 512 else "k_w1_accum"
+        if self.T > 163840:
+            return "k_direct"
+        if self.T <= 512:
+            return "k_w1_bp" if self.bp is not None else "k_w1_accum"
+        return "k_wsplit_accum+k_winverse" if self.bp is not None else "k_wsplit_accum"
 
 
 def timed(torch, dist, world, steps, warmup, fn):
@@ -392,28 +392,32 @@ def other_configs(torch, dist, _lib, ctx, dev):
     share of configs[4] (20000 frames x 25000 atoms, float32 path)."""
     res = []
     specs = [
-        ("configs[1]: FFT VACF timeseries 1000 x 10000 x 3", "fft", 1000, 10000, False, False, 10, 3),
-        ("configs[2] shape with vacf_by_particle: FFT VACF 10000 x 100000 x 3", "fft", 10000, 100000, True, False, 3, 1),
-        ("configs[3]: windowed (direct) VACF 5000 x 50000 x 3", "direct", 5000, 50000, False, False, 3, 1),
-        ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float32 path", "helfand", 20000, 25000, False, True, 2, 1),
+        ("configs[1]: FFT VACF timeseries 1000 x 10000 x 3", "fft", 1000, 10000, False, False, False, 10, 3),
+        ("configs[2] shape with vacf_by_particle: FFT VACF 10000 x 100000 x 3", "fft", 10000, 100000, True, False, False, 3, 1),
+        ("configs[3]: windowed (direct) VACF 5000 x 50000 x 3", "direct", 5000, 50000, False, False, False, 3, 1),
+        ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float32 path", "helfand", 20000, 25000, False, True, False, 2, 1),
+        ("configs[4] per-GPU share, helfand_fft option (float64): 20000 x 25000 x 3", "helfand", 20000, 25000, False, False, True, 3, 1),
+        ("long trajectory: FFT VACF timeseries 20000 x 25000 x 3", "fft", 20000, 25000, False, False, False, 5, 1),
+        ("long trajectory with vacf_by_particle: FFT VACF 20000 x 25000 x 3", "fft", 20000, 25000, True, False, False, 3, 1),
     ]
-    for name, mode, T, A, byp, f32, steps, warm in specs:
+    for name, mode, T, A, byp, f32, hfft, steps, warm in specs:
         try:
             ctx.stage_free()
             ctx.trim()
             torch.cuda.empty_cache()
             seed = SEED + {"fft": 3, "direct": 4, "helfand": 5}[mode]
-            c = Case(torch, ctx, dev, mode, T, A, 3, 0, A * 3, seed, byp, f32, False)
+            c = Case(torch, ctx, dev, mode, T, A, 3, 0, A * 3, seed, byp, f32, hfft)
             el = timed(torch, dist, 1, steps, warm, c.step)
             hist = ctx.timing_history(steps)
             kms = statistics.median(m for _, m in hist)
-            r = roofline_of(c, kms, False, f32)
+            r = roofline_of(c, kms, hfft, f32)
             res.append({"workload": name, "ms_per_step": el / steps * 1e3, "steps": steps,
                         "value": T * A / (el / steps), "unit": "lag-points/s", "roofline": r})
             del c
         except Exception as e:
             res.append({"workload": name, "error": str(e)[:300]})
     ctx.set_option("direct_f32", 0)
+    ctx.set_option("helfand_fft", 0)
     return res
 
 

@@ -110,11 +110,11 @@ int ta_stage_free(ta_ctx *ctx);
 int ta_stage_synth(ta_ctx *ctx, int slab, uint64_t seed, int64_t col_offset, int64_t n_cols_total,
                    void *stream);
 /* Release the context's cached workspaces.  They are sized by the largest call so far and kept
- * until this call or ta_ctx_destroy: per-workgroup spectra (<= 42 MB), the atom-major
- * by-particle scratch (n_atoms * n_frames * 8 bytes), the pair-major copies of frame-major *_dev
- * inputs (the input's size, twice for Helfand), the 64 MiB landing buffer of ta_stage_commit,
- * the outer-radix path's scratch (n_workgroups * 4 * 2R * M * 16 bytes: 5.4 GB at R = 16,
- * M = 10240) and the product slab of the "helfand_fft" option (the input's size).             */
+ * until this call or ta_ctx_destroy: partial spectra (<= 42 MB), with a by-particle array the
+ * atom-major scratch (n_atoms * n_frames * 8 bytes) and the power spectra of one block of atoms
+ * (2.5 GiB unless "bp_spec_atoms" says otherwise), the pair-major copies of frame-major *_dev
+ * inputs (the input's size, twice for Helfand), the 64 MiB landing buffer of ta_stage_commit
+ * and the product slab of the "helfand_fft" option (the input's size).                        */
 int ta_trim(ta_ctx *ctx);
 
 /* ---- compute on staged slabs (host-facing, blocking) -------------------
@@ -125,7 +125,7 @@ int ta_trim(ta_ctx *ctx);
  *                   slab 0 = velocities, slab 1 = positions; `scale` is
  *                   1 / (2 * kB * mean(volumes) * temp_avg) (viscosity.py:229-231)
  * h_timeseries: (n_frames,) = mean over atoms; h_by_particle: (n_frames, n_atoms)
- * or NULL.  n_frames above the largest on-chip FFT plan (10240) is evaluated by the
+ * or NULL.  ta_vacf_fft beyond 163840 frames (the largest FFT plan) is evaluated by the
  * direct correlator (same quantity: the reference asserts their equality).      */
 int ta_vacf_fft(ta_ctx *ctx, double *h_timeseries, double *h_by_particle);
 int ta_vacf_direct(ta_ctx *ctx, double *h_timeseries, double *h_by_particle);
@@ -173,13 +173,11 @@ int ta_last_timing(ta_ctx *ctx, float *total_ms, float *main_kernel_ms);
  * *n_out = number of entries written.  Blocks until those calls have completed.      */
 int ta_timing_history(ta_ctx *ctx, int max_n, float *total_ms, float *main_kernel_ms, int *n_out);
 /* FFT length bookkeeping for a given n_frames: *m_out = padded half-length M
- * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1; the lag-sum
- * path: M = 2^a or 5*2^a up to 512 frames, R0*512 with R0 in {2,4,5,8,10,16,20} above).  Up to
- * M = 10240 the transform runs on chip; up to 16 x 10240 the lag sums (no
- * by-particle output) use an outer radix step around the on-chip transform
- * (n_stages counts it); beyond that, and for by-particle output past 10240
- * frames, ta_vacf_fft* compute the same quantity with the direct correlator
- * and this call returns TA_E_UNSUPPORTED.                                     */
+ * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1): M = R * R0 * 512 with
+ * R0 in {1,2,4,5,8,10,16,20} and the outer radix R = 1 up to 10240 frames (one on-chip
+ * transform per pass), R in {2,4,8,16} up to 163840 frames (n_stages counts the outer step).
+ * Beyond that ta_vacf_fft* compute the same quantity with the direct correlator and this
+ * call returns TA_E_UNSUPPORTED.                                              */
 int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_stages);
 /* options (key, value):
  *   "direct_f32" 0|1 : direct correlators (ta_vacf_direct*, ta_helfand_msd*) evaluate
@@ -187,7 +185,7 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *                      and add them into float64 accumulators (BASELINE configs[4]'s
  *                      float32 path; ~1e-6 relative accuracy).  Default 0 = float64.
  *   "helfand_fft" 0|1: ta_helfand_msd* evaluate the mean squared differences in O(T log T)
- *                      (with a by-particle array: for n_frames <= 10240, else as default): sum (P[i]-P[i+k])^2 = S1(k) - 2 S2(k), S2 by the FFT
+ *                      (n_frames <= 163840, else as default): sum (P[i]-P[i+k])^2 = S1(k) - 2 S2(k), S2 by the FFT
  *                      lag sums of the product slab P = (m v) x, S1 by prefix sums.  An
  *                      extension (the reference has only the O(T^2) loop,
  *                      viscosity.py:201-233, which stays the default): ~1e-15 of the series'
@@ -199,7 +197,10 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *   "fft_nwg", "direct_nwg" : persistent workgroup counts (0 = automatic);
  *   "direct_chunk" 0|8|10, "direct_groups" n : force the direct correlators' lags per chunk /
  *                      cap the atoms a workgroup works on at once (0 = automatic);
- *   "fft_debug" : diagnostics.   Unknown keys return TA_E_INVALID.                */
+ *   "bp_spec_atoms" n : FFT path with a by-particle array: atoms per block of power spectra
+ *                      (scratch = n * 16 * M bytes; 0 = as many as fit 2.5 GiB);
+ *   "bp_prefetch" 0..3 : sub-series of the next atom's spectrum the inverse kernel requests
+ *                      ahead (default 2).   Unknown keys return TA_E_INVALID.             */
 int ta_set_option(ta_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

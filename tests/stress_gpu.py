@@ -39,7 +39,7 @@ def host_cases(n_cases, seed):
                 slabs[1][lo:hi] = x[lo:hi]
             ctx.stage_commit(lo, hi)
         v64, x64 = v.astype(np.float64), x.astype(np.float64)
-        by_particle = bool(rng.random() < 0.5) and kind != "fftlong"
+        by_particle = bool(rng.random() < 0.5)
         if kind == "helfand":
             scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
             ts, bp = ctx.helfand_msd(m, scale, by_particle=by_particle)
@@ -79,7 +79,7 @@ def main(n_cases, seed=1234):
              5120, 8192, 10240]
     for case in range(n_cases):
         kind = rng.choice(["fft", "fft", "fft", "direct", "helfand", "fftlong"])
-        if kind == "fftlong":  # beyond the on-chip transform: lag sums through csrc/fft_long.hip
+        if kind == "fftlong":  # beyond one on-chip transform: outer radix (csrc/wfft.hpp)
             T = int(rng.choice([10241, 16384, 16385, 20480, 20481, 32769, 40961])) if rng.random() < 0.4 \
                 else int(rng.integers(10241, 60000))
             A_all = int(rng.integers(1, 7))
@@ -98,7 +98,7 @@ def main(n_cases, seed=1234):
         dv, dx = torch.from_numpy(v).cuda(), torch.from_numpy(x).cuda()
         dm = torch.from_numpy(m[lo:hi].copy()).cuda()
         ld_row, off = A_all * D, lo * D * 8
-        by_particle = bool(rng.random() < 0.5) and kind != "fftlong"
+        by_particle = bool(rng.random() < 0.5)
         ld_bp = A + int(rng.integers(0, 3))
         ctx.set_option("fft_nwg", int(rng.choice([0, 0, 1, 2, 3, 8, 16])))
         ctx.set_option("direct_nwg", int(rng.choice([0, 0, 1, 2, 5])))

@@ -44,7 +44,7 @@ def test_plan_info():
     for T, M in ((1, 512), (16, 512), (17, 512), (500, 512), (512, 512), (513, 1024), (1000, 1024),
                  (1025, 2048), (2049, 2560), (5001, 5120), (5121, 8192), (10000, 10240), (10240, 10240)):
         assert _lib.fft_plan_info(T)["M"] == M
-    # beyond the on-chip plans: outer radix R x on-chip M (lag sums; csrc/fft_long.hip)
+    # beyond one on-chip transform: outer radix R x on-chip M (csrc/wfft.hpp)
     for T, M in ((10241, 16384), (16385, 20480), (20481, 32768), (40961, 65536), (163840, 163840)):
         info = _lib.fft_plan_info(T)
         assert info["M"] == M

@@ -1,6 +1,6 @@
-"""Same-box A/B of the two by-particle FFT evaluations: the two-kernel path (forward pass-split
-+ inverse, fft_debug 0) against the single kernel k_wbp (fft_debug 3).  Prints the largest
-difference between their results and the per-call time of each (HIP events around the call).
+"""By-particle FFT evaluation (forward kernel + inverse kernel per block of atoms) timed with
+the inverse kernel's spectrum prefetch depth 0..3 on one box; prints the per-call time (HIP
+events around the call) and the library's own (total, main kernels) timing of the last call.
 
     python tools/bp_ab.py [n_frames] [n_atoms] [dim] [spec_atoms]
 """
@@ -25,9 +25,7 @@ def main():
         ctx.set_option("bp_spec_atoms", spec_atoms)
     stream = torch.cuda.current_stream(dev).cuda_stream
     res = {}
-    for name, dbg, pf in (("two-kernel", 0, 2), ("k_wbp", 3, 0), ("two-kernel pf0", 0, 0), ("two-kernel pf1", 0, 1),
-                          ("two-kernel pf3", 0, 3), ("two-kernel", 0, 2)):
-        ctx.set_option("fft_debug", dbg)
+    for name, pf in (("prefetch 2", 2), ("prefetch 0", 0), ("prefetch 1", 1), ("prefetch 3", 3), ("prefetch 2", 2)):
         ctx.set_option("bp_prefetch", pf)
         lag = torch.zeros(T, dtype=torch.float64, device=dev)
         bp = torch.empty((T, A), dtype=torch.float64, device=dev)
@@ -46,7 +44,7 @@ def main():
         print(f"{name:15s} {ms:8.3f} ms/call  atoms*frames/s {A * T / ms / 1e-3:.3e}  last_timing {tm}", flush=True)
         res.setdefault(name, (lag.cpu().numpy(), bp[:, : min(A, 4096)].cpu().numpy()))
         del lag, bp
-    a, b = res["two-kernel"], res["k_wbp"]
+    a, b = res["prefetch 2"], res["prefetch 0"]
     print("max |lag diff|", float(np.max(np.abs(a[0] - b[0]))), "max |bp diff|", float(np.max(np.abs(a[1] - b[1]))),
           "bp scale", float(np.max(np.abs(b[1]))))
 

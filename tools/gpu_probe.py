@@ -18,13 +18,10 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--nwg", type=int, default=0)
     ap.add_argument("--bp", type=int, default=0)
-    ap.add_argument("--debug", type=int, default=0)
     a = ap.parse_args()
     ctx = _lib.Context(0)
     if a.nwg:
         ctx.set_option("fft_nwg" if a.mode == "fft" else "direct_nwg", a.nwg)
-    if a.debug:
-        ctx.set_option("fft_debug", a.debug)
     dev = torch.device("cuda:0")
     for case in a.cases.split(","):
         T, A = (int(x) for x in case.split("x"))

@@ -9,9 +9,8 @@ import sys
 
 
 def short(name):
-    for key in ("k_wsplit_accum", "k_wfft_accum", "k_wf_sum", "k_wf_fold", "k_wf_lags", "k_relayout", "k_synth", "k_unlayout",
-                "k_fft_accum_long", "k_fft_accum", "k_fft_finalize", "k_row_sums", "k_direct",
-                "k_sum_partials", "k_helfand"):
+    for key in ("k_wsplit_accum", "k_winverse", "k_w1_accum", "k_w1_bp", "k_wf_sum", "k_wf_fold", "k_wf_lags", "k_relayout",
+                "k_synth", "k_unlayout", "k_bp_transpose", "k_row_sums", "k_direct", "k_sum_partials", "k_helfand"):
         if key in name:
             return key
     return name[:60]

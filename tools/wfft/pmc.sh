@@ -1,9 +1,9 @@
 #!/bin/bash
-# PMC snapshot of k_wfft_accum / k_whalf_accum from the standalone harness (run on the GPU box).
+# PMC snapshot of k_wsplit_accum from the standalone harness (run on the GPU box).
 # usage: pmc.sh TAG [env assignments...] -- harness args
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-x}; shift
 OUT=$R/gpurun_out/pmcw_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-ARGS=${@:-"time 30000 10000 2 0 0 0"}
+ARGS=${@:-"time 30000 10000 2 0"}
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES SQ_INST_CYCLES_VMEM_RD" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "FETCH_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))

@@ -1,6 +1,12 @@
-// wfft_test.hip — standalone check + timing of k_wfft_accum (tools only; not part of the library).
-//   wfft_test check            : few pairs, compare the accumulated spectrum with a CPU transform
+// wfft_test.hip — standalone check + timing of the kernels of csrc/wfft.hpp (tools only; not part
+// of the library).  Plan from the environment: WF_R0 (first-stage radix, default 20), WF_R (outer
+// radix, default 1).
+//   wfft_test check            : 11 pairs; the summed spectrum of the forward kernel against a
+//                                long-double transform, and the inverse kernel's lag sums against
+//                                the direct sums of products
 //   wfft_test time <n_pairs> [T] [reps] [stamp]
+//                              : forward kernel, lag-sum mode; stamp = 1 adds the in-kernel s_memtime
+//                                split (S1 incl. waiting for rows / S2 incl. the barrier)
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -55,122 +61,104 @@ __global__ void k_fill(double* p, size_t n, unsigned long long seed) {
 }
 
 template <int R0>
-static int run(int argc, char** argv) {
+static int run(int R, int argc, char** argv) {
     using P = WPlan<R0>;
-    const int M = P::M;
+    const int M = P::M, L = 2 * R * M;
     const bool check = argc < 2 || !strcmp(argv[1], "check");
     const long n_pairs = check ? 11 : atol(argv[2]);
-    const int T = argc > 3 ? atoi(argv[3]) : (M == 10240 ? 10000 : M - 37);
+    const int T = argc > 3 ? atoi(argv[3]) : (R * M == 10240 ? 10000 : R * M - 37);
     const int reps = argc > 4 ? atoi(argv[4]) : 5;
     const bool stamp = argc > 5 && atoi(argv[5]);
-    const bool touch = !(argc > 6 && atoi(argv[6]) == 0);
-    const bool inter = !(argc > 7 && atoi(argv[7]) == 0);
-    const long pitch = T;
-    int ncu = 256;
+    const long pitch = (T + 7) / 8 * 8;
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
-    ncu = prop.multiProcessorCount;
-    const bool half = getenv("WF_HALF") && R0 == 20;
-    const int split = getenv("WF_SPLIT") ? atoi(getenv("WF_SPLIT")) : 0;  // 1: plain, 2: interleaved
-    int nwg = (int)std::min<long>(ncu, n_pairs);
-    if (half) nwg = std::max(16, (int)std::min<long>(2 * ncu, 2 * n_pairs) / 16 * 16);
-    if (split) nwg = std::max(16, (int)std::min<long>(ncu, 2 * n_pairs) / 16 * 16);
-    // twiddles
-    std::vector<cd> tw(wf_table_elems(R0));
-    wf_fill_table(R0, tw.data());
+    const int ncu = prop.multiProcessorCount, gran = 16 * R;
+    const int nwg = std::max<long>(gran, std::min<long>(ncu, 2 * R * n_pairs) / gran * gran);
+    const int n_tuples = nwg / (2 * R);
+    std::vector<cd> tw(wf_table_elems(R0, R));
+    wf_fill_table(R0, R, tw.data());
     cd* d_tw;
-    double *d_pm, *d_acc;
+    double *d_pm, *d_acc, *d_spec, *d_lag;
     unsigned long long* d_st;
     const size_t n_el = (size_t)n_pairs * pitch * 2;
     CK(hipMalloc(&d_tw, tw.size() * sizeof(cd)));
     CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
     CK(hipMalloc(&d_pm, n_el * 8));
-    CK(hipMalloc(&d_acc, (size_t)nwg * 2 * M * 8));
+    CK(hipMalloc(&d_acc, (size_t)n_tuples * L * 8));
+    CK(hipMalloc(&d_spec, (size_t)L * 8));
+    CK(hipMalloc(&d_lag, (size_t)T * 8));
     CK(hipMalloc(&d_st, (size_t)nwg * 8 * 8));
-    CK(hipMemset(d_acc, 0, (size_t)nwg * 2 * M * 8));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_whalf_accum<false>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WHalf::kLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_whalf_accum<true>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)WHalf::kLds));
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, d_pm, n_el, 12345ull);
     CK(hipDeviceSynchronize());
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wfft_accum<P, false>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wfft_accum<P, false, false>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wfft_accum<P, true, false, false>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wfft_accum<P, true, false, true>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wfft_accum<P, false, false, false>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wfft_accum<P, true>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsplit_accum<P, false, false>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsplit_accum<P, false, true>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wsplit_accum<P, true, true>),
-                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
     auto launch = [&]() {
-        if (split && stamp)
-            hipLaunchKernelGGL((k_wsplit_accum<P, true, true>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
-                               n_pairs, d_tw, d_acc, d_st);
-        else if (split == 2)
-            hipLaunchKernelGGL((k_wsplit_accum<P, false, true>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
-                               n_pairs, d_tw, d_acc, d_st);
-        else if (split)
-            hipLaunchKernelGGL((k_wsplit_accum<P, false, false>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
-                               n_pairs, d_tw, d_acc, d_st);
-        else if (half && stamp)
-            hipLaunchKernelGGL((k_whalf_accum<true>), dim3(nwg), dim3(256), WHalf::kLds, 0, d_pm, pitch, T, n_pairs,
-                               d_tw, d_acc, d_st);
-        else if (half)
-            hipLaunchKernelGGL((k_whalf_accum<false>), dim3(nwg), dim3(256), WHalf::kLds, 0, d_pm, pitch, T, n_pairs,
-                               d_tw, d_acc, d_st);
-        else if (stamp && !inter)
-            hipLaunchKernelGGL((k_wfft_accum<P, true, false, false>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
-                               n_pairs, d_tw, d_acc, d_st);
-        else if (stamp && !touch)
-            hipLaunchKernelGGL((k_wfft_accum<P, true, false, true>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
-                               n_pairs, d_tw, d_acc, d_st);
-        else if (!inter)
-            hipLaunchKernelGGL((k_wfft_accum<P, false, false, false>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
-                               n_pairs, d_tw, d_acc, d_st);
-        else if (stamp)
-            hipLaunchKernelGGL((k_wfft_accum<P, true>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
-                               n_pairs, d_tw, d_acc, d_st);
-        else if (!touch)
-            hipLaunchKernelGGL((k_wfft_accum<P, false, false>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
-                               n_pairs, d_tw, d_acc, d_st);
-        else
-            hipLaunchKernelGGL((k_wfft_accum<P, false>), dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T,
-                               n_pairs, d_tw, d_acc, d_st);
+        auto go = [&](auto kern) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)P::kLds));
+            hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T, n_pairs, d_tw, d_acc, 0, R,
+                               d_st);
+        };
+        if (R > 1) stamp ? go(k_wsplit_accum<P, false, true, true>) : go(k_wsplit_accum<P, false, true, false>);
+        else stamp ? go(k_wsplit_accum<P, false, false, true>) : go(k_wsplit_accum<P, false, false, false>);
         CK(hipGetLastError());
     };
     launch();
     CK(hipDeviceSynchronize());
     if (check) {
-        std::vector<double> h((size_t)n_pairs * pitch * 2), acc((size_t)nwg * 2 * M);
+        std::vector<double> h(n_el), acc((size_t)n_tuples * L);
         CK(hipMemcpy(h.data(), d_pm, h.size() * 8, hipMemcpyDeviceToHost));
         CK(hipMemcpy(acc.data(), d_acc, acc.size() * 8, hipMemcpyDeviceToHost));
-        std::vector<long double> ref(2 * (size_t)M, 0.0L);
+        std::vector<long double> ref((size_t)L, 0.0L);
         for (long p = 0; p < n_pairs; ++p) {
-            std::vector<cl> a(2 * (size_t)M, cl(0, 0));
+            std::vector<cl> a((size_t)L, cl(0, 0));
             for (int t = 0; t < T; ++t) a[t] = cl(h[(p * pitch + t) * 2], h[(p * pitch + t) * 2 + 1]);
             fft_rec(a);
             for (size_t k = 0; k < a.size(); ++k) ref[k] += std::norm(a[k]);
         }
+        // spectrum layout [pass c][q][cc][lane]: bin k = 2R (q + R0 s) + c, s = (lane >> 3) + 8 (lane & 7) + 64 cc
+        std::vector<double> spec((size_t)L, 0.0);
         long double mx = 0, err = 0;
-        for (size_t k = 0; k < ref.size(); ++k) {
-            long double got = 0;
-            for (int w = 0; w < nwg; ++w) got += acc[(size_t)w * 2 * M + k];
-            mx = std::max(mx, fabsl(ref[k]));
-            err = std::max(err, fabsl(got - ref[k]));
+        for (int c = 0; c < 2 * R; ++c)
+            for (int q = 0; q < R0; ++q)
+                for (int cc = 0; cc < 8; ++cc)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const size_t i = (size_t)c * M + (q * 8 + cc) * 64 + lane;
+                        long double got = 0;
+                        for (int w = 0; w < n_tuples; ++w) got += acc[(size_t)w * L + i];
+                        spec[i] = (double)got;
+                        const int sb = (lane >> 3) + 8 * (lane & 7) + 64 * cc;
+                        const size_t k = (size_t)2 * R * (q + R0 * sb) + c;
+                        mx = std::max(mx, fabsl(ref[k]));
+                        err = std::max(err, fabsl(got - ref[k]));
+                    }
+        const bool ok_f = err / mx < 1e-12L;
+        printf("forward  R0=%d R=%d L=%d T=%d pairs=%ld  max|ref|=%Lg  max err=%Lg  rel=%Lg  %s\n", R0, R, L, T, n_pairs,
+               mx, err, err / mx, ok_f ? "OK" : "FAIL");
+        // inverse kernel on the summed spectrum: lag sums against sum_p sum_t conj(z[t]) z[t+n] / (T - n)
+        CK(hipMemcpy(d_spec, spec.data(), spec.size() * 8, hipMemcpyHostToDevice));
+        auto inv = [&](auto kern) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)P::kLds));
+            hipLaunchKernelGGL(kern, dim3(1), dim3(P::NT), P::kLds, 0, d_spec, T, 1L, d_tw, d_lag, 0L, R);
+        };
+        if (R > 1) inv(k_winverse<P, true, 0>);
+        else inv(k_winverse<P, false, 0>);
+        CK(hipDeviceSynchronize());
+        std::vector<double> lag(T);
+        CK(hipMemcpy(lag.data(), d_lag, lag.size() * 8, hipMemcpyDeviceToHost));
+        long double lmx = 0, lerr = 0;
+        for (int n = 0; n < T; n += std::max(1, T / 97)) {
+            long double sref = 0;
+            for (long p = 0; p < n_pairs; ++p)
+                for (int t = 0; t + n < T; ++t)
+                    sref += (long double)h[(p * pitch + t) * 2] * h[(p * pitch + t + n) * 2] +
+                            (long double)h[(p * pitch + t) * 2 + 1] * h[(p * pitch + t + n) * 2 + 1];
+            sref /= (long double)(T - n);
+            lmx = std::max(lmx, fabsl(sref));
+            lerr = std::max(lerr, fabsl((long double)lag[n] - sref));
         }
-        printf("R0=%d M=%d T=%d pairs=%ld  max|ref|=%Lg  max err=%Lg  rel=%Lg  %s\n", R0, M, T, n_pairs, mx,
-               err, err / mx, err / mx < 1e-12L ? "OK" : "FAIL");
-        return err / mx < 1e-12L ? 0 : 1;
+        const bool ok_i = lerr / lmx < 1e-11L;
+        printf("inverse  max|ref|=%Lg  max err=%Lg  rel=%Lg  %s\n", lmx, lerr, lerr / lmx, ok_i ? "OK" : "FAIL");
+        return ok_f && ok_i ? 0 : 1;
     }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -187,18 +175,18 @@ static int run(int argc, char** argv) {
         sum += ms;
     }
     const double bytes = (double)n_pairs * T * 16.0;
-    printf("R0=%d M=%d T=%d pairs=%ld nwg=%d: best %.3f ms  mean %.3f ms  %.1f GB/s  (x150000 pairs: %.2f ms)\n", R0,
-           M, T, n_pairs, nwg, best, sum / reps, bytes / best * 1e-6, best * 150000.0 / n_pairs);
+    printf("R0=%d R=%d L=%d T=%d pairs=%ld nwg=%d: best %.3f ms  mean %.3f ms  %.1f GB/s  (x150000 pairs: %.2f ms)\n", R0,
+           R, L, T, n_pairs, nwg, best, sum / reps, bytes / best * 1e-6, best * 150000.0 / n_pairs);
     if (stamp) {
         std::vector<unsigned long long> st((size_t)nwg * 8);
         CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
         for (int h = 0; h < 2; ++h) {
-            double s[4] = {0, 0, 0, 0};
+            double s[2] = {0, 0};
             for (int w = 0; w < nwg; ++w)
-                for (int i = 0; i < 4; ++i) s[i] += (double)st[(size_t)w * 8 + h * 4 + i];
-            const double per = (double)nwg * ((double)n_pairs / nwg);
-            printf("cycles/pair (wave %d): S1A %.0f  S2A %.0f  S1B %.0f  S2B %.0f  total %.0f\n", 4 * h, s[0] / per,
-                   s[1] / per, s[2] / per, s[3] / per, (s[0] + s[1] + s[2] + s[3]) / per);
+                for (int i = 0; i < 2; ++i) s[i] += (double)st[(size_t)w * 8 + h * 4 + i];
+            const double per = (double)nwg * ((double)n_pairs / n_tuples);  // unit-passes
+            printf("cycles per unit and pass (wave %d): S1 %.0f  S2 %.0f  total %.0f\n", 4 * h, s[0] / per, s[1] / per,
+                   (s[0] + s[1]) / per);
         }
     }
     return 0;
@@ -207,14 +195,15 @@ static int run(int argc, char** argv) {
 int main(int argc, char** argv) {
     const char* r = getenv("WF_R0");
     const int R0 = r ? atoi(r) : 20;
+    const int R = getenv("WF_R") ? atoi(getenv("WF_R")) : 1;
     switch (R0) {
-        case 20: return run<20>(argc, argv);
-        case 16: return run<16>(argc, argv);
-        case 10: return run<10>(argc, argv);
-        case 8: return run<8>(argc, argv);
-        case 5: return run<5>(argc, argv);
-        case 4: return run<4>(argc, argv);
-        case 2: return run<2>(argc, argv);
+        case 20: return run<20>(R, argc, argv);
+        case 16: return run<16>(R, argc, argv);
+        case 10: return run<10>(R, argc, argv);
+        case 8: return run<8>(R, argc, argv);
+        case 5: return run<5>(R, argc, argv);
+        case 4: return run<4>(R, argc, argv);
+        case 2: return run<2>(R, argc, argv);
     }
     fprintf(stderr, "unsupported WF_R0\n");
     return 2;

@@ -55,7 +55,6 @@ struct ta_ctx {
     // options
     int64_t opt_fft_nwg = 0;
     int64_t opt_direct_nwg = 0;
-    int64_t opt_fft_debug = 0;
     int64_t opt_direct_f32 = 0;
     int64_t opt_direct_groups = 0;
     int64_t opt_direct_chunk = 0;
@@ -504,7 +503,6 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return fail(ctx, TA_E_INVALID, "null argument");
     if (!strcmp(key, "fft_nwg")) ctx->opt_fft_nwg = value;
     else if (!strcmp(key, "direct_nwg")) ctx->opt_direct_nwg = value;
-    else if (!strcmp(key, "fft_debug")) ctx->opt_fft_debug = value;
     else if (!strcmp(key, "direct_f32")) ctx->opt_direct_f32 = value;
     else if (!strcmp(key, "direct_groups")) ctx->opt_direct_groups = value;
     else if (!strcmp(key, "direct_chunk")) ctx->opt_direct_chunk = value;
