@@ -375,8 +375,13 @@ __global__ void __launch_bounds__(P::NT)
     for (long item = tuple * grp; item < n_units;) {
         // ---- S1: radix-R0 butterfly u = tid over rows u + 512 j of u_c (jo = 0 requested during
         // the previous S2); g = W_M^u, h = W_L^{c u}
-        const cd g = wf_load(twr, (unsigned)(tid * R) * 32u, 0u), g2 = wf_load(twr, (unsigned)(tid * R) * 64u, 0u),
-                 h = wf_load(twr, (unsigned)(tid * pass) * 16u, 0u);
+        cd g, g2, h;
+        auto load_seeds = [&]() {
+            g = wf_load(twr, (unsigned)(tid * R) * 32u, 0u);
+            g2 = wf_load(twr, (unsigned)(tid * R) * 64u, 0u);
+            h = wf_load(twr, (unsigned)(tid * pass) * 16u, 0u);
+        };
+        if constexpr (!LONG) load_seeds();
 #if WF_ABL != 2
         if constexpr (LONG) {
             // u_c[u + 512 j] = sum_jo z[u + 512 j + M jo] U(j, jo), U = W_L^{c (512 j + M jo)} lane-uniform,
@@ -391,20 +396,36 @@ __global__ void __launch_bounds__(P::NT)
                     x[j] = cmul(x[j], tw_uniform(tw2, idx));
                 }
             }
-            int base = 0;
-            for (int jo = 1; jo < R; ++jo) {
-                base += so;
-                base -= base >= L ? L : 0;
-                if (jo * M >= T) break;  // nothing but padding from here on
-                int idx = base;
+            auto outer_rows = [&](auto single) {
+                int base = 0;
+                for (int jo = 1; jo < R; ++jo) {
+                    base += so;
+                    base -= base >= L ? L : 0;
+                    if (jo * M >= T) break;  // nothing but padding from here on
+                    int idx = base;
+                    // four rows in flight at a time: all R0 at once would not fit next to x[]
 #pragma unroll
-                for (int j = 0; j < R0; ++j) {
-                    const cd z = load_row(crs, kind, (unsigned)(N1 * j + M * jo));
-                    x[j] = wf_cfma(x[j], z, tw_uniform(tw2, idx));
-                    idx += sj;
-                    idx -= idx >= L ? L : 0;
+                    for (int j0 = 0; j0 < R0; j0 += 4) {
+                        cd z[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (j0 + i < R0)
+                                z[i] = load_row(crs, decltype(single)::value ? kind : 2, (unsigned)(N1 * (j0 + i) + M * jo));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (j0 + i < R0) {
+                                x[j0 + i] = wf_cfma(x[j0 + i], z[i], tw_uniform(tw2, idx));
+                                idx += sj;
+                                idx -= idx >= L ? L : 0;
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-            }
+            };
+            if (BYP && kind != 2) outer_rows(std::true_type{});
+            else outer_rows(std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            load_seeds();  // after the row loads: their registers are free again
         } else if (pass) {
             // pass B twist, lane-uniform part: W_{2 R0}^j = tw2[j * 512]
 #pragma unroll
