@@ -159,7 +159,7 @@ def timed(torch, dist, world, steps, warmup, fn):
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     return elapsed
@@ -273,11 +273,19 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # TA_BENCH_ONE_GPU=1: rehearsal of the N > 1 path on a one-GPU box (tests/test_gpu_dist.py):
+    # every rank on device 0, gloo instead of RCCL, lag sums reduced through the host
+    one_gpu = os.environ.get("TA_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from transport_analysis_amd import _lib
     from transport_analysis_amd.dist import atom_shard, reduce_lagsum
@@ -303,7 +311,10 @@ def main():
 
     def step():
         case.step()
-        result["ts"] = reduce_lagsum(case.lagsum, a_total)  # device tensor in and out
+        if one_gpu and world > 1:
+            result["ts"] = reduce_lagsum(case.lagsum.cpu(), a_total)
+        else:
+            result["ts"] = reduce_lagsum(case.lagsum, a_total)  # device tensor in and out
 
     elapsed = timed(torch, dist, world, args.steps, args.warmup, step)
     hist = ctx.timing_history(min(args.steps, 64))

@@ -69,3 +69,30 @@ def test_classes_distributed_two_ranks_one_gpu(tmp_path, T, A):
         assert scale_rel_err(z["visc_ts"], hts) < TOL
         if hi > lo:
             assert scale_rel_err(z["visc_bp"], hbp[:, lo:hi]) < TOL
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_rehearsal_on_one_gpu(scaling):
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one JSON line from
+    rank 0, value = whole-job lag-points over the max-over-ranks time), rehearsed with both ranks
+    on this box's one GPU (TA_BENCH_ONE_GPU=1: gloo instead of RCCL)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TA_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    port = 34500 + (os.getpid() % 1000) + (1 if scaling == "weak" else 2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "2000", "--atoms", "3000",
+           "--scaling", scaling]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    total = 6000 if scaling == "weak" else 3000
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["config"]["n_atoms_total"] == total
+    assert d["value"] == pytest.approx(2000 * total / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    assert d["roofline"]["frac"] > 0 and d["config"]["sharding"] == "atoms x2"
