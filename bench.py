@@ -105,6 +105,7 @@ class Case:
         self.torch, self.ctx, self.mode, self.T, self.A, self.D = torch, ctx, mode, T, A, D
         self.helfand_fft = helfand_fft
         ctx.set_option("direct_f32", 1 if float32 else 0)
+        ctx.set_option("stage_device_f32", 1 if float32 else 0)  # float32 path: float32 device slabs
         ctx.set_option("helfand_fft", 1 if helfand_fft else 0)
         self.stream = torch.cuda.current_stream().cuda_stream
         ctx.stage_alloc_device(T, A, D, n_slabs=2 if mode == "helfand" else 1)
@@ -428,6 +429,7 @@ def other_configs(torch, dist, _lib, ctx, dev):
         except Exception as e:
             res.append({"workload": name, "error": str(e)[:300]})
     ctx.set_option("direct_f32", 0)
+    ctx.set_option("stage_device_f32", 0)
     ctx.set_option("helfand_fft", 0)
     return res
 

@@ -700,7 +700,8 @@ def test_classes_float32_and_float64_staging_bit_equal(fft):
 
 
 def test_helfand_config4_full_per_gpu_share(ctx):
-    """BASELINE configs[4] at ONE GPU's full share: 20000 frames x 25000 atoms x 3, float32 path,
+    """BASELINE configs[4] at ONE GPU's full share: 20000 frames x 25000 atoms x 3, float32 path
+    on float32 device slabs,
     staged pair-major (viscosity.py:210-226 is the loop replaced).  Size-independent checks:
     lag 0 exactly 0; selected lags against float64 slab differences over the whole block; the
     lag sums of the two half blocks add up to the whole's."""
@@ -718,10 +719,12 @@ def test_helfand_config4_full_per_gpu_share(ctx):
         ctx.stage_read_dev(0, fm.data_ptr(), n * D, st)
         xm = 30.0 + 0.002 * torch.cumsum(fm, dim=0)
         ctx.stage_commit_dev(1, xm.data_ptr(), n * D, 0, T, stream=st)
+        ctx.stage_read_dev(1, xm.data_ptr(), n * D, st)  # as stored: rounded to float32
         torch.cuda.synchronize()
         return fm, xm
 
     ctx.set_option("direct_f32", 1)
+    ctx.set_option("stage_device_f32", 1)  # float32 device slabs: 2 x 6 GB instead of 2 x 12 GB
     try:
         v, x = stage(0, A)
         whole = torch.zeros(T, dtype=torch.float64, device="cuda")
@@ -747,6 +750,7 @@ def test_helfand_config4_full_per_gpu_share(ctx):
         assert float((parts - whole).abs().max().item()) < TOL_F32 * float(whole.abs().max().item())
     finally:
         ctx.set_option("direct_f32", 0)
+        ctx.set_option("stage_device_f32", 0)
         ctx.stage_free()
         ctx.trim()
         torch.cuda.empty_cache()
@@ -851,3 +855,92 @@ def test_vacf_fft_many_units_per_workgroup(ctx, T, A, D):
     assert scale_rel_err(ts, want_ts) < TOL
     ts2, _ = run_vacf(ctx, v, True, False)
     assert scale_rel_err(ts2, want_ts) < TOL
+
+
+# ------------------------------------------------------------------ float32 device slabs
+@pytest.mark.parametrize("T,A,D", [(300, 7, 3), (1000, 33, 3), (2500, 5, 2), (17001, 2, 1)])
+def test_float32_device_slabs_change_nothing(ctx, T, A, D):
+    """"stage_device_f32": float32 host slabs kept as float32 on the device (half the footprint,
+    BASELINE configs[4]'s float32 path).  The float32 direct correlators read them as they are and
+    every other evaluation widens them first: all results are bit-equal to those from float64
+    device slabs of the same (float32-representable) values.  viscosity.py:201-233,
+    velocityautocorr.py:208-238."""
+    from oracle import numpy_oracle as orc
+
+    v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=77 + T)
+    v, x = v.astype(np.float32), x.astype(np.float32)
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+
+    def run_all(dev_f32):
+        out = {}
+        ctx.set_option("stage_device_f32", dev_f32)
+        sv, sx = ctx.stage_alloc(T, A, D, n_slabs=2, dtype=np.float32)
+        sv[...] = v
+        sx[...] = x
+        ctx.stage_commit(0, T)
+        for f32 in (1, 0):
+            ctx.set_option("direct_f32", f32)
+            out[f"helfand{f32}"] = ctx.helfand_msd(m, scale, by_particle=True)
+            out[f"direct{f32}"] = ctx.vacf_direct(by_particle=True)
+        out["fft"] = ctx.vacf_fft(by_particle=True)
+        ctx.set_option("helfand_fft", 1)
+        out["helfand_fft"] = ctx.helfand_msd(m, scale, by_particle=False)
+        ctx.set_option("helfand_fft", 0)
+        return out
+
+    try:
+        a, b = run_all(1), run_all(0)
+    finally:
+        for key in ("stage_device_f32", "direct_f32", "helfand_fft"):
+            ctx.set_option(key, 0)
+    for key in a:
+        assert np.array_equal(a[key][0], b[key][0]), key
+        if a[key][1] is not None:
+            assert np.array_equal(a[key][1], b[key][1]), key
+    want_bp, want_ts = orc.helfand(v.astype(np.float64), x.astype(np.float64), m, vol, 300.0) if T <= 2500 else (None, None)
+    if want_ts is not None:
+        assert scale_rel_err(a["helfand1"][0], want_ts) < TOL_F32
+        assert scale_rel_err(a["helfand0"][0], want_ts) < TOL
+
+
+def test_float32_device_slabs_staged_api(ctx):
+    """Device-only float32 slabs: ta_stage_synth rounds once to float32, ta_stage_commit_dev /
+    ta_stage_read_dev round-trip float32 data exactly, and the staged float32 Helfand evaluation
+    equals the one on float64 slabs holding the same rounded values."""
+    import torch
+
+    T, A, D = 4000, 300, 3
+    st = torch.cuda.current_stream().cuda_stream
+    m = torch.linspace(1.0, 16.0, A, dtype=torch.float64, device="cuda")
+    res = []
+    try:
+        ctx.set_option("direct_f32", 1)
+        for dev_f32 in (1, 0):
+            ctx.set_option("stage_device_f32", dev_f32)
+            ctx.stage_alloc_device(T, A, D, n_slabs=2)
+            ctx.stage_synth(0, 99, 0, A * D, st)
+            fm = torch.empty((T, A * D), dtype=torch.float64, device="cuda")
+            ctx.stage_read_dev(0, fm.data_ptr(), A * D, st)
+            torch.cuda.synchronize()
+            if dev_f32:
+                assert bool((fm == fm.float().double()).all().item())  # float32 values
+                v32 = fm.clone()
+            else:
+                ctx.stage_commit_dev(0, v32.data_ptr(), A * D, 0, T, stream=st)  # same rounded values
+            xm = (30.0 + 0.002 * torch.cumsum(v32, dim=0)).float()
+            ctx.stage_commit_dev(1, xm.data_ptr(), A * D, 0, T, dtype=np.float32, stream=st)
+            back = torch.empty((T, A * D), dtype=torch.float64, device="cuda")
+            ctx.stage_read_dev(1, back.data_ptr(), A * D, st)
+            torch.cuda.synchronize()
+            assert bool((back == xm.double()).all().item())
+            lag = torch.zeros(T, dtype=torch.float64, device="cuda")
+            bp = torch.zeros((T, A), dtype=torch.float64, device="cuda")
+            ctx.helfand_msd_staged(m.data_ptr(), 1.0, lag.data_ptr(), bp.data_ptr(), A, st)
+            torch.cuda.synchronize()
+            res.append((lag.cpu().numpy(), bp.cpu().numpy()))
+    finally:
+        ctx.set_option("stage_device_f32", 0)
+        ctx.set_option("direct_f32", 0)
+        ctx.stage_free()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert float(np.max(np.abs(res[0][0]))) > 0

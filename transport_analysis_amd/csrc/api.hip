@@ -41,6 +41,7 @@ struct ta_ctx {
     // device slabs are pair-major (layout.hip) with st_pitch rows per column pair
     int64_t st_T = 0, st_A = 0, st_pitch = 0;
     int st_D = 0, st_dtype = TA_F64, st_nslabs = 0;
+    bool st_dev_f32 = false;  // device slabs hold float32 elements ("stage_device_f32")
     std::vector<void*> h_slabs;
     std::vector<double*> d_slabs;
     // timing: a ring of event quadruples, one per compute call (start, main kernel start,
@@ -62,6 +63,7 @@ struct ta_ctx {
     int64_t opt_bp_block = 0;
     int64_t opt_bp_spec_atoms = 0;
     int64_t opt_bp_prefetch = 2;
+    int64_t opt_stage_device_f32 = 0;
 };
 
 namespace {
@@ -94,8 +96,8 @@ int ensure(ta_ctx* ctx, DevBuf& b, size_t bytes) {
 }
 
 inline int64_t pm_pitch(int64_t n_frames) { return (n_frames + 7) / 8 * 8; }
-inline size_t pm_bytes(int64_t n_frames, int64_t n_cols) {
-    return (size_t)((n_cols + 1) / 2) * (size_t)pm_pitch(n_frames) * 16;
+inline size_t pm_bytes(int64_t n_frames, int64_t n_cols, bool f32 = false) {
+    return (size_t)((n_cols + 1) / 2) * (size_t)pm_pitch(n_frames) * (f32 ? 8 : 16);
 }
 
 int get_wf_table(ta_ctx* ctx, int R0, int R, cd** out) {
@@ -128,10 +130,10 @@ int check_shape(ta_ctx* ctx, int64_t T, int64_t A, int D, int64_t ld_row) {
     return TA_OK;
 }
 
-int direct_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos,
+int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
                 const double* d_masses, int64_t T, int64_t A, int D, int64_t pitch, double scale,
-                double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st) {
-    const bool f32 = ctx->opt_direct_f32 != 0;
+                double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st, bool src_f32 = false) {
+    const bool f32 = ctx->opt_direct_f32 != 0;  // src_f32 only comes with it (compute_pm)
     // Shape of the launch.  A thread owns one chunk pair (2L lags); a column group = W waves;
     // a workgroup = G groups working on G atoms at once, so that ONE workgroup fills a CU's
     // 16 wave slots (G*W <= 16) and its waves are dealt evenly to the 4 SIMDs.  The column
@@ -188,7 +190,7 @@ int direct_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos,
     }
     TA_HIP_TRY(ctx, hipMemsetAsync(ctx->ts_partial.p, 0, sizeof(double) * rows * T, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-    TA_HIP_TRY(ctx, launch_direct(mode, f32, L, d_vel, d_pos, d_masses, pitch, (int)T, A, D, scale, bp_am,
+    TA_HIP_TRY(ctx, launch_direct(mode, f32, src_f32, L, d_vel, d_pos, d_masses, pitch, (int)T, A, D, scale, bp_am,
                                   Tp, (double*)ctx->ts_partial.p, (int)nwg, nt, lds, stage_buf,
                                   gnt, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
@@ -328,21 +330,42 @@ int helfand_impl(ta_ctx* ctx, const double* pm_vel, const double* pm_pos, const 
 enum { W_FFT = 0, W_DIRECT = 1, W_HELFAND = 2 };
 
 // one compute call on pair-major slabs, bracketed by the timing events
-int compute_pm(ta_ctx* ctx, int which, const double* pm_vel, const double* pm_pos, const double* d_masses,
+int compute_pm(ta_ctx* ctx, int which, const void* pm_vel_any, const void* pm_pos_any, const double* d_masses,
                int64_t pitch, int64_t T, int64_t A, int D, double scale, double* d_lagsum, double* d_bp,
-               int64_t ld_bp, hipStream_t st, bool record_start) {
+               int64_t ld_bp, hipStream_t st, bool record_start, bool pm_f32 = false) {
     int rc;
     ctx->timing_valid = false;
     if (record_start) {
         ctx->ev = ctx->ring[ctx->n_calls % ta_ctx::kRing];
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
     }
+    // float32 device slabs are read as they are by the float32 direct correlators; every other
+    // evaluation works on a float64 copy (same layout) in the context's scratch slabs
+    const bool direct_on_f32 = pm_f32 && ctx->opt_direct_f32 &&
+                               (which == W_DIRECT || (which == W_HELFAND && !(ctx->opt_helfand_fft && T >= 2)));
+    if (pm_f32 && !direct_on_f32) {
+        const size_t n_el = (size_t)((A * D + 1) / 2) * (size_t)pitch * 2;
+        const void* src[2] = {pm_vel_any, pm_pos_any};
+        for (int k = 0; k < 2; ++k) {
+            if (!src[k]) continue;
+            if ((rc = ensure(ctx, ctx->pm_in[k], n_el * sizeof(double)))) return rc;
+            TA_HIP_TRY(ctx, launch_widen_f32((const float*)src[k], (double*)ctx->pm_in[k].p, (long)n_el, st));
+        }
+        pm_vel_any = ctx->pm_in[0].p;
+        if (pm_pos_any) pm_pos_any = ctx->pm_in[1].p;
+    }
+    const double* pm_vel = (const double*)pm_vel_any;
+    const double* pm_pos = (const double*)pm_pos_any;
     // paths without a dominant kernel of their own re-record ev[1]/ev[2] inside
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     if (which == W_FFT) rc = fft_impl(ctx, pm_vel, pitch, T, A, D, d_lagsum, d_bp, ld_bp, st);
     else if (which == W_DIRECT)
-        rc = direct_impl(ctx, MODE_VACF, pm_vel, nullptr, nullptr, T, A, D, pitch, 1.0, d_lagsum, d_bp, ld_bp, st);
+        rc = direct_impl(ctx, MODE_VACF, pm_vel_any, nullptr, nullptr, T, A, D, pitch, 1.0, d_lagsum, d_bp, ld_bp, st,
+                         direct_on_f32);
+    else if (direct_on_f32)
+        rc = direct_impl(ctx, MODE_HELFAND, pm_vel_any, pm_pos_any, d_masses, T, A, D, pitch, scale, d_lagsum, d_bp,
+                         ld_bp, st, true);
     else rc = helfand_impl(ctx, pm_vel, pm_pos, d_masses, pitch, T, A, D, scale, d_lagsum, d_bp, ld_bp, st);
     if (rc) return rc;
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
@@ -356,7 +379,7 @@ int relayout_input(ta_ctx* ctx, int k, const double* d_src, int64_t T, int64_t n
                    hipStream_t st, const double** out) {
     int rc = ensure(ctx, ctx->pm_in[k], pm_bytes(T, n_cols));
     if (rc) return rc;
-    TA_HIP_TRY(ctx, launch_relayout(d_src, false, ld_row, n_cols, T, (double*)ctx->pm_in[k].p, pm_pitch(T), 0, st));
+    TA_HIP_TRY(ctx, launch_relayout(d_src, false, ld_row, n_cols, T, ctx->pm_in[k].p, false, pm_pitch(T), 0, st));
     *out = (const double*)ctx->pm_in[k].p;
     return TA_OK;
 }
@@ -401,7 +424,7 @@ int staged_entry(ta_ctx* ctx, int which, const double* d_masses, double scale, d
     if (rc) return rc;
     return compute_pm(ctx, which, ctx->d_slabs[0], need == 2 ? ctx->d_slabs[1] : nullptr, d_masses,
                       ctx->st_pitch, ctx->st_T, ctx->st_A, ctx->st_D, scale, d_lagsum, d_bp, ld_bp,
-                      (hipStream_t)stream, true);
+                      (hipStream_t)stream, true, ctx->st_dev_f32);
 }
 
 }  // namespace
@@ -510,6 +533,7 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "bp_block")) ctx->opt_bp_block = value;
     else if (!strcmp(key, "bp_spec_atoms")) ctx->opt_bp_spec_atoms = value;
     else if (!strcmp(key, "bp_prefetch")) ctx->opt_bp_prefetch = value;
+    else if (!strcmp(key, "stage_device_f32")) ctx->opt_stage_device_f32 = value;
     else return fail(ctx, TA_E_INVALID, std::string("unknown option ") + key);
     return TA_OK;
 }
@@ -537,7 +561,9 @@ static int stage_alloc_common(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, in
     ta_stage_free(ctx);
     const size_t n = (size_t)n_frames * n_atoms * dim;
     const size_t esz = dtype == TA_F32 ? 4 : 8;
-    const size_t dbytes = pm_bytes(n_frames, n_atoms * dim);
+    // device slabs hold float32 when the option asks for it and nothing wider is coming in
+    const bool dev_f32 = ctx->opt_stage_device_f32 && (dtype == TA_F32 || !h_slabs);
+    const size_t dbytes = pm_bytes(n_frames, n_atoms * dim, dev_f32);
     for (int i = 0; i < n_slabs; ++i) {
         void* h = nullptr;
         double* d = nullptr;
@@ -560,6 +586,7 @@ static int stage_alloc_common(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, in
     ctx->st_A = n_atoms;
     ctx->st_D = dim;
     ctx->st_dtype = dtype;
+    ctx->st_dev_f32 = dev_f32;
     ctx->st_nslabs = n_slabs;
     ctx->st_pitch = pm_pitch(n_frames);
     // the zero fill ran on the context's stream; later fills may come on any stream
@@ -600,7 +627,7 @@ int ta_stage_commit(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
             TA_HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce.p, src, (size_t)m * row * esz, hipMemcpyHostToDevice,
                                            ctx->stream));
             TA_HIP_TRY(ctx, launch_relayout(ctx->bounce.p, ctx->st_dtype == TA_F32, (long)row, (long)row, m,
-                                            ctx->d_slabs[i], ctx->st_pitch, f, ctx->stream));
+                                            ctx->d_slabs[i], ctx->st_dev_f32, ctx->st_pitch, f, ctx->stream));
         }
     }
     return TA_OK;
@@ -617,7 +644,8 @@ int ta_stage_commit_dev(ta_ctx* ctx, int slab, const void* d_src, int dtype, int
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc_ = order_after_staging(ctx, (hipStream_t)stream)) return rc_;
     TA_HIP_TRY(ctx, launch_relayout(d_src, dtype == TA_F32, ld_row, ctx->st_A * ctx->st_D, frame_hi - frame_lo,
-                                    ctx->d_slabs[slab], ctx->st_pitch, frame_lo, (hipStream_t)stream));
+                                    ctx->d_slabs[slab], ctx->st_dev_f32, ctx->st_pitch, frame_lo,
+                                    (hipStream_t)stream));
     return TA_OK;
 }
 
@@ -629,7 +657,7 @@ int ta_stage_synth(ta_ctx* ctx, int slab, uint64_t seed, int64_t col_offset, int
         return fail(ctx, TA_E_INVALID, "column block outside the synthetic tensor");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc_ = order_after_staging(ctx, (hipStream_t)stream)) return rc_;
-    TA_HIP_TRY(ctx, launch_synth(ctx->d_slabs[slab], ctx->st_pitch, ctx->st_A * ctx->st_D, ctx->st_T, seed,
+    TA_HIP_TRY(ctx, launch_synth(ctx->d_slabs[slab], ctx->st_dev_f32, ctx->st_pitch, ctx->st_A * ctx->st_D, ctx->st_T, seed,
                                  col_offset, n_cols_total, (hipStream_t)stream));
     return TA_OK;
 }
@@ -640,7 +668,7 @@ int ta_stage_read_dev(ta_ctx* ctx, int slab, double* d_dst, int64_t ld_row, void
     if (ld_row < ctx->st_A * ctx->st_D) return fail(ctx, TA_E_INVALID, "ld_row smaller than n_atoms*dim");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc_ = order_after_staging(ctx, (hipStream_t)stream)) return rc_;
-    TA_HIP_TRY(ctx, launch_unlayout(ctx->d_slabs[slab], ctx->st_pitch, ctx->st_A * ctx->st_D, ctx->st_T, d_dst,
+    TA_HIP_TRY(ctx, launch_unlayout(ctx->d_slabs[slab], ctx->st_dev_f32, ctx->st_pitch, ctx->st_A * ctx->st_D, ctx->st_T, d_dst,
                                     ld_row, (hipStream_t)stream));
     return TA_OK;
 }
@@ -752,10 +780,11 @@ static int host_compute(ta_ctx* ctx, int which, const double* h_masses, double s
         for (int64_t b = 0; b < n_blocks; ++b) {
             const int64_t lo = b * CH, hi = std::min(A, lo + CH);
             const int64_t pair_lo = lo * D / 2;  // lo is a multiple of 64: a pair boundary
-            const double* v = ctx->d_slabs[0] + pair_lo * ctx->st_pitch * 2;
-            const double* x = need == 2 ? ctx->d_slabs[1] + pair_lo * ctx->st_pitch * 2 : nullptr;
+            const size_t off = (size_t)pair_lo * ctx->st_pitch * (ctx->st_dev_f32 ? 8 : 16);  // bytes
+            const void* v = (const char*)ctx->d_slabs[0] + off;
+            const void* x = need == 2 ? (const char*)ctx->d_slabs[1] + off : nullptr;
             if ((rc = compute_pm(ctx, which, v, x, d_m ? d_m + lo : nullptr, ctx->st_pitch, T, hi - lo, D, scale,
-                                 d_ls + b * T, d_bp + lo, A, ctx->stream, true)))
+                                 d_ls + b * T, d_bp + lo, A, ctx->stream, true, ctx->st_dev_f32)))
                 return rc;
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
             TA_HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_stage, 0));

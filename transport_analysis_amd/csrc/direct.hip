@@ -40,19 +40,24 @@ size_t direct_lds_bytes(int T, bool f32, int L) {
     return (size_t)(nchunks + 3) * group_stride_dwords(L, f32 ? 1 : 2) * 4;
 }
 
-static const void* direct_kernel(int mode, bool f32, int L, bool gs) {
-#define TA_K(M, LL, GS, R) reinterpret_cast<const void*>(k_direct<M, LL, GS, R>)
-#define TA_X(LL)                                                                         \
-    if (L == LL) {                                                                       \
-        if (mode == MODE_VACF) {                                                         \
-            if (f32) return gs ? TA_K(MODE_VACF, LL, true, float) : TA_K(MODE_VACF, LL, false, float); \
-            return gs ? TA_K(MODE_VACF, LL, true, double) : TA_K(MODE_VACF, LL, false, double);        \
-        }                                                                                \
-        if (f32) return gs ? TA_K(MODE_HELFAND, LL, true, float) : TA_K(MODE_HELFAND, LL, false, float); \
-        return gs ? TA_K(MODE_HELFAND, LL, true, double) : TA_K(MODE_HELFAND, LL, false, double);       \
+// src_f32: float32 slabs (only with the float32 arithmetic path: f32 must be set too)
+static const void* direct_kernel(int mode, bool f32, int L, bool gs, bool src_f32) {
+    if (src_f32 && !f32) return nullptr;
+#define TA_K(M, LL, GS, R, S) reinterpret_cast<const void*>(k_direct<M, LL, GS, R, S>)
+#define TA_PICK(M, LL)                                                                               \
+    if (src_f32) return gs ? TA_K(M, LL, true, float, float) : TA_K(M, LL, false, float, float);      \
+    if (f32) return gs ? TA_K(M, LL, true, float, double) : TA_K(M, LL, false, float, double);        \
+    return gs ? TA_K(M, LL, true, double, double) : TA_K(M, LL, false, double, double);
+#define TA_X(LL)                                  \
+    if (L == LL) {                                \
+        if (mode == MODE_VACF) {                  \
+            TA_PICK(MODE_VACF, LL)                \
+        }                                         \
+        TA_PICK(MODE_HELFAND, LL)                 \
     }
     TA_DIRECT_CHUNKS(TA_X)
 #undef TA_X
+#undef TA_PICK
 #undef TA_K
     return nullptr;
 }
@@ -64,12 +69,12 @@ bool direct_chunk_supported(int L) {
     return false;
 }
 
-hipError_t launch_direct(int mode, bool f32, int L, const double* vel, const double* pos,
+hipError_t launch_direct(int mode, bool f32, bool src_f32, int L, const void* vel, const void* pos,
                          const double* masses, long ld_row, int T, long n_atoms, int D,
                          double scale, double* by_particle, long ld_bp, double* ts_partial, int nwg,
                          int nt, size_t lds_bytes, void* stage_buf, int gnt, hipStream_t st) {
     const bool gs = stage_buf != nullptr;  // long trajectory: column staged in global memory
-    const void* fn = direct_kernel(mode, f32, L, gs);
+    const void* fn = direct_kernel(mode, f32, L, gs, src_f32);
     if (!fn) return hipErrorInvalidValue;
     if (!gs) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -82,7 +87,7 @@ hipError_t launch_direct(int mode, bool f32, int L, const double* vel, const dou
 }
 
 int direct_max_wg_per_cu(int mode, bool f32, int L, int nt, size_t lds_bytes, bool global_stage) {
-    const void* fn = direct_kernel(mode, f32, L, global_stage);
+    const void* fn = direct_kernel(mode, f32, L, global_stage, false);
     if (!fn) return 1;
     int n = 0;
     if (!global_stage)

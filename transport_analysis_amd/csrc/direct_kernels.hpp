@@ -251,9 +251,10 @@ __device__ __forceinline__ void chunk_accumulate(const float* __restrict__ s, in
 // GLOBAL_STAGE: trajectories too long for LDS (one column = (T/L+3) padded groups > 160 KiB)
 // stage the column in the group's slice of `stage_buf` instead ([gridDim.x * n_groups][n_slots],
 // L1/L2 resident): same code, lower rate, no limit on n_frames.
-template <int MODE, int L, bool GLOBAL_STAGE, typename Real>
+// SrcT: element type of the pair-major slabs (float64, or float32 device slabs: "stage_device_f32")
+template <int MODE, int L, bool GLOBAL_STAGE, typename Real, typename SrcT = double>
 __global__ void __launch_bounds__(1024)
-    k_direct(const double* __restrict__ vel, const double* __restrict__ pos,
+    k_direct(const SrcT* __restrict__ vel, const SrcT* __restrict__ pos,
              const double* __restrict__ masses, long pitch, int T, long n_atoms, int D,
              double scale, double* __restrict__ by_particle, long ld_bp,
              double* __restrict__ ts_partial, void* __restrict__ stage_buf, int gnt) {
@@ -292,8 +293,8 @@ __global__ void __launch_bounds__(1024)
                     double val = 0.0;
                     if (valid && e < T) {
                         const long g = cbase + 2L * e;
-                        val = vel[g];
-                        if (MODE == MODE_HELFAND) val = (mass * val) * pos[g];
+                        val = (double)vel[g];
+                        if (MODE == MODE_HELFAND) val = (mass * val) * (double)pos[g];
                     }
                     s[lds_slot<L, Real>(e)] = (Real)val;
                 }

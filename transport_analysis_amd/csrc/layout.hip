@@ -23,10 +23,10 @@ namespace {
 // src: frame-major rows [0, t_count) x columns [0, n_cols), row stride ld_row elements of SrcT.
 // dst rows t_dst0 + [0, t_count) of every pair are written.  64 x 64 tiles through LDS: reads
 // are 512 B (256 B for float32) per row segment, writes 1 KiB per pair (64 rows x 16 B).
-template <typename SrcT>
+template <typename SrcT, typename DstT>
 __global__ void __launch_bounds__(256)
     k_relayout(const SrcT* __restrict__ src, long ld_row, long n_cols, long t_count,
-               double* __restrict__ dst, long pitch, long t_dst0) {
+               DstT* __restrict__ dst, long pitch, long t_dst0) {
     __shared__ __attribute__((aligned(16))) double tile[64][66];
     const int tid = threadIdx.x;
     const long c0 = (long)blockIdx.x * 64, r0 = (long)blockIdx.y * 64;
@@ -46,20 +46,24 @@ __global__ void __launch_bounds__(256)
         const long pair = c0 / 2 + pp;
         if (pair < n_pairs && r0 + r < t_count) {
             const double2 v = *reinterpret_cast<const double2*>(&tile[r][2 * pp]);
-            *reinterpret_cast<double2*>(dst + (pair * pitch + t_dst0 + r0 + r) * 2) = v;
+            DstT* d = dst + (pair * pitch + t_dst0 + r0 + r) * 2;
+            if constexpr (sizeof(DstT) == 8) *reinterpret_cast<double2*>(d) = v;
+            else *reinterpret_cast<float2*>(d) = float2{(float)v.x, (float)v.y};
         }
     }
 }
 
 // The inverse, for callers that want a frame-major copy back (tests, diagnostics).
+template <typename PmT>
 __global__ void __launch_bounds__(256)
-    k_unlayout(const double* __restrict__ pm, long pitch, long n_cols, long t_count,
+    k_unlayout(const PmT* __restrict__ pm, long pitch, long n_cols, long t_count,
                double* __restrict__ dst, long ld_row) {
     const long n_pairs = (n_cols + 1) / 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs * t_count;
          i += (long)gridDim.x * blockDim.x) {
         const long pair = i / t_count, t = i - pair * t_count;
-        const double2 v = *reinterpret_cast<const double2*>(pm + (pair * pitch + t) * 2);
+        const PmT* q = pm + (pair * pitch + t) * 2;
+        const double2 v = double2{(double)q[0], (double)q[1]};
         dst[t * ld_row + 2 * pair] = v.x;
         if (2 * pair + 1 < n_cols) dst[t * ld_row + 2 * pair + 1] = v.y;
     }
@@ -117,8 +121,9 @@ __device__ __forceinline__ double synth_value(unsigned long long seed, unsigned 
 }
 
 // element (t, c) of the shard = synth(seed, t * n_cols_total + col_offset + c)
+template <typename PmT>
 __global__ void __launch_bounds__(256)
-    k_synth(double* __restrict__ pm, long pitch, long n_cols, long T, unsigned long long seed,
+    k_synth(PmT* __restrict__ pm, long pitch, long n_cols, long T, unsigned long long seed,
             long col_offset, long n_cols_total) {
     const long n_pairs = (n_cols + 1) / 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pairs * T;
@@ -128,29 +133,36 @@ __global__ void __launch_bounds__(256)
         double2 v;
         v.x = synth_value(seed, (unsigned long long)(t * n_cols_total + col_offset + c));
         v.y = c + 1 < n_cols ? synth_value(seed, (unsigned long long)(t * n_cols_total + col_offset + c + 1)) : 0.0;
-        *reinterpret_cast<double2*>(pm + (pair * pitch + t) * 2) = v;
+        PmT* q = pm + (pair * pitch + t) * 2;  // float32 slabs hold the value rounded once
+        q[0] = (PmT)v.x, q[1] = (PmT)v.y;
     }
 }
 
 }  // namespace
 
 hipError_t launch_relayout(const void* src, bool src_f32, long ld_row, long n_cols, long t_count,
-                           double* dst, long pitch, long t_dst0, hipStream_t st) {
+                           void* dst, bool dst_f32, long pitch, long t_dst0, hipStream_t st) {
     if (t_count <= 0 || n_cols <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n_cols + 63) / 64), (unsigned)((t_count + 63) / 64));
-    if (src_f32)
-        hipLaunchKernelGGL(k_relayout<float>, grid, dim3(256), 0, st, (const float*)src, ld_row, n_cols,
-                           t_count, dst, pitch, t_dst0);
-    else
-        hipLaunchKernelGGL(k_relayout<double>, grid, dim3(256), 0, st, (const double*)src, ld_row, n_cols,
-                           t_count, dst, pitch, t_dst0);
+#define TA_GO(S, Dt) \
+    hipLaunchKernelGGL((k_relayout<S, Dt>), grid, dim3(256), 0, st, (const S*)src, ld_row, n_cols, t_count, (Dt*)dst, pitch, t_dst0)
+    if (src_f32 && dst_f32) TA_GO(float, float);
+    else if (src_f32) TA_GO(float, double);
+    else if (dst_f32) TA_GO(double, float);
+    else TA_GO(double, double);
+#undef TA_GO
     return hipGetLastError();
 }
 
-hipError_t launch_unlayout(const double* pm, long pitch, long n_cols, long t_count, double* dst,
+hipError_t launch_unlayout(const void* pm, bool pm_f32, long pitch, long n_cols, long t_count, double* dst,
                            long ld_row, hipStream_t st) {
     if (t_count <= 0 || n_cols <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_unlayout, dim3(2048), dim3(256), 0, st, pm, pitch, n_cols, t_count, dst, ld_row);
+    if (pm_f32)
+        hipLaunchKernelGGL(k_unlayout<float>, dim3(2048), dim3(256), 0, st, (const float*)pm, pitch, n_cols, t_count,
+                           dst, ld_row);
+    else
+        hipLaunchKernelGGL(k_unlayout<double>, dim3(2048), dim3(256), 0, st, (const double*)pm, pitch, n_cols,
+                           t_count, dst, ld_row);
     return hipGetLastError();
 }
 
@@ -162,11 +174,15 @@ hipError_t launch_bp_transpose(const double* src, long src_ld, long n_atoms, lon
     return hipGetLastError();
 }
 
-hipError_t launch_synth(double* pm, long pitch, long n_cols, long T, unsigned long long seed,
+hipError_t launch_synth(void* pm, bool pm_f32, long pitch, long n_cols, long T, unsigned long long seed,
                         long col_offset, long n_cols_total, hipStream_t st) {
     if (T <= 0 || n_cols <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_synth, dim3(4096), dim3(256), 0, st, pm, pitch, n_cols, T, seed, col_offset,
-                       n_cols_total);
+    if (pm_f32)
+        hipLaunchKernelGGL(k_synth<float>, dim3(4096), dim3(256), 0, st, (float*)pm, pitch, n_cols, T, seed,
+                           col_offset, n_cols_total);
+    else
+        hipLaunchKernelGGL(k_synth<double>, dim3(4096), dim3(256), 0, st, (double*)pm, pitch, n_cols, T, seed,
+                           col_offset, n_cols_total);
     return hipGetLastError();
 }
 

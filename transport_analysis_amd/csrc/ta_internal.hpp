@@ -11,8 +11,9 @@
 namespace ta {
 
 // direct.hip
-// vel / pos: pair-major slabs (layout.hip) of `pitch` rows per pair
-hipError_t launch_direct(int mode, bool f32, int L, const double* vel, const double* pos,
+// vel / pos: pair-major slabs (layout.hip) of `pitch` rows per pair, float64 or (src_f32, with the
+// float32 arithmetic path only) float32 elements
+hipError_t launch_direct(int mode, bool f32, bool src_f32, int L, const void* vel, const void* pos,
                          const double* masses, long pitch, int T, long n_atoms, int D,
                          double scale, double* by_particle, long ld_bp, double* ts_partial, int nwg,
                          int nt, size_t lds_bytes, void* stage_buf, int gnt, hipStream_t st);
@@ -40,14 +41,15 @@ hipError_t launch_helfand_combine_bp(double* Ca, long n_atoms, int T, double fac
 hipError_t launch_widen_f32(const float* in, double* out, long n, hipStream_t st);
 
 // layout.hip: frame-major (n_frames, ld_row) float32/float64 rows -> pair-major slab rows
+// (dst_f32 / pm_f32: the slab holds float32 elements)
 hipError_t launch_relayout(const void* src, bool src_f32, long ld_row, long n_cols, long t_count,
-                           double* dst, long pitch, long t_dst0, hipStream_t st);
-hipError_t launch_unlayout(const double* pm, long pitch, long n_cols, long t_count, double* dst,
+                           void* dst, bool dst_f32, long pitch, long t_dst0, hipStream_t st);
+hipError_t launch_unlayout(const void* pm, bool pm_f32, long pitch, long n_cols, long t_count, double* dst,
                            long ld_row, hipStream_t st);
 // atom-major by-particle scratch -> (n_frames, ld_bp); partial: [ceil(n_atoms/64)][T] or NULL
 hipError_t launch_bp_transpose(const double* src, long src_ld, long n_atoms, long T, double* bp, long ld_bp,
                                double* partial, hipStream_t st);
-hipError_t launch_synth(double* pm, long pitch, long n_cols, long T, unsigned long long seed,
+hipError_t launch_synth(void* pm, bool pm_f32, long pitch, long n_cols, long T, unsigned long long seed,
                         long col_offset, long n_cols_total, hipStream_t st);
 
 // wfft.hip: FFT evaluation on pair-major slabs, padded length L = 2 R R0 512 (wfft.hpp)

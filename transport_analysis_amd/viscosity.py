@@ -112,6 +112,9 @@ class ViscosityHelfand(AnalysisBase):
             self._ctx = _lib.Context(self._device)
         self._ctx.set_option("direct_f32", int(self._float32))
         self._ctx.set_option("helfand_fft", int(self._fft))
+        # float32 path: the device slabs keep float32 staging as float32 (half the footprint; the
+        # kernels round the staged value to float32 anyway, so the results do not change)
+        self._ctx.set_option("stage_device_f32", int(self._float32))
         self._lo, self._hi = 0, self.n_particles
         if self._distributed:
             from .dist import shard_of_this_rank
