@@ -179,3 +179,18 @@ def test_c_oracle_step_kat():
     assert_almost_equal(ts, g("kat_vacf_poly_N5001_D3.npy"), decimal=3)
     _, ts = c_oracle.vacf_windowed(v)
     assert_almost_equal(ts, g("kat_vacf_poly_N5001_D3.npy"), decimal=4)
+
+
+def test_parallel_numpy_oracle_matches_one_core():
+    """oracle/parallel.py (bench.py's all-cores CPU line): blocks of atoms in child processes add
+    up to the one-process result on the same synthetic tensor."""
+    from oracle import numpy_oracle as orc
+    from oracle import parallel, synth
+
+    T, A, D = 300, 11, 3
+    lag, seconds, n = parallel.vacf_fft_all_cores(7, T, A * D + 5, A, D, n_workers=3)
+    v = synth.synthetic_block(7, T, A * D + 5, 0, A * D).reshape(T, A, D)
+    bp, _ = orc.vacf_fft(v)
+    assert n == 3 and seconds > 0
+    np.testing.assert_allclose(lag, bp.sum(axis=1), rtol=0, atol=1e-12 * float(np.max(np.abs(bp))) * A)
+    assert parallel.usable_cpus() >= 1

@@ -44,24 +44,48 @@ def main():
     # in KB and reports half of the bytes of a wide streaming read on gfx950
     # (MI355X_MICROARCH.md, HBM): 2 * FETCH_SIZE + WRITE_SIZE.  Keyed by the library's hash.
     if len(sys.argv) > 3:
-        key, kern = sys.argv[2], sys.argv[3]
-        pmc = res.get("pmc", {}).get(kern, {})
-        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-            import hashlib
+        import hashlib
 
-            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-            so = os.path.join(root, "transport_analysis_amd", "libta_hip.so")
-            sha = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
-            f = os.path.join(out, "hbm_traffic.json")
-            rec = {"so_sha16": sha, "entries": {}}
-            rec["entries"][key] = {
-                "hbm_bytes_per_launch": 2 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024,
-                "FETCH_SIZE_KB_raw": pmc["FETCH_SIZE"], "WRITE_SIZE_KB_raw": pmc["WRITE_SIZE"],
-                "TCC_EA0_RDREQ_sum": pmc.get("TCC_EA0_RDREQ_sum"), "kernel": kern,
-                "note": "2*FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate --pmc passes; L2 fabric-side "
-                        "counters (Infinity-Cache hits are counted)"}
+        key, kern = sys.argv[2], sys.argv[3]
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        so = os.path.join(root, "transport_analysis_amd", "libta_hip.so")
+        sha = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
+        f = os.path.join(out, "hbm_traffic.json")
+        rec = {"so_sha16": sha, "entries": {}}
+        # entries of earlier runs with the same library are kept (TA_TRAFFIC_MERGE = their file)
+        prev = os.environ.get("TA_TRAFFIC_MERGE", "")
+        if prev and os.path.exists(prev):
+            old = json.load(open(prev))
+            if old.get("so_sha16") == sha:
+                rec["entries"].update(old.get("entries", {}))
+        note = ("2*FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate --pmc passes; L2 fabric-side counters "
+                "(Infinity-Cache hits are counted)")
+        if "+" not in kern:
+            pmc = res.get("pmc", {}).get(kern, {})
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                rec["entries"][key] = {
+                    "hbm_bytes_per_launch": 2 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024,
+                    "FETCH_SIZE_KB_raw": pmc["FETCH_SIZE"], "WRITE_SIZE_KB_raw": pmc["WRITE_SIZE"],
+                    "TCC_EA0_RDREQ_sum": pmc.get("TCC_EA0_RDREQ_sum"), "kernel": kern, "note": note}
+        else:
+            # a path of several kernels per step: every dispatch of every named kernel, summed, per
+            # step of the profiled command (TA_PROFILE_STEPS = its steps + warm-ups)
+            n_steps = int(os.environ.get("TA_PROFILE_STEPS", "4"))
+            tot, parts = 0.0, {}
+            for sub, cname, mul in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
+                for fcsv in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(fcsv)):
+                        k = short(r["Kernel_Name"])
+                        if k in kern.split("+") and r["Counter_Name"] == cname:
+                            b = mul * float(r["Counter_Value"]) * 1024 / n_steps
+                            tot += b
+                            parts[k] = parts.get(k, 0.0) + b
+            if tot > 0:
+                rec["entries"][key] = {"hbm_bytes_per_launch": tot, "per_kernel_bytes_per_step": parts,
+                                       "kernel": kern, "steps_profiled": n_steps, "note": note + "; per step"}
+        if rec["entries"]:
             json.dump(rec, open(f, "w"), indent=1)
-            print("wrote", f, rec["entries"][key]["hbm_bytes_per_launch"])
+            print("wrote", f, {k: v["hbm_bytes_per_launch"] for k, v in rec["entries"].items()})
 
 
 if __name__ == "__main__":
