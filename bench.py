@@ -425,6 +425,7 @@ def other_configs(torch, dist, _lib, ctx, dev):
             hist = ctx.timing_history(steps)
             kms = statistics.median(m for _, m in hist)
             r = roofline_of(c, kms, hfft, f32)
+            r["traffic"] = recorded_traffic(f"{mode}_{T}x{A}x3" + ("_bp" if byp else ""))
             res.append({"workload": name, "ms_per_step": el / steps * 1e3, "steps": steps,
                         "value": T * A / (el / steps), "unit": "lag-points/s", "roofline": r})
             del c
