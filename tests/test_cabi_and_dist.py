@@ -40,12 +40,14 @@ def test_no_cpu_fallback():
 def test_plan_info():
     from transport_analysis_amd import _lib
 
-    # M = R0 * 512, R0 in {1, 2, 4, 5, 8, 10, 16, 20} (csrc/wfft.hpp)
+    # M = R0 * 512, R0 in {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20} (csrc/wfft.hpp)
     for T, M in ((1, 512), (16, 512), (17, 512), (500, 512), (512, 512), (513, 1024), (1000, 1024),
-                 (1025, 2048), (2049, 2560), (5001, 5120), (5121, 8192), (10000, 10240), (10240, 10240)):
+                 (1025, 1536), (1537, 2048), (2049, 2560), (2561, 3072), (3073, 4096), (5001, 5120),
+                 (5121, 6144), (6145, 8192), (10000, 10240), (10240, 10240)):
         assert _lib.fft_plan_info(T)["M"] == M
     # beyond one on-chip transform: outer radix R x on-chip M (csrc/wfft.hpp)
-    for T, M in ((10241, 16384), (16385, 20480), (20481, 32768), (40961, 65536), (163840, 163840)):
+    for T, M in ((10241, 12288), (12289, 16384), (16385, 20480), (20481, 24576), (24577, 32768),
+                 (40961, 49152), (163840, 163840)):
         info = _lib.fft_plan_info(T)
         assert info["M"] == M
     assert _lib.fft_plan_info(163841) is None  # handled by the direct correlator

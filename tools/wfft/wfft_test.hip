@@ -73,7 +73,15 @@ static int run(int R, int argc, char** argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int ncu = prop.multiProcessorCount, gran = 16 * R;
-    const int nwg = std::max<long>(gran, std::min<long>(ncu, 2 * R * n_pairs) / gran * gran);
+    int per_cu = 1;  // resident workgroups per compute unit, as the library sizes its grid
+    {
+        auto kern = k_wsplit_accum<P, false, false, false>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)P::kLds));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, P::NT, P::kLds) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+    }
+    const int nwg = std::max<long>(gran, std::min<long>((long)ncu * per_cu, 2 * R * n_pairs) / gran * gran);
     const int n_tuples = nwg / (2 * R);
     std::vector<cd> tw(wf_table_elems(R0, R));
     wf_fill_table(R0, R, tw.data());
@@ -138,7 +146,7 @@ static int run(int R, int argc, char** argv) {
         auto inv = [&](auto kern) {
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)P::kLds));
-            hipLaunchKernelGGL(kern, dim3(1), dim3(P::NT), P::kLds, 0, d_spec, T, 1L, d_tw, d_lag, 0L, R);
+            hipLaunchKernelGGL(kern, dim3(1), dim3(P::NT_INV), P::kLds, 0, d_spec, T, 1L, d_tw, d_lag, 0L, R);
         };
         if (R > 1) inv(k_winverse<P, true, 0>);
         else inv(k_winverse<P, false, 0>);
@@ -199,10 +207,13 @@ int main(int argc, char** argv) {
     switch (R0) {
         case 20: return run<20>(R, argc, argv);
         case 16: return run<16>(R, argc, argv);
+        case 12: return run<12>(R, argc, argv);
         case 10: return run<10>(R, argc, argv);
         case 8: return run<8>(R, argc, argv);
+        case 6: return run<6>(R, argc, argv);
         case 5: return run<5>(R, argc, argv);
         case 4: return run<4>(R, argc, argv);
+        case 3: return run<3>(R, argc, argv);
         case 2: return run<2>(R, argc, argv);
     }
     fprintf(stderr, "unsupported WF_R0\n");

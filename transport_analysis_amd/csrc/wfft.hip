@@ -10,7 +10,7 @@
 namespace ta {
 namespace {
 
-constexpr int kR0s[] = {1, 2, 4, 5, 8, 10, 16, 20};
+constexpr int kR0s[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20};
 constexpr int kOuter[] = {1, 2, 4, 8, 16};
 
 template <class K>
@@ -35,7 +35,7 @@ template <int R0>
 hipError_t launch_inverse_r0(int R, int nwg, hipStream_t st, const double* spec, int T, long n_items, const cd* tw,
                              double* out, long ld, int pf) {
     using P = WPlan<R0>;
-    constexpr int NSA = P::NS1;
+    constexpr int NSA = P::NS_INV;
     auto kern = R > 1    ? k_winverse<P, true, 0>
                 : pf <= 0 ? k_winverse<P, false, 0>
                 : pf == 1 ? k_winverse<P, false, 1>
@@ -43,7 +43,7 @@ hipError_t launch_inverse_r0(int R, int nwg, hipStream_t st, const double* spec,
                           : k_winverse<P, false, NSA>;
     hipError_t e = set_lds(kern, P::kLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, spec, T, n_items, tw, out, ld, R);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT_INV), P::kLds, st, spec, T, n_items, tw, out, ld, R);
     return hipGetLastError();
 }
 
@@ -127,10 +127,13 @@ int wfft_max_wg_per_cu(int R0) {
     switch (R0) {
         case 1: return 2;  // 64 KiB of LDS per 256-thread workgroup
         case 2: return max_wg_r0<2>();
+        case 3: return max_wg_r0<3>();
         case 4: return max_wg_r0<4>();
         case 5: return max_wg_r0<5>();
+        case 6: return max_wg_r0<6>();
         case 8: return max_wg_r0<8>();
         case 10: return max_wg_r0<10>();
+        case 12: return max_wg_r0<12>();
         case 16: return max_wg_r0<16>();
         case 20: return max_wg_r0<20>();
     }
@@ -162,10 +165,13 @@ hipError_t launch_wfft_forward(int R0, int R, bool by_particle, int nwg, hipStre
     if (R < 1 || nwg < 16 * R || nwg % (16 * R)) return hipErrorInvalidValue;
     switch (R0) {
         case 2: return launch_forward_r0<2>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 3: return launch_forward_r0<3>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 4: return launch_forward_r0<4>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 5: return launch_forward_r0<5>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 6: return launch_forward_r0<6>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 8: return launch_forward_r0<8>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 10: return launch_forward_r0<10>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 12: return launch_forward_r0<12>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 16: return launch_forward_r0<16>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 20: return launch_forward_r0<20>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
     }
@@ -178,10 +184,13 @@ hipError_t launch_wfft_inverse(int R0, int R, int nwg, hipStream_t st, const dou
     if (R < 1 || nwg < 1) return hipErrorInvalidValue;
     switch (R0) {
         case 2: return launch_inverse_r0<2>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 3: return launch_inverse_r0<3>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 4: return launch_inverse_r0<4>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 5: return launch_inverse_r0<5>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 6: return launch_inverse_r0<6>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 8: return launch_inverse_r0<8>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 10: return launch_inverse_r0<10>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 12: return launch_inverse_r0<12>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 16: return launch_inverse_r0<16>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 20: return launch_inverse_r0<20>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
     }

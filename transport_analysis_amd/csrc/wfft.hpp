@@ -12,7 +12,7 @@
 // descriptor's bounds check, which IS the zero padding.
 //
 // Transform.  The series is padded to L = 2 R M points, M = R0 * 512 the on-chip length
-// (R0 in {2, 4, 5, 8, 10, 16, 20}) and R the outer radix (1 up to 10240 frames, then 2, 4, 8, 16).
+// (R0 in {2, 3, 4, 5, 6, 8, 10, 12, 16, 20}) and R the outer radix (1 up to 10240 frames, then 2, 4, 8, 16).
 // Bin k = 2R s + c of the L-point transform is output s of an M-point transform ("pass" c < 2R):
 //     Z[2R s + c] = FFT_M(u_c)[s],   u_c[t] = W_L^{c t} sum_{jo < R} z[t + M jo] W_2R^{c jo},  t < M
 // (R = 1: pass A = even bins of the zero-padded series, pass B = odd bins).  A pass is
@@ -36,6 +36,10 @@
 
 namespace ta {
 
+#ifndef WF_NW_R0
+#define WF_NW_R0 0  // experiment: plan R0 = WF_NW_R0 runs with WF_NW_VAL waves per workgroup
+#define WF_NW_VAL 0
+#endif
 #ifndef WF_ABL
 #define WF_ABL 0  // timing ablations (wrong results): 1 no S2, 2 no S1 arithmetic, 3 no row loads,
                   // 4 no S2 arithmetic (LDS traffic only), 5 no S2 exchanges (arithmetic only)
@@ -50,8 +54,58 @@ __device__ __forceinline__ void static_for_range(F&& f) {
 
 typedef unsigned int wf_u32x4 __attribute__((ext_vector_type(4)));
 
-// ---- first-stage DFTs that fft_engine.hpp does not have: prime-factor 2x5 and 4x5 -----------
-// n = (5 n1 + N1 n2) mod N, k1 = k mod N1, k2 = k mod 5: X[k] = sum W_N1^{n1 k1} W_5^{n2 k2} x[n]
+// ---- first-stage DFTs that fft_engine.hpp does not have: radix 3 and the prime-factor
+// butterflies 2x3, 4x3, 2x5, 4x5 (no internal twiddles) --------------------------------------------
+// N = N1 N2 coprime: n = (N2 n1 + N1 n2) mod N, k1 = k mod N1, k2 = k mod N2:
+// X[k] = sum W_N1^{n1 k1} W_N2^{n2 k2} x[n]
+template <>
+struct Dft<3> {
+    static __device__ __forceinline__ void run(cd (&v)[3]) {
+        constexpr double kS3 = 0.86602540378443864676372317075294;  // sin(2 pi / 3)
+        const cd t = v[1] + v[2], d = v[1] - v[2];
+        const cd m = cd{v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y};
+        const cd e = cd{kS3 * d.y, -kS3 * d.x};  // -i sin(2 pi / 3) (v1 - v2)
+        v[0] = v[0] + t;
+        v[1] = m + e;
+        v[2] = m - e;
+    }
+};
+
+template <>
+struct Dft<6> {
+    static __device__ __forceinline__ void run(cd (&v)[6]) {
+        cd s[2][3];
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2) {
+            const cd a = v[(2 * j2) % 6], b = v[(3 + 2 * j2) % 6];
+            s[0][j2] = a + b;
+            s[1][j2] = a - b;
+        }
+        Dft<3>::run(s[0]);
+        Dft<3>::run(s[1]);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] = s[q % 2][q % 3];
+    }
+};
+
+template <>
+struct Dft<12> {
+    static __device__ __forceinline__ void run(cd (&v)[12]) {
+        cd s[4][3];
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2) {
+            cd t[4] = {v[(4 * j2) % 12], v[(3 + 4 * j2) % 12], v[(6 + 4 * j2) % 12], v[(9 + 4 * j2) % 12]};
+            Dft<4>::run(t);
+#pragma unroll
+            for (int k1 = 0; k1 < 4; ++k1) s[k1][j2] = t[k1];
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) Dft<3>::run(s[k1]);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) v[q] = s[q % 4][q % 3];
+    }
+};
+
 template <>
 struct Dft<10> {
     static __device__ __forceinline__ void run(cd (&v)[10]) {
@@ -116,10 +170,25 @@ template <int R0_>
 struct WPlan {
     static constexpr int R0 = R0_;
     static constexpr int N1 = 512;          // sub-series length = one wave's transform
-    static constexpr int NT = 512;          // threads: one first-stage butterfly each
-    static constexpr int NW = NT / 64;
+    // forward kernel: with fewer than 8 sub-series, 8 waves would mostly idle through S2 (and all
+    // land on the same SIMDs): small plans run in small workgroups, several per compute unit, and a
+    // thread runs K1 of the 512 first-stage butterflies.  Waves per workgroup by same-box A/B
+    // (tools/wfft, 24 GB of input): R0 = 2: 2 (9.3 ms against 18.9 ms with 8), R0 = 3: 2 (3.0 vs
+    // 3.6 ms with 3, 3.4 with 1), R0 = 4: 2 (3.78 vs 3.98 ms with 4), R0 = 5: 4 (10.4 vs 11.5 with 8,
+    // 12.5 with 5), R0 = 6: 4 (6.1 vs 6.7 with 6, 8.7 with 3); from R0 = 8 on 8 waves (R0 = 8 with 4:
+    // 8.3 vs 7.6 ms; R0 = 10 with 4 / 5: 10.8 / 14.3 vs 9.7; R0 = 12 with 4 / 6: 13.4 / 19.4 vs 11.8;
+    // R0 = 20 with 4: 11.6 vs 9.2).
+    static constexpr int NW = R0 == WF_NW_R0 ? WF_NW_VAL : R0 <= 4 ? 2 : R0 <= 6 ? 4 : 8;
+    static constexpr int NT = 64 * NW;
+    static constexpr int K1 = (N1 + NT - 1) / NT;
+    // (measured: trading the resident stage twiddles for a fourth wave per SIMD in the small plans
+    // costs 5-10 %: 1000 frames 9.96 vs 9.26 ms, 2000 frames 10.56 vs 9.62 ms per 24 GB)
+    static constexpr int kMinWavesPerSimd = 1;
+    static constexpr bool kTwResident = true;
     static constexpr int M = R0 * N1;
-    static constexpr int NS1 = (R0 + NW - 1) / NW;  // sub-series per wave: q = wave + 8 s
+    static constexpr int NS1 = (R0 + NW - 1) / NW;  // sub-series per wave: q = wave + NW s
+    // inverse kernel: 512 threads, one first-stage butterfly each
+    static constexpr int NT_INV = 512, NW_INV = 8, NS_INV = (R0 + 7) / 8;
     static constexpr size_t kLds = (size_t)M * sizeof(cd);
 };
 
@@ -299,7 +368,7 @@ __device__ __forceinline__ cd wf_cfma(cd acc, cd a, cd b) {  // acc + a b
 }
 
 template <class P, bool BYP = false, bool LONG = false, bool STAMP = false>
-__global__ void __launch_bounds__(P::NT)
+__global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
     k_wsplit_accum(const double* __restrict__ pm, long pitch, int T, long n_units,
                    const cd* __restrict__ tw2, double* __restrict__ accg, int D, int R_arg,
                    unsigned long long* __restrict__ stamps) {
@@ -307,7 +376,8 @@ __global__ void __launch_bounds__(P::NT)
     cd* lds = reinterpret_cast<cd*>(smem_raw);
     constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW, NS1 = P::NS1, M = P::M;
     const int R = LONG ? R_arg : 1, npass = 2 * R, L = npass * M;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    int lane = tid & 63;
     const int bi = blockIdx.x >> 3;
     const int pass = bi % npass;
     const long tuple = (blockIdx.x & 7) + 8 * (bi / npass), n_tuples = gridDim.x / npass;
@@ -344,42 +414,58 @@ __global__ void __launch_bounds__(P::NT)
                                                  live ? T * 16 : 0, 0x00020000);
     };
     // row u + 512 j + M jo of the unit (a single real column: that half of the row, imaginary part 0)
-    auto load_row = [&](__amdgpu_buffer_rsrc_t rs, int kd, unsigned row_off) {
-        if (!BYP || kd == 2) return wf_load(rs, (unsigned)tid * 16u, row_off * 16u);
+    auto load_row = [&](__amdgpu_buffer_rsrc_t rs, int kd, int u, unsigned row_off) {
+        if (!BYP || kd == 2) return wf_load(rs, (unsigned)u * 16u, row_off * 16u);
         return cd{__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                                 rs, (unsigned)tid * 16u + (unsigned)kd * 8u, row_off * 16u, 0)),
+                                                 rs, (unsigned)u * 16u + (unsigned)kd * 8u, row_off * 16u, 0)),
                   0.0};
     };
-    cd x[R0];
+    // thread tid runs the first-stage butterflies u = tid + NT k, k < K1 (u < 512)
+    constexpr int K1 = P::K1, NT = P::NT;
+    cd xx[K1][R0];
     auto issue_loads = [&](__amdgpu_buffer_rsrc_t rs, int kd) {
-        if (!BYP || kd == 2) {
 #pragma unroll
-            for (int j = 0; j < R0; ++j) x[j] = load_row(rs, 2, (unsigned)(N1 * j));
-        } else {
+        for (int k1 = 0; k1 < K1; ++k1) {
+            const int u = tid + NT * k1;  // rows past 512 j + 511 belong to the next j: never loaded
+            if (K1 * NT != N1 && u >= N1) continue;
+            if (!BYP || kd == 2) {
 #pragma unroll
-            for (int j = 0; j < R0; ++j) x[j] = load_row(rs, kd, (unsigned)(N1 * j));
+                for (int j = 0; j < R0; ++j) xx[k1][j] = load_row(rs, 2, u, (unsigned)(N1 * j));
+            } else {
+#pragma unroll
+                for (int j = 0; j < R0; ++j) xx[k1][j] = load_row(rs, kd, u, (unsigned)(N1 * j));
+            }
         }
     };
     int kind = 2, nkind = 2;
     __amdgpu_buffer_rsrc_t crs = unit_rsrc(tuple * grp, 0, &kind);
     issue_loads(crs, kind);
-    // the wave-local stage twiddles stay in registers for the whole launch (one pass's
-    // accumulators leave room for them: 14 fewer loads per wave and unit)
+    // the wave-local stage twiddles stay in registers for the whole launch where one pass's
+    // accumulators leave room for them (14 fewer loads per wave and unit); the small plans trade
+    // them for a fourth wave per SIMD and load them again before every S2
     cd twa[7], twb[7];
+    auto load_stage_tw = [&]() {
 #pragma unroll
-    for (int a = 0; a < 7; ++a) {
-        twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + a * 64) * 16u);
-        twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + (7 + a) * 64) * 16u);
-    }
+        for (int a = 0; a < 7; ++a) {
+            twa[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + a * 64) * 16u);
+            twb[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + (7 + a) * 64) * 16u);
+        }
+    };
+    if constexpr (P::kTwResident) load_stage_tw();
     int k = 0;  // unit of the atom (by-particle mode)
     for (long item = tuple * grp; item < n_units;) {
-        // ---- S1: radix-R0 butterfly u = tid over rows u + 512 j of u_c (jo = 0 requested during
-        // the previous S2); g = W_M^u, h = W_L^{c u}
+        // ---- S1: radix-R0 butterflies u = tid + NT k over rows u + 512 j of u_c (jo = 0 requested
+        // during the previous S2); g = W_M^u, h = W_L^{c u}
+#pragma unroll
+        for (int k1 = 0; k1 < K1; ++k1) {
+        const int u = tid + NT * k1;
+        if (K1 * NT != N1 && u >= N1) continue;
+        cd(&x)[R0] = xx[k1];
         cd g, g2, h;
         auto load_seeds = [&]() {
-            g = wf_load(twr, (unsigned)(tid * R) * 32u, 0u);
-            g2 = wf_load(twr, (unsigned)(tid * R) * 64u, 0u);
-            h = wf_load(twr, (unsigned)(tid * pass) * 16u, 0u);
+            g = wf_load(twr, (unsigned)(u * R) * 32u, 0u);
+            g2 = wf_load(twr, (unsigned)(u * R) * 64u, 0u);
+            h = wf_load(twr, (unsigned)(u * pass) * 16u, 0u);
         };
         if constexpr (!LONG) load_seeds();
 #if WF_ABL != 2
@@ -410,7 +496,7 @@ __global__ void __launch_bounds__(P::NT)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             if (j0 + i < R0)
-                                z[i] = load_row(crs, decltype(single)::value ? kind : 2, (unsigned)(N1 * (j0 + i) + M * jo));
+                                z[i] = load_row(crs, decltype(single)::value ? kind : 2, u, (unsigned)(N1 * (j0 + i) + M * jo));
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             if (j0 + i < R0) {
@@ -440,10 +526,10 @@ __global__ void __launch_bounds__(P::NT)
             cd te = pass ? h : cd{1.0, 0.0};
             cd to = pass ? cmul(h, g) : g;
             if (pass) x[0] = cmul(x[0], te);
-            lds[tid] = x[0];
+            lds[u] = x[0];
             if constexpr (R0 > 1) {
                 x[1] = cmul(x[1], to);
-                lds[N1 + tid] = x[1];
+                lds[N1 + u] = x[1];
             }
 #pragma unroll
             for (int q = 2; q < R0; ++q) {
@@ -454,12 +540,17 @@ __global__ void __launch_bounds__(P::NT)
                     te = cmul(te, g2);
                     x[q] = cmul(x[q], te);
                 }
-                lds[q * N1 + tid] = x[q];
+                lds[q * N1 + u] = x[q];
             }
+        }
+        }
+        if constexpr (!P::kTwResident) {
+            asm volatile("" : "+v"(lane));  // keeps the loads (and their registers) inside the loop
+            load_stage_tw();
         }
         WF_STAMP(0)
         __syncthreads();
-        // ---- S2: sub-series q = wave + 8 s, two or three in flight per wave; the next unit's
+        // ---- S2: sub-series q = wave + NW s, two or three in flight per wave; the next unit's
         // rows are requested after the last one (before the barrier)
         const bool last_of_item = !BYP || k == upa - 1;
         long nitem = item;
@@ -545,8 +636,8 @@ __global__ void __launch_bounds__(P::NT)
         }
     }
     if constexpr (STAMP) {
-        if (lane == 0 && (wave == 0 || wave == 4))
-            for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + (wave / 4) * 4 + i] = st_acc[i];
+        if (lane == 0 && (wave == 0 || wave == NW / 2))
+            for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + (wave ? 4 : 0) + i] = st_acc[i];
     }
 #undef WF_STAMP
 }
@@ -614,12 +705,12 @@ struct WfSubT {
 
 
 template <class P, bool LONG = false, int PF = 0>
-__global__ void __launch_bounds__(P::NT)
+__global__ void __launch_bounds__(P::NT_INV)
     k_winverse(const double* __restrict__ spec, int T, long n_items, const cd* __restrict__ tw2,
                double* __restrict__ out, long ld, int R_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
-    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW, M = P::M, NSA = P::NS1;
+    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW_INV, M = P::M, NSA = P::NS_INV;
     static_assert(!LONG || PF == 0, "the spectrum prefetch is for the single-transform case");
     const int R = LONG ? R_arg : 1, L = 2 * R * M;
     int tid = threadIdx.x, lane = tid & 63;
