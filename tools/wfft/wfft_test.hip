@@ -146,7 +146,7 @@ static int run(int R, int argc, char** argv) {
         auto inv = [&](auto kern) {
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)P::kLds));
-            hipLaunchKernelGGL(kern, dim3(1), dim3(P::NT_INV), P::kLds, 0, d_spec, T, 1L, d_tw, d_lag, 0L, R);
+            hipLaunchKernelGGL(kern, dim3(1), dim3(P::NT), P::kLds, 0, d_spec, T, 1L, d_tw, d_lag, 0L, R);
         };
         if (R > 1) inv(k_winverse<P, true, 0>);
         else inv(k_winverse<P, false, 0>);

@@ -35,7 +35,7 @@ template <int R0>
 hipError_t launch_inverse_r0(int R, int nwg, hipStream_t st, const double* spec, int T, long n_items, const cd* tw,
                              double* out, long ld, int pf) {
     using P = WPlan<R0>;
-    constexpr int NSA = P::NS_INV;
+    constexpr int NSA = P::NS1;
     auto kern = R > 1    ? k_winverse<P, true, 0>
                 : pf <= 0 ? k_winverse<P, false, 0>
                 : pf == 1 ? k_winverse<P, false, 1>
@@ -43,7 +43,7 @@ hipError_t launch_inverse_r0(int R, int nwg, hipStream_t st, const double* spec,
                           : k_winverse<P, false, NSA>;
     hipError_t e = set_lds(kern, P::kLds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT_INV), P::kLds, st, spec, T, n_items, tw, out, ld, R);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, spec, T, n_items, tw, out, ld, R);
     return hipGetLastError();
 }
 

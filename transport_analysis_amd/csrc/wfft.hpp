@@ -187,8 +187,6 @@ struct WPlan {
     static constexpr bool kTwResident = true;
     static constexpr int M = R0 * N1;
     static constexpr int NS1 = (R0 + NW - 1) / NW;  // sub-series per wave: q = wave + NW s
-    // inverse kernel: 512 threads, one first-stage butterfly each
-    static constexpr int NT_INV = 512, NW_INV = 8, NS_INV = (R0 + 7) / 8;
     static constexpr size_t kLds = (size_t)M * sizeof(cd);
 };
 
@@ -705,13 +703,16 @@ struct WfSubT {
 
 
 template <class P, bool LONG = false, int PF = 0>
-__global__ void __launch_bounds__(P::NT_INV)
+__global__ void __launch_bounds__(P::NT)
     k_winverse(const double* __restrict__ spec, int T, long n_items, const cd* __restrict__ tw2,
                double* __restrict__ out, long ld, int R_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
-    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW_INV, M = P::M, NSA = P::NS_INV;
+    // the forward kernel's workgroup: NW waves (one per sub-series up to 8), K1 first-stage
+    // butterflies u = tid + NT k per thread
+    constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW, NT = P::NT, K1 = P::K1, M = P::M, NSA = P::NS1;
     static_assert(!LONG || PF == 0, "the spectrum prefetch is for the single-transform case");
+    static_assert(PF <= NSA, "prefetch depth counts sub-series of a wave");
     const int R = LONG ? R_arg : 1, L = 2 * R * M;
     int tid = threadIdx.x, lane = tid & 63;
     const int wave = tid >> 6;
@@ -765,11 +766,15 @@ __global__ void __launch_bounds__(P::NT_INV)
                 for (int s = 0; s < PF; ++s) load_spec(item + gridDim.x, 0, s);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            cd x[R0];
-            const cd g = wf_load(twr, (unsigned)(tid * R) * 32u, 0u), g2 = wf_load(twr, (unsigned)(tid * R) * 64u, 0u);
+            cd xx[K1][R0];
 #pragma unroll
-            for (int q = 0; q < R0; ++q) x[q] = lds[q * N1 + tid];
-            {
+            for (int k1 = 0; k1 < K1; ++k1) {
+                const int u = tid + NT * k1;
+                if (K1 * NT != N1 && u >= N1) continue;
+                cd(&x)[R0] = xx[k1];
+                const cd g = wf_load(twr, (unsigned)(u * R) * 32u, 0u), g2 = wf_load(twr, (unsigned)(u * R) * 64u, 0u);
+#pragma unroll
+                for (int q = 0; q < R0; ++q) x[q] = lds[q * N1 + u];
                 cd te = cd{1.0, 0.0}, to = g;
                 if constexpr (R0 > 1) x[1] = cmul(x[1], to);
 #pragma unroll
@@ -782,56 +787,69 @@ __global__ void __launch_bounds__(P::NT_INV)
                         x[q] = cmul(x[q], te);
                     }
                 }
+                Dft<R0>::run(x);  // x[j'] = Q[u + 512 j']
             }
-            Dft<R0>::run(x);  // x[j'] = Q[tid + 512 j']
             __syncthreads();  // every thread has read its G values: LDS free for Q in natural order
 #pragma unroll
-            for (int j = 0; j < R0; ++j) lds[tid + N1 * j] = x[j];
+            for (int k1 = 0; k1 < K1; ++k1) {
+                const int u = tid + NT * k1;
+                if (K1 * NT != N1 && u >= N1) continue;
+#pragma unroll
+                for (int j = 0; j < R0; ++j) lds[u + N1 * j] = xx[k1][j];
+            }
             __syncthreads();
             double* o = out + item * ld;
-            // Q[M - n] for n = u + 512 j: element (512 - u) + 512 (R0 - 1 - j), u > 0
-            const int mu = tid == 0 ? 0 : N1 - tid;
-            if constexpr (!LONG) {
-                const cd h = wf_load(twr, (unsigned)tid * 16u, 0u);
 #pragma unroll
-                for (int j = 0; j < R0; ++j) {
-                    const int n = tid + N1 * j;
-                    const int jm = tid == 0 ? (R0 - j) % R0 : R0 - 1 - j;
-                    const cd qm = lds[mu + N1 * jm];
-                    // W_2M^n = W_2M^u * W_{2 R0}^j = cos - i sin (the second factor lane-uniform)
-                    const cd w = j == 0 ? h : cmul(h, tw_uniform(tw2, j * N1));
-                    const double ar = 0.5 * (x[j].x + qm.x), br = 0.5 * (x[j].y + qm.y), bi = -0.5 * (x[j].x - qm.x);
-                    const double lagv = ar + (w.x * br - w.y * bi);
-                    if (n < T) o[n] = lagv / (2.0 * (double)M * (double)(T - n));  // 2M(T-n) < 2^53: exact product
-                }
-            } else {
-                // passes c0 = 2 cp (real parts of the input) and c1 = c0 + 1 (imaginary parts):
-                // lag[n] += Re(W_L^{c0 n} Q_c0[n0]) + Re(W_L^{c1 n} Q_c1[n0]), n = n0 + M jo,
-                // W_L^{c n} = W_L^{c u} (per thread) x W_L^{c (512 j + M jo)} (lane-uniform, index mod L)
-                const int c0 = 2 * cp, c1 = c0 + 1;
-                const cd h0 = wf_load(twr, (unsigned)(tid * c0) * 16u, 0u), h1 = wf_load(twr, (unsigned)(tid * c1) * 16u, 0u);
-                const bool first = cp == 0, last = cp == R - 1;
-                int j0 = 0, j1 = 0;  // c (512 j) mod L
+            for (int k1 = 0; k1 < K1; ++k1) {
+                const int u = tid + NT * k1;
+                if (K1 * NT != N1 && u >= N1) continue;
+                cd(&x)[R0] = xx[k1];
+                // Q[M - n] for n = u + 512 j: element (512 - u) + 512 (R0 - 1 - j), u > 0
+                const int mu = u == 0 ? 0 : N1 - u;
+                if constexpr (!LONG) {
+                    const cd h = wf_load(twr, (unsigned)u * 16u, 0u);
 #pragma unroll
-                for (int j = 0; j < R0; ++j) {
-                    const int jm = tid == 0 ? (R0 - j) % R0 : R0 - 1 - j;
-                    const cd qm = lds[mu + N1 * jm];
-                    const cd qa = cd{0.5 * (x[j].x + qm.x), 0.5 * (x[j].y - qm.y)};
-                    const cd qb = cd{0.5 * (x[j].y + qm.y), -0.5 * (x[j].x - qm.x)};
-                    int i0 = j0, i1 = j1;
-                    for (int jo = 0; jo < R; ++jo) {
-                        const int n = tid + N1 * j + M * jo;
-                        const cd w0 = cmul(h0, tw_uniform(tw2, i0)), w1 = cmul(h1, tw_uniform(tw2, i1));
-                        double a = (w0.x * qa.x - w0.y * qa.y) + (w1.x * qb.x - w1.y * qb.y);
-                        if (n < T) {
-                            if (!first) a += o[n];
-                            o[n] = last ? a / ((double)L * (double)(T - n)) : a;  // L (T-n) < 2^53: exact product
-                        }
-                        i0 += c0 * M, i0 -= i0 >= L ? L : 0;
-                        i1 += c1 * M, i1 -= i1 >= L ? L : 0;
+                    for (int j = 0; j < R0; ++j) {
+                        const int n = u + N1 * j;
+                        const int jm = u == 0 ? (R0 - j) % R0 : R0 - 1 - j;
+                        const cd qm = lds[mu + N1 * jm];
+                        // W_2M^n = W_2M^u * W_{2 R0}^j = cos - i sin (the second factor lane-uniform)
+                        const cd w = j == 0 ? h : cmul(h, tw_uniform(tw2, j * N1));
+                        const double ar = 0.5 * (x[j].x + qm.x), br = 0.5 * (x[j].y + qm.y),
+                                     bi = -0.5 * (x[j].x - qm.x);
+                        const double lagv = ar + (w.x * br - w.y * bi);
+                        if (n < T) o[n] = lagv / (2.0 * (double)M * (double)(T - n));  // 2M(T-n) < 2^53: exact product
                     }
-                    j0 += c0 * N1, j0 -= j0 >= L ? L : 0;
-                    j1 += c1 * N1, j1 -= j1 >= L ? L : 0;
+                } else {
+                    // passes c0 = 2 cp (real parts of the input) and c1 = c0 + 1 (imaginary parts):
+                    // lag[n] += Re(W_L^{c0 n} Q_c0[n0]) + Re(W_L^{c1 n} Q_c1[n0]), n = n0 + M jo,
+                    // W_L^{c n} = W_L^{c u} (per thread) x W_L^{c (512 j + M jo)} (lane-uniform, index mod L)
+                    const int c0 = 2 * cp, c1 = c0 + 1;
+                    const cd h0 = wf_load(twr, (unsigned)(u * c0) * 16u, 0u),
+                             h1 = wf_load(twr, (unsigned)(u * c1) * 16u, 0u);
+                    const bool first = cp == 0, last = cp == R - 1;
+                    int j0 = 0, j1 = 0;  // c (512 j) mod L
+#pragma unroll
+                    for (int j = 0; j < R0; ++j) {
+                        const int jm = u == 0 ? (R0 - j) % R0 : R0 - 1 - j;
+                        const cd qm = lds[mu + N1 * jm];
+                        const cd qa = cd{0.5 * (x[j].x + qm.x), 0.5 * (x[j].y - qm.y)};
+                        const cd qb = cd{0.5 * (x[j].y + qm.y), -0.5 * (x[j].x - qm.x)};
+                        int i0 = j0, i1 = j1;
+                        for (int jo = 0; jo < R; ++jo) {
+                            const int n = u + N1 * j + M * jo;
+                            const cd w0 = cmul(h0, tw_uniform(tw2, i0)), w1 = cmul(h1, tw_uniform(tw2, i1));
+                            double a = (w0.x * qa.x - w0.y * qa.y) + (w1.x * qb.x - w1.y * qb.y);
+                            if (n < T) {
+                                if (!first) a += o[n];
+                                o[n] = last ? a / ((double)L * (double)(T - n)) : a;  // L (T-n) < 2^53: exact product
+                            }
+                            i0 += c0 * M, i0 -= i0 >= L ? L : 0;
+                            i1 += c1 * M, i1 -= i1 >= L ? L : 0;
+                        }
+                        j0 += c0 * N1, j0 -= j0 >= L ? L : 0;
+                        j1 += c1 * N1, j1 -= j1 >= L ? L : 0;
+                    }
                 }
             }
             __syncthreads();  // Q consumed before the next transform's sub-series overwrite the LDS
