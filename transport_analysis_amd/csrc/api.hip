@@ -545,7 +545,7 @@ int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_st
     // [outer radix R while the rows are read,] first-stage radix R0 (none up to 512 frames), then
     // one wave per 512-point sub-series (8 x 8 x 8)
     if (m_out) *m_out = (int64_t)R * R0 * 512;
-    if (n_threads) *n_threads = R0 < 8 ? 64 * R0 : 512;  // forward kernel: a wave per sub-series, up to 8
+    if (n_threads) *n_threads = wfft_threads(R0);
     if (n_stages) *n_stages = (R0 == 1 ? 3 : 4) + (R > 1 ? 1 : 0);
     return TA_OK;
 }

@@ -57,6 +57,7 @@ bool wfft_choose(long n_frames, int* R0, int* R);  // smallest R R0 512 >= n_fra
 size_t wfft_table_elems(int R0, int R);
 void wfft_fill_table(int R0, int R, cd* table);
 int wfft_max_wg_per_cu(int R0);
+int wfft_threads(int R0);
 // forward kernel (R0 > 1), nwg a multiple of 16 R: lag-sum mode n_units column pairs ->
 // accg [nwg / 2R][L] partial spectra; by-particle mode n_units atoms -> accg [n_units][L]
 hipError_t launch_wfft_forward(int R0, int R, bool by_particle, int nwg, hipStream_t st, const double* pm,

@@ -123,6 +123,23 @@ size_t wfft_table_elems(int R0, int R) { return wf_table_elems(R0, R); }
 
 void wfft_fill_table(int R0, int R, cd* a) { wf_fill_table(R0, R, a); }
 
+// threads per workgroup of the forward / inverse kernels of plan R0 (512-point kernels: a wave)
+int wfft_threads(int R0) {
+    switch (R0) {
+        case 2: return WPlan<2>::NT;
+        case 3: return WPlan<3>::NT;
+        case 4: return WPlan<4>::NT;
+        case 5: return WPlan<5>::NT;
+        case 6: return WPlan<6>::NT;
+        case 8: return WPlan<8>::NT;
+        case 10: return WPlan<10>::NT;
+        case 12: return WPlan<12>::NT;
+        case 16: return WPlan<16>::NT;
+        case 20: return WPlan<20>::NT;
+    }
+    return 64;
+}
+
 int wfft_max_wg_per_cu(int R0) {
     switch (R0) {
         case 1: return 2;  // 64 KiB of LDS per 256-thread workgroup
