@@ -944,3 +944,45 @@ def test_float32_device_slabs_staged_api(ctx):
         ctx.stage_free()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert float(np.max(np.abs(res[0][0]))) > 0
+
+
+@pytest.mark.parametrize("T,A", [(1000, 400000), (1500, 260000), (2500, 160000), (3000, 130000), (6000, 66000)])
+def test_vacf_fft_small_plans_at_scale(ctx, T, A):
+    """The plans below 8 sub-series (R0 = 2, 3, 5, 6: workgroups of 2 or 4 waves, several per
+    compute unit) and R0 = 12 on ~10 GB each: the lag sums of the whole block equal the sum over
+    its two halves (size-independent linearity), and selected lags equal plain torch reductions
+    over the staged tensor.  velocityautocorr.py:208-215."""
+    import torch
+
+    D = 3
+    st = torch.cuda.current_stream().cuda_stream
+    seed = 20250824 + 11
+
+    def lagsums(lo, hi, keep=False):
+        ctx.stage_alloc_device(T, hi - lo, D, n_slabs=1)
+        ctx.stage_synth(0, seed, lo * D, A * D, st)
+        out = torch.zeros(T, dtype=torch.float64, device="cuda")
+        ctx.vacf_fft_staged(out.data_ptr(), 0, 0, st)
+        fm = None
+        if keep:
+            fm = torch.empty((T, (hi - lo) * D), dtype=torch.float64, device="cuda")
+            ctx.stage_read_dev(0, fm.data_ptr(), (hi - lo) * D, st)
+        torch.cuda.synchronize()
+        return out, fm
+
+    try:
+        whole, fm = lagsums(0, A, keep=True)
+        scale = float((fm * fm).sum().item()) / T
+        for k in (0, 1, T // 3, T - 1):
+            ref = float((fm[: T - k] * fm[k:]).sum().item()) / (T - k)
+            assert abs(float(whole[k].item()) - ref) < TOL * scale, (k, float(whole[k].item()), ref)
+        del fm
+        torch.cuda.empty_cache()
+        cut = A // 2 + 1  # an odd number of columns in the first half
+        a, _ = lagsums(0, cut)
+        b, _ = lagsums(cut, A)
+        assert float((a + b - whole).abs().max().item()) < TOL * scale
+    finally:
+        ctx.stage_free()
+        ctx.trim()
+        torch.cuda.empty_cache()
