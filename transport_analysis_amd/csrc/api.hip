@@ -264,6 +264,10 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         const size_t spec_bytes = sizeof(double) * (size_t)L;
         int64_t CA = ctx->opt_bp_spec_atoms > 0 ? ctx->opt_bp_spec_atoms : (int64_t)(((size_t)5 << 29) / spec_bytes);
         CA = std::min<int64_t>(A, std::max<int64_t>(2, (CA + 1) / 2 * 2));
+        {  // equal blocks instead of full ones and a remainder
+            const int64_t n_blocks = (A + CA - 1) / CA;
+            CA = std::min<int64_t>(CA, ((A + n_blocks - 1) / n_blocks + 1) / 2 * 2);
+        }
         if ((rc = ensure(ctx, ctx->bp_spec, spec_bytes * (size_t)CA))) return rc;
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
         for (int64_t a0 = 0; a0 < A; a0 += CA) {
