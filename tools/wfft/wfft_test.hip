@@ -122,14 +122,14 @@ static int run(int R, int argc, char** argv) {
             fft_rec(a);
             for (size_t k = 0; k < a.size(); ++k) ref[k] += std::norm(a[k]);
         }
-        // spectrum layout [pass c][q][cc][lane]: bin k = 2R (q + R0 s) + c, s = (lane >> 3) + 8 (lane & 7) + 64 cc
+        // spectrum layout [pass c][q][cc / 2][lane][cc & 1]: bin k = 2R (q + R0 s) + c, s = (lane >> 3) + 8 (lane & 7) + 64 cc
         std::vector<double> spec((size_t)L, 0.0);
         long double mx = 0, err = 0;
         for (int c = 0; c < 2 * R; ++c)
             for (int q = 0; q < R0; ++q)
                 for (int cc = 0; cc < 8; ++cc)
                     for (int lane = 0; lane < 64; ++lane) {
-                        const size_t i = (size_t)c * M + (q * 8 + cc) * 64 + lane;
+                        const size_t i = (size_t)c * M + (((q * 4 + cc / 2) * 64 + lane) * 2 + (cc & 1));
                         long double got = 0;
                         for (int w = 0; w < n_tuples; ++w) got += acc[(size_t)w * L + i];
                         spec[i] = (double)got;

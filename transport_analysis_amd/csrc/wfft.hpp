@@ -338,13 +338,13 @@ __device__ __forceinline__ void wf_sub512_x3(cd* __restrict__ reg0, cd* __restri
 // 256 registers without spilling.
 //
 // Lag-sum mode (BYP = false): units are the n_units column pairs of the slab, tuple t takes pairs
-//   t, t + n_tuples, ...; at the end the pass's accumulators go to accg[t][c][q][cc][lane]
+//   t, t + n_tuples, ...; at the end the pass's accumulators go to accg[t][c][q][cc / 2][lane][cc & 1]
 //   (a row of L doubles per tuple, summed over tuples afterwards).
 // By-particle mode (BYP = true): units are the atoms' column units (wf_unit_of); a tuple takes
 //   whole atoms (pairs of adjacent atoms when the number of columns per atom is odd), and after
 //   an atom's last unit the pass's accumulators -- the atom's power spectrum in this pass -- go
-//   to accg[atom][c][q][cc][lane] and start again from zero.
-// Either way a spectrum is L doubles in the order k_winverse reads them back in.
+//   to accg[atom][c][...] in the same order and start again from zero.
+// Either way a spectrum is L doubles, [pass][q][cc / 2][lane][cc & 1], as k_winverse reads them back.
 __device__ __forceinline__ void wf_unit_of(long atom, int k, int D, long* pair, int* kind) {
     // kind 2 = both columns of the pair (complex series), 0 / 1 = only that half (real series)
     const long c0 = atom * D;
@@ -451,6 +451,7 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
     };
     if constexpr (P::kTwResident) load_stage_tw();
     int k = 0;  // unit of the atom (by-particle mode)
+    bool zero_pending = false;
     for (long item = tuple * grp; item < n_units;) {
         // ---- S1: radix-R0 butterflies u = tid + NT k over rows u + 512 j of u_c (jo = 0 requested
         // during the previous S2); g = W_M^u, h = W_L^{c u}
@@ -548,6 +549,13 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
         }
         WF_STAMP(0)
         __syncthreads();
+        if (BYP && zero_pending) {
+#pragma unroll
+            for (int s = 0; s < NS1; ++s)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[s][c] = 0.0;
+            zero_pending = false;
+        }
         // ---- S2: sub-series q = wave + NW s, two or three in flight per wave; the next unit's
         // rows are requested after the last one (before the barrier)
         const bool last_of_item = !BYP || k == upa - 1;
@@ -586,7 +594,7 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
             });
         }
         const int wv = __builtin_amdgcn_readfirstlane(wave);
-        auto store_acc = [&](long row) {  // accg[row][pass][q][cc][lane]
+        auto store_acc = [&](long row) {  // accg[row][pass][q][cc / 2][lane][cc & 1]
             const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
                 accg + (row * npass + pass) * (long)M, 0, M * 8, 0x00020000);
 #pragma unroll
@@ -594,16 +602,23 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                 const int q = wv + NW * s;
                 if (NW * s + NW - 1 < R0 || q < R0) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wf_u32x2, acc[s][c]), sr,
-                                                              (unsigned)lane * 8u, (unsigned)((q * 8 + c) * 64) * 8u, 0);
-                        acc[s][c] = 0.0;
+                    for (int c2 = 0; c2 < 4; ++c2) {
+                        // 16 bytes per lane (cc = 2 c2, 2 c2 + 1): half the store instructions here and half
+                        // the load instructions in k_winverse (by-particle step 23.6 -> 23.0 ms)
+                        const cd two{acc[s][2 * c2], acc[s][2 * c2 + 1]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wf_u32x4, two), sr, (unsigned)lane * 16u,
+                                                               (unsigned)((q * 4 + c2) * 64) * 16u, 0);
                     }
                 }
             }
         };
         if constexpr (BYP) {
-            if (last_of_item) store_acc(item);  // the atom's power spectrum in this pass, then from zero
+            // the atom's power spectrum in this pass; the accumulators restart from zero before the
+            // next unit's S2
+            if (last_of_item) {
+                store_acc(item);
+                zero_pending = true;
+            }
         } else {
             if (nitem >= n_units) store_acc(tuple);
         }
@@ -626,9 +641,9 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                 const int q = wv + NW * s;
                 if (q < R0) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wf_u32x2, 0.0), sr, (unsigned)lane * 8u,
-                                                              (unsigned)((q * 8 + c) * 64) * 8u, 0);
+                    for (int c2 = 0; c2 < 4; ++c2)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wf_u32x4, cd{0.0, 0.0}), sr,
+                                                               (unsigned)lane * 16u, (unsigned)((q * 4 + c2) * 64) * 16u, 0);
                 }
             }
         }
@@ -729,11 +744,11 @@ __global__ void __launch_bounds__(P::NT)
             const_cast<double*>(spec + (live ? item : 0) * (long)L + (long)(2 * cp) * M), 0, live ? 2 * M * 8 : 0,
             0x00020000);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            v[s][c].x = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                                       sr, (unsigned)lane * 8u, (unsigned)((q * 8 + c) * 64) * 8u, 0));
-            v[s][c].y = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                                       sr, (unsigned)lane * 8u, (unsigned)(M + (q * 8 + c) * 64) * 8u, 0));
+        for (int c2 = 0; c2 < 4; ++c2) {  // 16 bytes per lane and load: elements cc = 2 c2, 2 c2 + 1 of a pass
+            const cd a = wf_load(sr, (unsigned)lane * 16u, (unsigned)((q * 4 + c2) * 64) * 16u);
+            const cd b = wf_load(sr, (unsigned)lane * 16u, (unsigned)(M / 2 + (q * 4 + c2) * 64) * 16u);
+            v[s][2 * c2] = cd{a.x, b.x};
+            v[s][2 * c2 + 1] = cd{a.y, b.y};
         }
     };
 #pragma unroll
