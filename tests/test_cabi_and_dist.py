@@ -46,8 +46,10 @@ def test_plan_info():
                  (5121, 6144), (6145, 8192), (10000, 10240), (10240, 10240)):
         assert _lib.fft_plan_info(T)["M"] == M
     # beyond one on-chip transform: outer radix R x on-chip M (csrc/wfft.hpp)
-    for T, M in ((10241, 12288), (12289, 16384), (16385, 20480), (20481, 24576), (24577, 32768),
-                 (40961, 49152), (163840, 163840)):
+    # (outer radix 2, 3, 4, 5, 8, 16 in front of the plans R0 = 12, 16, 20; smallest M (1 + 0.15 R))
+    for T, M in ((10241, 12288), (12289, 16384), (16385, 20480), (20481, 24576), (24577, 30720),
+                 (30000, 30720), (30721, 32768), (40961, 51200), (50000, 51200), (51201, 65536),
+                 (81921, 98304), (100000, 131072), (163840, 163840)):
         info = _lib.fft_plan_info(T)
         assert info["M"] == M
     assert _lib.fft_plan_info(163841) is None  # handled by the direct correlator

@@ -12,7 +12,7 @@
 // descriptor's bounds check, which IS the zero padding.
 //
 // Transform.  The series is padded to L = 2 R M points, M = R0 * 512 the on-chip length
-// (R0 in {2, 3, 4, 5, 6, 8, 10, 12, 16, 20}) and R the outer radix (1 up to 10240 frames, then 2, 4, 8, 16).
+// (R0 in {2, 3, 4, 5, 6, 8, 10, 12, 16, 20}) and R the outer radix (1 up to 10240 frames, then 2, 3, 4, 5, 8, 16).
 // Bin k = 2R s + c of the L-point transform is output s of an M-point transform ("pass" c < 2R):
 //     Z[2R s + c] = FFT_M(u_c)[s],   u_c[t] = W_L^{c t} sum_{jo < R} z[t + M jo] W_2R^{c jo},  t < M
 // (R = 1: pass A = even bins of the zero-padded series, pass B = odd bins).  A pass is
