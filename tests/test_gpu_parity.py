@@ -986,3 +986,25 @@ def test_vacf_fft_small_plans_at_scale(ctx, T, A):
         ctx.stage_free()
         ctx.trim()
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("T,A,D", [(1000, 9, 3), (2500, 10, 2), (6000, 9, 3), (10000, 8, 1)])
+def test_vacf_by_particle_prefetch_depths(ctx, T, A, D):
+    """Every spectrum-prefetch depth of the inverse kernel ("bp_prefetch" 0..3; plans with 1, 2 and 3
+    sub-series per wave) gives the same per-particle array bit for bit: the depth only moves
+    loads."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(T, A, D, seed=5000 + T)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
+    got = []
+    try:
+        for pf in (0, 1, 2, 3):
+            ctx.set_option("bp_prefetch", pf)
+            got.append(run_vacf(ctx, v, True, True))
+    finally:
+        ctx.set_option("bp_prefetch", 2)
+    for ts, bp in got:
+        assert np.array_equal(bp, got[0][1]) and np.array_equal(ts, got[0][0])
+    assert scale_rel_err(got[0][1], want_bp) < TOL
+    assert scale_rel_err(got[0][0], want_ts) < TOL
