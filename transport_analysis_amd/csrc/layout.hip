@@ -15,6 +15,8 @@
 // stands.  The transposition runs on the committed chunk while the next chunk crosses PCIe.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "ta_internal.hpp"
 
 namespace ta {
@@ -74,24 +76,53 @@ __global__ void __launch_bounds__(256)
 // (velocityautocorr.py:145-147).  64 x 64 tiles through LDS, both sides coalesced; with
 // `partial` the tile also adds its 64 atoms per lag: partial[tile_a][lag] (the mean over atoms,
 // velocityautocorr.py:214, summed over tiles in a fixed order afterwards).
+template <bool WIDE>
 __global__ void __launch_bounds__(256)
     k_bp_transpose(const double* __restrict__ src, long src_ld, long n_atoms, long T,
                    double* __restrict__ bp, long ld_bp, double* __restrict__ partial) {
     __shared__ double tile[64][65];
     const int tid = threadIdx.x;
     const long a0 = (long)blockIdx.x * 64, t0 = (long)blockIdx.y * 64;
+    if constexpr (WIDE) {
+        // 16 bytes per lane on both sides (src_ld, ld_bp even, bases 16-byte aligned): a row of 64
+        // doubles is read / written by 32 lanes
+        const int r = tid >> 5, c2 = tid & 31;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int a = i * 4 + (tid >> 6), t = tid & 63;
-        double v = 0.0;
-        if (a0 + a < n_atoms && t0 + t < T) v = src[(a0 + a) * src_ld + t0 + t];
-        tile[a][t] = v;
-    }
-    __syncthreads();
+        for (int i = 0; i < 8; ++i) {
+            const int a = i * 8 + r, t = 2 * c2;
+            double2 v = double2{0.0, 0.0};
+            if (a0 + a < n_atoms) {
+                const double* p = src + (a0 + a) * src_ld + t0 + t;
+                if (t0 + t + 1 < T) v = *reinterpret_cast<const double2*>(p);
+                else if (t0 + t < T) v.x = p[0];
+            }
+            tile[a][t] = v.x;
+            tile[a][t + 1] = v.y;
+        }
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int t = i * 4 + (tid >> 6), a = tid & 63;
-        if (a0 + a < n_atoms && t0 + t < T) bp[(t0 + t) * ld_bp + a0 + a] = tile[a][t];
+        for (int i = 0; i < 8; ++i) {
+            const int t = i * 8 + r, a = 2 * c2;
+            if (t0 + t < T) {
+                double* p = bp + (t0 + t) * ld_bp + a0 + a;
+                if (a0 + a + 1 < n_atoms) *reinterpret_cast<double2*>(p) = double2{tile[a][t], tile[a + 1][t]};
+                else if (a0 + a < n_atoms) p[0] = tile[a][t];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int a = i * 4 + (tid >> 6), t = tid & 63;
+            double v = 0.0;
+            if (a0 + a < n_atoms && t0 + t < T) v = src[(a0 + a) * src_ld + t0 + t];
+            tile[a][t] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = i * 4 + (tid >> 6), a = tid & 63;
+            if (a0 + a < n_atoms && t0 + t < T) bp[(t0 + t) * ld_bp + a0 + a] = tile[a][t];
+        }
     }
     if (partial && tid < 64 && t0 + tid < T) {
         double s = 0.0;
@@ -169,8 +200,12 @@ hipError_t launch_unlayout(const void* pm, bool pm_f32, long pitch, long n_cols,
 hipError_t launch_bp_transpose(const double* src, long src_ld, long n_atoms, long T, double* bp, long ld_bp,
                                double* partial, hipStream_t st) {
     if (T <= 0 || n_atoms <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_bp_transpose, dim3((unsigned)((n_atoms + 63) / 64), (unsigned)((T + 63) / 64)), dim3(256),
-                       0, st, src, src_ld, n_atoms, T, bp, ld_bp, partial);
+    const dim3 grid((unsigned)((n_atoms + 63) / 64), (unsigned)((T + 63) / 64));
+    const bool wide = src_ld % 2 == 0 && ld_bp % 2 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)bp & 15) == 0;
+    if (wide)
+        hipLaunchKernelGGL(k_bp_transpose<true>, grid, dim3(256), 0, st, src, src_ld, n_atoms, T, bp, ld_bp, partial);
+    else
+        hipLaunchKernelGGL(k_bp_transpose<false>, grid, dim3(256), 0, st, src, src_ld, n_atoms, T, bp, ld_bp, partial);
     return hipGetLastError();
 }
 
