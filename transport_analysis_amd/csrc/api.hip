@@ -307,7 +307,6 @@ int helfand_impl(ta_ctx* ctx, const double* pm_vel, const double* pm_pos, const 
         double* Q = Qpart + (size_t)n_parts * T;
         double* S2 = Q + T;
         double* C = S2 + T;
-        TA_HIP_TRY(ctx, hipMemsetAsync(Qpart, 0, sizeof(double) * (size_t)n_parts * T, st));
         TA_HIP_TRY(ctx, launch_helfand_product(pm_vel, pm_pos, d_masses, pitch, T, n_cols, D, P, Qpart, n_parts, st));
         TA_HIP_TRY(ctx, launch_sum_partials(Qpart, n_parts, T, Q, st));
         if ((rc = fft_impl(ctx, P, pitch, T, A, D, S2, nullptr, 0, st))) return rc;

@@ -26,7 +26,7 @@ hipError_t launch_row_sums(const double* bp, long n_rows, long n_cols, long ld, 
 hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,
                                hipStream_t st);
 // helfand_fft.hip: optional FFT evaluation of the Helfand lag sums
-// pair-major slabs in, product slab P out in the same layout; Qpart [n_parts][T] zeroed by caller
+// pair-major slabs in, product slab P out in the same layout; Qpart [n_parts][T] written in full
 hipError_t launch_helfand_product(const double* vel, const double* pos, const double* masses,
                                   long pitch, long T, long n_cols, int D, double* P, double* Qpart,
                                   int n_parts, hipStream_t st);
