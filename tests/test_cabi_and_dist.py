@@ -40,10 +40,11 @@ def test_no_cpu_fallback():
 def test_plan_info():
     from transport_analysis_amd import _lib
 
-    # M = R0 * 512, R0 in {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20} (csrc/wfft.hpp)
+    # M = R0 * 512, R0 in {1..10, 12, 14, 16, 18, 20} (csrc/wfft.hpp)
     for T, M in ((1, 512), (16, 512), (17, 512), (500, 512), (512, 512), (513, 1024), (1000, 1024),
-                 (1025, 1536), (1537, 2048), (2049, 2560), (2561, 3072), (3073, 4096), (5001, 5120),
-                 (5121, 6144), (6145, 8192), (10000, 10240), (10240, 10240)):
+                 (1025, 1536), (1537, 2048), (2049, 2560), (2561, 3072), (3073, 3584), (3585, 4096),
+                 (4097, 4608), (5001, 5120), (5121, 6144), (6145, 7168), (7169, 8192), (8193, 9216),
+                 (10000, 10240), (10240, 10240)):
         assert _lib.fft_plan_info(T)["M"] == M
     # beyond one on-chip transform: outer radix R x on-chip M (csrc/wfft.hpp)
     # (outer radix 2, 3, 4, 5, 8, 16 in front of the plans R0 = 12, 16, 20; smallest M (1 + 0.15 R))

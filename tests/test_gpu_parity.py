@@ -104,8 +104,9 @@ def test_vacf_n10_notebook(ctx):
 SHAPES = [(1, 1, 1), (2, 3, 3), (5, 2, 2), (16, 7, 3), (17, 4, 1), (33, 9, 2), (100, 40, 3),
           (129, 3, 3), (257, 33, 3), (640, 11, 2), (641, 5, 3), (1000, 37, 3), (1025, 6, 1),
           (2049, 3, 3), (2561, 4, 2), (4097, 2, 3), (5121, 2, 1), (10000, 3, 3), (10240, 2, 2),
-          # the remaining plan lengths: M = 32, 64, 80, 256, 512, 2048
-          (30, 5, 3), (64, 3, 2), (77, 4, 3), (200, 6, 1), (400, 5, 3), (2000, 3, 3)]
+          (30, 5, 3), (64, 3, 2), (77, 4, 3), (200, 6, 1), (400, 5, 3), (2000, 3, 3),
+          # first-stage radices 7, 9, 14, 18 (odd prime-power butterflies)
+          (3500, 5, 3), (4600, 3, 2), (7000, 4, 3), (9100, 3, 1)]
 
 
 @pytest.mark.parametrize("T,A,D", SHAPES)
@@ -758,7 +759,8 @@ def test_helfand_config4_full_per_gpu_share(ctx):
 
 @pytest.mark.parametrize("T,A,D", [(600, 19, 1), (1000, 37, 3), (1030, 24, 2), (2100, 21, 3), (2560, 18, 1),
                                    (3000, 17, 3), (4200, 16, 2), (6000, 13, 3), (8192, 12, 1), (10000, 11, 3),
-                                   (12000, 9, 3), (20000, 11, 1), (20480, 8, 2), (33000, 5, 3), (50000, 4, 1)])
+                                   (12000, 9, 3), (20000, 11, 1), (20480, 8, 2), (33000, 5, 3), (50000, 4, 1),
+                                   (3300, 14, 3), (4500, 12, 2), (6500, 11, 3), (9000, 10, 1)])
 @pytest.mark.parametrize("spec_atoms", [0, 6])
 def test_vacf_by_particle_blocks_of_atoms(ctx, T, A, D, spec_atoms):
     """The by-particle FFT evaluation (forward kernel leaving per-atom power spectra, inverse

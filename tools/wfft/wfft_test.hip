@@ -206,10 +206,14 @@ int main(int argc, char** argv) {
     const int R = getenv("WF_R") ? atoi(getenv("WF_R")) : 1;
     switch (R0) {
         case 20: return run<20>(R, argc, argv);
+        case 18: return run<18>(R, argc, argv);
         case 16: return run<16>(R, argc, argv);
+        case 14: return run<14>(R, argc, argv);
         case 12: return run<12>(R, argc, argv);
         case 10: return run<10>(R, argc, argv);
+        case 9: return run<9>(R, argc, argv);
         case 8: return run<8>(R, argc, argv);
+        case 7: return run<7>(R, argc, argv);
         case 6: return run<6>(R, argc, argv);
         case 5: return run<5>(R, argc, argv);
         case 4: return run<4>(R, argc, argv);

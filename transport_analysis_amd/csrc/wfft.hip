@@ -10,7 +10,7 @@
 namespace ta {
 namespace {
 
-constexpr int kR0s[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20};
+constexpr int kR0s[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20};
 constexpr int kOuter[] = {1, 2, 3, 4, 5, 8, 16};
 
 template <class K>
@@ -141,10 +141,14 @@ int wfft_threads(int R0) {
         case 4: return WPlan<4>::NT;
         case 5: return WPlan<5>::NT;
         case 6: return WPlan<6>::NT;
+        case 7: return WPlan<7>::NT;
         case 8: return WPlan<8>::NT;
+        case 9: return WPlan<9>::NT;
         case 10: return WPlan<10>::NT;
         case 12: return WPlan<12>::NT;
+        case 14: return WPlan<14>::NT;
         case 16: return WPlan<16>::NT;
+        case 18: return WPlan<18>::NT;
         case 20: return WPlan<20>::NT;
     }
     return 64;
@@ -158,10 +162,14 @@ int wfft_max_wg_per_cu(int R0) {
         case 4: return max_wg_r0<4>();
         case 5: return max_wg_r0<5>();
         case 6: return max_wg_r0<6>();
+        case 7: return max_wg_r0<7>();
         case 8: return max_wg_r0<8>();
+        case 9: return max_wg_r0<9>();
         case 10: return max_wg_r0<10>();
         case 12: return max_wg_r0<12>();
+        case 14: return max_wg_r0<14>();
         case 16: return max_wg_r0<16>();
+        case 18: return max_wg_r0<18>();
         case 20: return max_wg_r0<20>();
     }
     return 1;
@@ -196,10 +204,14 @@ hipError_t launch_wfft_forward(int R0, int R, bool by_particle, int nwg, hipStre
         case 4: return launch_forward_r0<4>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 5: return launch_forward_r0<5>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 6: return launch_forward_r0<6>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 7: return launch_forward_r0<7>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 8: return launch_forward_r0<8>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 9: return launch_forward_r0<9>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 10: return launch_forward_r0<10>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 12: return launch_forward_r0<12>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 14: return launch_forward_r0<14>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 16: return launch_forward_r0<16>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 18: return launch_forward_r0<18>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 20: return launch_forward_r0<20>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
     }
     return hipErrorInvalidValue;
@@ -215,10 +227,14 @@ hipError_t launch_wfft_inverse(int R0, int R, int nwg, hipStream_t st, const dou
         case 4: return launch_inverse_r0<4>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 5: return launch_inverse_r0<5>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 6: return launch_inverse_r0<6>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 7: return launch_inverse_r0<7>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 8: return launch_inverse_r0<8>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 9: return launch_inverse_r0<9>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 10: return launch_inverse_r0<10>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 12: return launch_inverse_r0<12>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 14: return launch_inverse_r0<14>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 16: return launch_inverse_r0<16>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
+        case 18: return launch_inverse_r0<18>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
         case 20: return launch_inverse_r0<20>(R, nwg, st, spec, T, n_items, tw, out, ld, prefetch);
     }
     return hipErrorInvalidValue;

@@ -12,7 +12,7 @@
 // descriptor's bounds check, which IS the zero padding.
 //
 // Transform.  The series is padded to L = 2 R M points, M = R0 * 512 the on-chip length
-// (R0 in {2, 3, 4, 5, 6, 8, 10, 12, 16, 20}) and R the outer radix (1 up to 10240 frames, then 2, 3, 4, 5, 8, 16).
+// (R0 in {2, ..., 10, 12, 14, 16, 18, 20}) and R the outer radix (1 up to 10240 frames, then 2, 3, 4, 5, 8, 16).
 // Bin k = 2R s + c of the L-point transform is output s of an M-point transform ("pass" c < 2R):
 //     Z[2R s + c] = FFT_M(u_c)[s],   u_c[t] = W_L^{c t} sum_{jo < R} z[t + M jo] W_2R^{c jo},  t < M
 // (R = 1: pass A = even bins of the zero-padded series, pass B = odd bins).  A pass is
@@ -69,6 +69,88 @@ struct Dft<3> {
         v[1] = m + e;
         v[2] = m - e;
     }
+};
+
+// odd N by its conjugate-symmetric pairs: with s_j = x_j + x_{N-j}, d_j = x_j - x_{N-j} (j <= N/2)
+// X_k, X_{N-k} = x_0 + sum_j cos(2 pi j k / N) s_j  -/+  i sum_j sin(2 pi j k / N) d_j
+template <int N>
+struct DftOddTables;
+template <>
+struct DftOddTables<7> {
+    static constexpr double c[3] = {0.62348980185873353053, -0.22252093395631440429, -0.90096886790241912624};
+    static constexpr double s[3] = {0.78183148246802980871, 0.97492791218182360702, 0.43388373911755812048};
+};
+template <>
+struct DftOddTables<9> {
+    static constexpr double c[4] = {0.76604444311897803520, 0.17364817766693034885, -0.5, -0.93969262078590838405};
+    static constexpr double s[4] = {0.64278760968653932632, 0.98480775301220805937, 0.86602540378443864676,
+                                    0.34202014332566873304};
+};
+template <int N>
+__device__ __forceinline__ void dft_odd(cd (&v)[N]) {
+    constexpr int H = N / 2;
+    using Tb = DftOddTables<N>;
+    cd sp[H], dm[H];
+#pragma unroll
+    for (int j = 1; j <= H; ++j) {
+        sp[j - 1] = v[j] + v[N - j];
+        dm[j - 1] = v[j] - v[N - j];
+    }
+    const cd x0 = v[0];
+    cd sum = x0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) sum = sum + sp[j];
+    v[0] = sum;
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
+        double rx = x0.x, ry = x0.y, ix = 0.0, iy = 0.0;
+#pragma unroll
+        for (int j = 1; j <= H; ++j) {
+            const int m = (j * k) % N;                      // cos / sin of 2 pi m / N by its mirror m <= N/2
+            const double cm = m == 0 ? 1.0 : Tb::c[(m <= H ? m : N - m) - 1];
+            const double sm = m == 0 ? 0.0 : m <= H ? Tb::s[m - 1] : -Tb::s[N - m - 1];
+            rx = fma(cm, sp[j - 1].x, rx);
+            ry = fma(cm, sp[j - 1].y, ry);
+            ix = fma(sm, dm[j - 1].x, ix);
+            iy = fma(sm, dm[j - 1].y, iy);
+        }
+        // -i (ix + i iy) = iy - i ix
+        v[k] = cd{rx + iy, ry - ix};
+        v[N - k] = cd{rx - iy, ry + ix};
+    }
+}
+template <>
+struct Dft<7> {
+    static __device__ __forceinline__ void run(cd (&v)[7]) { dft_odd<7>(v); }
+};
+template <>
+struct Dft<9> {
+    static __device__ __forceinline__ void run(cd (&v)[9]) { dft_odd<9>(v); }
+};
+
+// 2 x N2 prime-factor butterflies for odd N2 (as Dft<10>)
+template <int N2>
+__device__ __forceinline__ void dft_2x(cd (&v)[2 * N2]) {
+    constexpr int N = 2 * N2;
+    cd s[2][N2];
+#pragma unroll
+    for (int j2 = 0; j2 < N2; ++j2) {
+        const cd a = v[(2 * j2) % N], b = v[(N2 + 2 * j2) % N];
+        s[0][j2] = a + b;
+        s[1][j2] = a - b;
+    }
+    Dft<N2>::run(s[0]);
+    Dft<N2>::run(s[1]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = s[q % 2][q % N2];
+}
+template <>
+struct Dft<14> {
+    static __device__ __forceinline__ void run(cd (&v)[14]) { dft_2x<7>(v); }
+};
+template <>
+struct Dft<18> {
+    static __device__ __forceinline__ void run(cd (&v)[18]) { dft_2x<9>(v); }
 };
 
 template <>
@@ -175,10 +257,12 @@ struct WPlan {
     // thread runs K1 of the 512 first-stage butterflies.  Waves per workgroup by same-box A/B
     // (tools/wfft, 24 GB of input): R0 = 2: 2 (9.3 ms against 18.9 ms with 8), R0 = 3: 2 (3.0 vs
     // 3.6 ms with 3, 3.4 with 1), R0 = 4: 2 (3.78 vs 3.98 ms with 4), R0 = 5: 4 (10.4 vs 11.5 with 8,
-    // 12.5 with 5), R0 = 6: 4 (6.1 vs 6.7 with 6, 8.7 with 3); from R0 = 8 on 8 waves (R0 = 8 with 4:
+    // 12.5 with 5), R0 = 6: 4 (6.1 vs 6.7 with 6, 8.7 with 3), R0 = 7: 4 (5.10 vs 5.17 with 8, per
+    // 12 GB); from R0 = 8 on 8 waves (R0 = 9 with 3 / 4: 8.2 / 5.7 vs 5.0; R0 = 14 with 7: 9.6 vs 5.0;
+    // R0 = 18 with 6: 19.9 vs 4.8; R0 = 8 with 4:
     // 8.3 vs 7.6 ms; R0 = 10 with 4 / 5: 10.8 / 14.3 vs 9.7; R0 = 12 with 4 / 6: 13.4 / 19.4 vs 11.8;
     // R0 = 20 with 4: 11.6 vs 9.2).
-    static constexpr int NW = R0 == WF_NW_R0 ? WF_NW_VAL : R0 <= 4 ? 2 : R0 <= 6 ? 4 : 8;
+    static constexpr int NW = R0 == WF_NW_R0 ? WF_NW_VAL : R0 <= 4 ? 2 : R0 <= 7 ? 4 : 8;
     static constexpr int NT = 64 * NW;
     static constexpr int K1 = (N1 + NT - 1) / NT;
     // (measured: trading the resident stage twiddles for a fourth wave per SIMD in the small plans
