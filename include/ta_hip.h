@@ -175,7 +175,7 @@ int ta_timing_history(ta_ctx *ctx, int max_n, float *total_ms, float *main_kerne
 /* FFT length bookkeeping for a given n_frames: *m_out = padded half-length M
  * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1): M = R * R0 * 512 with
  * R0 in {1,...,10,12,14,16,18,20} and the outer radix R = 1 up to 10240 frames (one on-chip
- * transform per pass), R in {2,3,4,5,8,16} with R0 in {12,16,20} up to 163840 frames (n_stages
+ * transform per pass), R in {2,3,4,5,8,16} with R0 in {12,14,16,18,20} up to 163840 frames (n_stages
  * counts the outer step).
  * Beyond that ta_vacf_fft* compute the same quantity with the direct correlator and this
  * call returns TA_E_UNSUPPORTED.                                              */

@@ -47,10 +47,11 @@ def test_plan_info():
                  (10000, 10240), (10240, 10240)):
         assert _lib.fft_plan_info(T)["M"] == M
     # beyond one on-chip transform: outer radix R x on-chip M (csrc/wfft.hpp)
-    # (outer radix 2, 3, 4, 5, 8, 16 in front of the plans R0 = 12, 16, 20; smallest M (1 + 0.15 R))
-    for T, M in ((10241, 12288), (12289, 16384), (16385, 20480), (20481, 24576), (24577, 30720),
-                 (30000, 30720), (30721, 32768), (40961, 51200), (50000, 51200), (51201, 65536),
-                 (81921, 98304), (100000, 131072), (163840, 163840)):
+    # (outer radix 2, 3, 4, 5, 8, 16 in front of the plans R0 = 12, 14, 16, 18, 20; smallest M (1 + 0.15 R))
+    for T, M in ((10241, 12288), (12289, 14336), (14337, 16384), (16385, 18432), (18433, 20480),
+                 (20481, 21504), (24577, 27648), (27649, 30720), (30000, 30720), (30721, 32768),
+                 (40961, 46080), (50000, 51200), (51201, 57344), (81921, 98304), (100000, 114688),
+                 (163840, 163840)):
         info = _lib.fft_plan_info(T)
         assert info["M"] == M
     assert _lib.fft_plan_info(163841) is None  # handled by the direct correlator

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256)
 }  // namespace
 
 // Up to 10240 frames: the smallest on-chip length R0 * 512 >= n_frames.  Beyond: an outer radix R
-// in front of one of the three largest on-chip plans; a pass then forms its rows from R strided
+// in front of one of the five largest on-chip plans; a pass then forms its rows from R strided
 // rows each, work that grows like R^2 per pair next to the transforms' R log: the plan with the
 // smallest M' (1 + 0.15 R) wins (measured at 12 GB: 25000 frames as 5 x 5120: 12.9 ms, 30000 frames
 // as 3 x 10240: 8.1 ms).
@@ -120,7 +120,7 @@ bool wfft_choose(long n_frames, int* R0, int* R) {
         }
     double best = 0.0;
     for (int ro : kOuter)
-        for (int r : {12, 16, 20}) {
+        for (int r : {12, 14, 16, 18, 20}) {
             const long m = (long)ro * r * 512;
             if (ro == 1 || m < n_frames) continue;
             const double cost = (double)m * (1.0 + 0.15 * ro);
