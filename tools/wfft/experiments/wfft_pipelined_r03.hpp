@@ -1,3 +1,20 @@
+// EXPERIMENT RECORD (round 3) -- NOT part of the library; kept so the measurement can be repeated.
+//
+// A software-pipelined variant of k_wsplit_accum: the next unit's first stage (register-only
+// butterfly + output twiddles) runs inside S2 under the exchanges ("P1"), the third radix-8
+// stage runs beside the LDS stores of the next unit ("P2"), SIMD partner waves run the halves
+// of each phase in opposite order ("roles").  To build it, copy this file over
+// transport_analysis_amd/csrc/wfft.hpp and run tools/wfft/build.sh.
+//
+// Result (same box, tools/wfft/wfft_test time, 30000 pairs): R0 = 16 (no spills) 1.62-1.64 ms
+// against 1.61-1.65 ms for the two-barrier kernel with the same sub-series code; R0 = 20 slower
+// (80 row registers + 48 sub-series registers + Dft<20> temporaries spill 240-560 B).  The
+// stamps show why nothing is gained: per unit and pass (R0 = 16) P1 5.0k cycles + 2.7k waiting at
+// barrier A for the SIMD partner, P2 2.6k + 2.1k waiting at B -- the older wave of a SIMD runs
+// ahead, the younger one finishes alone.  Counters of the two-barrier kernel say what the limit
+// is: with 10 % fewer vector instructions (5.34e8 -> 4.79e8) the duration does not move and
+// SQ_WAIT_INST_LDS grows by 42 % (2.65e8 -> 3.77e8), SQ_LDS_DATA_FIFO_FULL by 38 %: the LDS
+// store path (three 16-byte store round trips per point and pass), not vector issue.
 // wfft.hpp — per-wave FFT kernels on pair-major slabs (gfx950): power spectra of column pairs
 // (forward kernel) and the lag values of a power spectrum (inverse kernel).
 //
@@ -642,6 +659,9 @@ __device__ __forceinline__ cd wf_cfma(cd acc, cd a, cd b) {  // acc + a b
     return {acc.x + (a.x * b.x - a.y * b.y), acc.y + (a.x * b.y + a.y * b.x)};
 }
 
+#ifndef WF_ORDER
+#define WF_ORDER 0  // experiment: where the next unit's first stage sits among the stages of S2
+#endif
 template <class P, bool BYP = false, bool LONG = false, bool STAMP = false>
 __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
     k_wsplit_accum(const double* __restrict__ pm, long pitch, int T, long n_units,
@@ -712,105 +732,81 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
             }
         }
     };
-    int kind = 2, nkind = 2;
-    __amdgpu_buffer_rsrc_t crs = unit_rsrc(tuple * grp, 0, &kind);
-    issue_loads(crs, kind);
-    // the wave-local stage twiddles stay in registers for the whole launch where one pass's
-    // accumulators leave room for them (14 fewer loads per wave and unit); the small plans trade
-    // them for a fourth wave per SIMD and load them again before every S2
-    WfTw stw;
-    auto load_stage_tw = [&]() {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            stw.b[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + (14 + a) * 64) * 16u);
-            stw.c[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + (18 + a) * 64) * 16u);
-        }
-    };
-    if constexpr (P::kTwResident) load_stage_tw();
-    WfAddr wad;
-    wad.init(lane, (unsigned)P::sub_base(wave) * kWfSubBytes);
-    const WfSub wsub(wad, smem_raw);
-    int k = 0;  // unit of the atom (by-particle mode)
-    bool zero_pending = false;
-    for (long item = tuple * grp; item < n_units;) {
-        // ---- S1: radix-R0 butterflies u = tid + NT k over rows u + 512 j of u_c (jo = 0 requested
-        // during the previous S2); g = W_M^u, h = W_L^{c u}
+    // ---- S1 in registers, in two pieces: rows -> radix-R0 butterflies u = tid + NT k over rows
+    // u + 512 j of u_c (jo = 0 in xx), then the output twiddles W_L^{u (2R q + c)} = h g^q,
+    // g = W_M^u, h = W_L^{c u}: two chains (even / odd q) by g^2
+    auto s1_butterfly = [&](__amdgpu_buffer_rsrc_t crs, int kind) {
 #pragma unroll
         for (int k1 = 0; k1 < K1; ++k1) {
-        const int u = tid + NT * k1;
-        if (K1 * NT != N1 && u >= N1) continue;
-        cd(&x)[R0] = xx[k1];
-        cd g, g2, h;
-        auto load_seeds = [&]() {
-            g = wf_load(twr, (unsigned)(u * R) * 32u, 0u);
-            g2 = wf_load(twr, (unsigned)(u * R) * 64u, 0u);
-            h = wf_load(twr, (unsigned)(u * pass) * 16u, 0u);
-        };
-        if constexpr (!LONG) load_seeds();
+            const int u = tid + NT * k1;
+            if (K1 * NT != N1 && u >= N1) continue;
+            cd(&x)[R0] = xx[k1];
 #if WF_ABL != 2
-        if constexpr (LONG) {
-            // u_c[u + 512 j] = sum_jo z[u + 512 j + M jo] U(j, jo), U = W_L^{c (512 j + M jo)} lane-uniform,
-            // its index advanced by c 512 per j and c M per jo (mod L: one conditional subtraction)
-            const int sj = pass * N1, so = pass * M;
-            if (pass) {
-                int idx = 0;
+            if constexpr (LONG) {
+                // u_c[u + 512 j] = sum_jo z[u + 512 j + M jo] U(j, jo), U = W_L^{c (512 j + M jo)} lane-uniform,
+                // its index advanced by c 512 per j and c M per jo (mod L: one conditional subtraction)
+                const int sj = pass * N1, so = pass * M;
+                if (pass) {
+                    int idx = 0;
 #pragma unroll
-                for (int j = 1; j < R0; ++j) {
-                    idx += sj;
-                    idx -= idx >= L ? L : 0;
-                    x[j] = cmul(x[j], tw_uniform(tw2, idx));
-                }
-            }
-            auto outer_rows = [&](auto single) {
-                int base = 0;
-                for (int jo = 1; jo < R; ++jo) {
-                    base += so;
-                    base -= base >= L ? L : 0;
-                    if (jo * M >= T) break;  // nothing but padding from here on
-                    int idx = base;
-                    // four rows in flight at a time: all R0 at once would not fit next to x[]
-#pragma unroll
-                    for (int j0 = 0; j0 < R0; j0 += 4) {
-                        cd z[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (j0 + i < R0)
-                                z[i] = load_row(crs, decltype(single)::value ? kind : 2, u, (unsigned)(N1 * (j0 + i) + M * jo));
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (j0 + i < R0) {
-                                x[j0 + i] = wf_cfma(x[j0 + i], z[i], tw_uniform(tw2, idx));
-                                idx += sj;
-                                idx -= idx >= L ? L : 0;
-                            }
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 1; j < R0; ++j) {
+                        idx += sj;
+                        idx -= idx >= L ? L : 0;
+                        x[j] = cmul(x[j], tw_uniform(tw2, idx));
                     }
                 }
-            };
-            if (BYP && kind != 2) outer_rows(std::true_type{});
-            else outer_rows(std::false_type{});
-            __builtin_amdgcn_sched_barrier(0);
-            load_seeds();  // after the row loads: their registers are free again
-        } else if (pass) {
-            // pass B twist, lane-uniform part W_{2 R0}^j: literals (wfft_twist.inc) instead of 19
-            // scalar loads per butterfly
+                auto outer_rows = [&](auto single) {
+                    int base = 0;
+                    for (int jo = 1; jo < R; ++jo) {
+                        base += so;
+                        base -= base >= L ? L : 0;
+                        if (jo * M >= T) break;  // nothing but padding from here on
+                        int idx = base;
+                        // four rows in flight at a time: all R0 at once would not fit next to x[]
 #pragma unroll
-            for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], cd{WfTwist<R0>::re(j), WfTwist<R0>::im(j)});
-        }
-        Dft<R0>::run(x);
+                        for (int j0 = 0; j0 < R0; j0 += 4) {
+                            cd z[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (j0 + i < R0)
+                                    z[i] = load_row(crs, decltype(single)::value ? kind : 2, u, (unsigned)(N1 * (j0 + i) + M * jo));
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (j0 + i < R0) {
+                                    x[j0 + i] = wf_cfma(x[j0 + i], z[i], tw_uniform(tw2, idx));
+                                    idx += sj;
+                                    idx -= idx >= L ? L : 0;
+                                }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                };
+                if (BYP && kind != 2) outer_rows(std::true_type{});
+                else outer_rows(std::false_type{});
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (pass) {
+                // pass B twist, lane-uniform part W_{2 R0}^j: literals, not scalar loads -- a scalar load
+                // among the LDS operations of S2 would make the wait for it a drain of all of them
+                // (one counter, and scalar loads return out of order)
+#pragma unroll
+                for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], cd{WfTwist<R0>::re(j), WfTwist<R0>::im(j)});
+            }
+            Dft<R0>::run(x);
 #endif
-        {
-            // output twiddles W_L^{u (2R q + c)} = h g^q: two chains (even / odd q) by g^2, each
-            // output stored as soon as it is scaled (the 20 stores of a wave take ~260 LDS-path
-            // cycles: issued in one burst at the end they are fully exposed)
+        }
+    };
+    auto s1_twiddle = [&]() {
+#pragma unroll
+        for (int k1 = 0; k1 < K1; ++k1) {
+            const int u = tid + NT * k1;
+            if (K1 * NT != N1 && u >= N1) continue;
+            cd(&x)[R0] = xx[k1];
+            const cd g = wf_load(twr, (unsigned)(u * R) * 32u, 0u), g2 = wf_load(twr, (unsigned)(u * R) * 64u, 0u),
+                     h = wf_load(twr, (unsigned)(u * pass) * 16u, 0u);
             cd te = pass ? h : cd{1.0, 0.0};
             cd to = pass ? cmul(h, g) : g;
             if (pass) x[0] = cmul(x[0], te);
-            lds[u] = x[0];
-            if constexpr (R0 > 1) {
-                x[1] = cmul(x[1], to);
-                lds[N1 + u] = x[1];
-            }
+            if constexpr (R0 > 1) x[1] = cmul(x[1], to);
 #pragma unroll
             for (int q = 2; q < R0; ++q) {
                 if (q & 1) {
@@ -820,110 +816,212 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                     te = cmul(te, g2);
                     x[q] = cmul(x[q], te);
                 }
-                lds[q * N1 + u] = x[q];
             }
         }
-        }
-        if constexpr (!P::kTwResident) {
-            asm volatile("" : "+v"(lane));  // keeps the loads (and their registers) inside the loop
-            load_stage_tw();
-        }
-        WF_STAMP(0)
-        __syncthreads();
-        if (BYP && zero_pending) {
+    };
+    auto s1_store = [&]() {
 #pragma unroll
-            for (int s = 0; s < NS1; ++s)
+        for (int k1 = 0; k1 < K1; ++k1) {
+            const int u = tid + NT * k1;
+            if (K1 * NT != N1 && u >= N1) continue;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) acc[s][c] = 0.0;
-            zero_pending = false;
+            for (int q = 0; q < R0; ++q) lds[q * N1 + u] = xx[k1][q];
         }
-        // ---- S2: sub-series q = wave + NW s, two or three in flight per wave; the next unit's
-        // rows are requested after the last one (before the barrier)
+    };
+    // the tuple's next unit after (item, k)
+    auto advance = [&](long item, int k, long* nitem, int* nk) {
         const bool last_of_item = !BYP || k == upa - 1;
-        long nitem = item;
+        *nitem = item;
         if (last_of_item) {
-            if (BYP && grp == 2 && (item & 1) == 0 && item + 1 < n_units) nitem = item + 1;
-            else nitem = (item & ~(long)(grp - 1)) + grp * n_tuples;
+            if (BYP && grp == 2 && (item & 1) == 0 && item + 1 < n_units) *nitem = item + 1;
+            else *nitem = (item & ~(long)(grp - 1)) + grp * n_tuples;
         }
-        const int nk = last_of_item ? 0 : k + 1;
-        const __amdgpu_buffer_rsrc_t nrs = unit_rsrc(nitem, nk, &nkind);
-#if WF_ABL == 1
-        if (T < 0)
-#endif
-        if constexpr (NS1 == 3 && P::NLO == 2 && P::REM != 0) {
-            // two full slots and a partial third: the waves that own three sub-series take them
-            // three at a time, the others two at a time
-            if (wave < P::REM) wf_sub512_x3(wsub, stw, acc[0], acc[1], acc[2]);
-            else wf_sub512_x2<0>(wsub, stw, acc[0], acc[1]);
-        } else {
-            static_for_range<0, NS1>([&](auto ss) {
-                constexpr int s = decltype(ss)::value;
-                constexpr bool full = s < P::NLO;                       // every wave has this slot
-                constexpr bool nfull = s + 1 < P::NLO;                  // ... and the next one
-                constexpr bool head = full && nfull && (s % 2 == 0);
-                constexpr bool tail = full && s > 0 && (s % 2 == 1);
-                if constexpr (head) {
-                    wf_sub512_x2<s>(wsub, stw, acc[s], acc[s + 1]);
-                } else if constexpr (!tail) {
-                    if (full || wave < P::REM) wf_sub512<s>(wsub, stw, acc[s]);
-                }
-            });
-        }
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        auto store_acc = [&](long row) {  // accg[row][pass][q][cc / 2][lane][cc & 1]
-            const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
-                accg + (row * npass + pass) * (long)M, 0, M * 8, 0x00020000);
+        *nk = last_of_item ? 0 : k + 1;
+    };
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    auto store_acc = [&](long row, bool zeros) {  // accg[row][pass][q][cc / 2][lane][cc & 1]
+        const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+            accg + (row * npass + pass) * (long)M, 0, M * 8, 0x00020000);
 #pragma unroll
-            for (int s = 0; s < NS1; ++s) {
-                const int q = P::sub_base(wv) + s;
-                if (s < P::NLO || wv < P::REM) {
+        for (int s = 0; s < NS1; ++s) {
+            const int q = P::sub_base(wv) + s;
+            if (s < P::NLO || wv < P::REM) {
 #pragma unroll
-                    for (int c2 = 0; c2 < 4; ++c2) {
-                        // 16 bytes per lane (cc = 2 c2, 2 c2 + 1): half the store instructions here and half
-                        // the load instructions in k_winverse (by-particle step 23.6 -> 23.0 ms)
-                        const cd two{acc[s][2 * c2], acc[s][2 * c2 + 1]};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wf_u32x4, two), sr, (unsigned)lane * 16u,
-                                                               (unsigned)((q * 4 + c2) * 64) * 16u, 0);
-                    }
+                for (int c2 = 0; c2 < 4; ++c2) {
+                    // 16 bytes per lane (cc = 2 c2, 2 c2 + 1): half the store instructions here and half
+                    // the load instructions in k_winverse
+                    const cd two = zeros ? cd{0.0, 0.0} : cd{acc[s][2 * c2], acc[s][2 * c2 + 1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wf_u32x4, two), sr, (unsigned)lane * 16u,
+                                                           (unsigned)((q * 4 + c2) * 64) * 16u, 0);
                 }
             }
-        };
-        if constexpr (BYP) {
-            // the atom's power spectrum in this pass; the accumulators restart from zero before the
-            // next unit's S2
-            if (last_of_item) {
-                store_acc(item);
-                zero_pending = true;
-            }
-        } else {
-            if (nitem >= n_units) store_acc(tuple);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#if WF_ABL != 3
-        issue_loads(nrs, nkind);
-#endif
-        kind = nkind, item = nitem, k = nk, crs = nrs;
-        WF_STAMP(1)
-        __syncthreads();
-    }
-    if constexpr (!BYP) {
+    };
+    long item = tuple * grp;
+    if (item >= n_units) {
         // a tuple without units still owes its (zero) row of the partial spectra
-        if (tuple * grp >= n_units) {
-            const int wv = __builtin_amdgcn_readfirstlane(wave);
-            const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
-                accg + (tuple * npass + pass) * (long)M, 0, M * 8, 0x00020000);
+        if constexpr (!BYP) store_acc(tuple, true);
+        return;
+    }
+    // ---- prologue: the first unit's first stage; the resident constants of S2
+    int kind = 2, k = 0;  // unit k of the atom (by-particle mode)
+    {
+        const __amdgpu_buffer_rsrc_t crs = unit_rsrc(item, 0, &kind);
+        issue_loads(crs, kind);
+        s1_butterfly(crs, kind);
+    }
+    // the wave-local stage constants (tangent form) stay in registers for the whole launch
+    WfTw stw;
 #pragma unroll
-            for (int s = 0; s < NS1; ++s) {
-                const int q = P::sub_base(wv) + s;
-                if (s < P::sub_count(wv)) {
+    for (int a = 0; a < 4; ++a) {
+        stw.b[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + (14 + a) * 64) * 16u);
+        stw.c[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + (18 + a) * 64) * 16u);
+    }
+    WfAddr wad;
+    wad.init(lane, (unsigned)P::sub_base(wave) * kWfSubBytes);
+    const WfSub wsub(wad, smem_raw);
+    const bool extra = wave < P::REM;  // this wave owns NLO + 1 sub-series
+    s1_twiddle();
+    s1_store();
+    long nitem;
+    int nk, nkind = 2;
+    advance(item, k, &nitem, &nk);
+    __amdgpu_buffer_rsrc_t nrs = unit_rsrc(nitem, nk, &nkind);
+    issue_loads(nrs, nkind);
+    WF_STAMP(1)
+    __syncthreads();
+    // ---- steady state.  Between the barriers B and A ("P1") the unit in LDS goes through the
+    // LDS-bound part of S2 -- read, first and second radix-8 stage with their exchanges, all the
+    // wave's sub-series in flight -- and the register-only first stage of the NEXT unit (its rows
+    // were requested before barrier B) runs in between, under the exchanges.  Between A and B
+    // ("P2") the third radix-8 stage (registers only, |.|^2 into the accumulators) runs beside
+    // the LDS stores of the next unit's first-stage outputs; then the rows of the unit after
+    // that are requested.
+    // (a wave's number of sub-series is a compile-time constant of its loop: the waves with one
+    // more than the others run their own copy, straight-line code between the barriers)
+    //
+    // Roles.  The two waves of a SIMD (w and w + NW / 2) run the halves of a phase in opposite
+    // order: in P1 role 0 goes through the exchanges first and computes the next unit's first
+    // stage under its last exchange, role 1 computes first and exchanges afterwards; in P2 role 0
+    // stores first, role 1 runs the third stage first.  Run in the same order, every wave of the
+    // workgroup is in its LDS burst at the same time (vector pipes idle behind full LDS queues) and
+    // then in its vector burst (LDS idle).
+    auto pin_xx = [&]() {
 #pragma unroll
-                    for (int c2 = 0; c2 < 4; ++c2)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wf_u32x4, cd{0.0, 0.0}), sr,
-                                                               (unsigned)lane * 16u, (unsigned)((q * 4 + c2) * 64) * 16u, 0);
+        for (int k1 = 0; k1 < K1; ++k1)
+#pragma unroll
+            for (int q = 0; q < R0; ++q) wf_pin(xx[k1][q].x), wf_pin(xx[k1][q].y);
+    };
+    auto steady = [&](auto nsub_c, auto role_c) {
+        constexpr int NSUB = decltype(nsub_c)::value;
+        constexpr int ROLE = decltype(role_c)::value;
+        cd v[NSUB][8];
+#define WF_EACH_SUB(call)                                      \
+    static_for_range<0, NSUB>([&](auto ss) {                   \
+        constexpr int s = decltype(ss)::value;                 \
+        constexpr unsigned SO = s * kWfSubBytes;               \
+        (void)SO;                                              \
+        call;                                                  \
+    })
+        for (;;) {
+            if constexpr (ROLE == 1) {
+                s1_butterfly(nrs, nkind);
+                s1_twiddle();
+                pin_xx();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            WF_EACH_SUB(wsub.template read_a<SO>(v[s]));
+            __builtin_amdgcn_wave_barrier();
+#if WF_ABL != 1
+            WF_EACH_SUB(wsub.template stage_a_w<SO>(v[s]));
+            WF_EACH_SUB(wsub.template stage_a_r<SO>(v[s]));
+            WF_EACH_SUB(wsub.template stage_b_w<SO>(v[s], stw));
+#endif
+            if constexpr (ROLE == 0) {
+                // under exchange 2: the sub-series are in LDS, not in registers
+                __builtin_amdgcn_sched_barrier(0);
+                s1_butterfly(nrs, nkind);
+                s1_twiddle();
+                pin_xx();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#if WF_ABL != 1
+            WF_EACH_SUB(wsub.template stage_b_r<SO>(v[s]));
+#endif
+            WF_STAMP(0)
+            __syncthreads();  // A: every wave has read its sub-series for the last time
+            WF_STAMP(2)
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s)  // (the third stage belongs on THIS side of the barrier)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wf_pin(v[s][i].x), wf_pin(v[s][i].y);
+            if constexpr (ROLE == 0) {
+                s1_store();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#if WF_ABL != 1
+            WF_EACH_SUB(wsub.stage_c(v[s], stw, acc[s]));
+#endif
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) wf_pin(acc[s][c]);
+            if constexpr (ROLE == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                s1_store();
+            }
+            if constexpr (BYP) {
+                // the atom's power spectrum in this pass; the accumulators restart from zero
+                if (k == upa - 1) {
+                    store_acc(item, false);
+#pragma unroll
+                    for (int s = 0; s < NS1; ++s)
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) acc[s][c] = 0.0;
                 }
+            }
+            // (past the tuple's last unit the stores above and the request below move nothing that
+            // is used: the loop ends at the barrier below)
+            item = nitem, k = nk, kind = nkind;
+            advance(item, k, &nitem, &nk);
+            nrs = unit_rsrc(nitem, nk, &nkind);
+            __builtin_amdgcn_sched_barrier(0);
+#if WF_ABL != 3
+            issue_loads(nrs, nkind);
+#endif
+            WF_STAMP(1)
+            __syncthreads();  // B: the unit's first-stage outputs are in LDS
+            WF_STAMP(3)
+            if (item >= n_units) break;
+        }
+#undef WF_EACH_SUB
+    };
+    {
+        using N_HI = std::integral_constant<int, P::NLO + 1>;
+        using N_LO = std::integral_constant<int, P::NLO>;
+        using R0_ = std::integral_constant<int, 0>;
+        using R1_ = std::integral_constant<int, 1>;
+        const bool role1 = wave >= NW / 2;  // the SIMD partner of wave w is w + NW / 2 (8 waves)
+        if constexpr (NW < 8) {
+            if (P::REM != 0 && extra) steady(N_HI{}, R0_{});
+            else steady(N_LO{}, R0_{});
+        } else if constexpr (P::REM == NW / 2) {  // the waves with one sub-series more are the role-0 waves
+            if (extra) steady(N_HI{}, R0_{});
+            else steady(N_LO{}, R1_{});
+        } else if constexpr (P::REM == 0) {
+            if (role1) steady(N_LO{}, R1_{});
+            else steady(N_LO{}, R0_{});
+        } else {
+            if (extra) {
+                if (P::REM > NW / 2 && role1) steady(N_HI{}, R1_{});
+                else steady(N_HI{}, R0_{});
+            } else {
+                if (role1) steady(N_LO{}, R1_{});
+                else if constexpr (P::REM < NW / 2) steady(N_LO{}, R0_{});
             }
         }
     }
+    if constexpr (!BYP) store_acc(tuple, false);
     if constexpr (STAMP) {
         if (lane == 0 && (wave == 0 || wave == NW / 2))
             for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + (wave ? 4 : 0) + i] = st_acc[i];

@@ -189,12 +189,13 @@ static int run(int R, int argc, char** argv) {
         std::vector<unsigned long long> st((size_t)nwg * 8);
         CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
         for (int h = 0; h < 2; ++h) {
-            double s[2] = {0, 0};
+            double s[4] = {0, 0, 0, 0};
             for (int w = 0; w < nwg; ++w)
-                for (int i = 0; i < 2; ++i) s[i] += (double)st[(size_t)w * 8 + h * 4 + i];
+                for (int i = 0; i < 4; ++i) s[i] += (double)st[(size_t)w * 8 + h * 4 + i];
             const double per = (double)nwg * ((double)n_pairs / n_tuples);  // unit-passes
-            printf("cycles per unit and pass (wave %d): S1 %.0f  S2 %.0f  total %.0f\n", 4 * h, s[0] / per, s[1] / per,
-                   (s[0] + s[1]) / per);
+            // P1: exchanges of S2 + the next unit's first stage; P2: third stage + LDS stores + row requests
+            printf("cycles per unit and pass (wave %d): P1 %.0f  wait A %.0f  P2 %.0f  wait B %.0f  total %.0f\n", 4 * h,
+                   s[0] / per, s[2] / per, s[1] / per, s[3] / per, (s[0] + s[1] + s[2] + s[3]) / per);
         }
     }
     return 0;
