@@ -23,7 +23,16 @@ algorithmic bytes (n_frames*n_atoms*dim*8 per launch) and the median of its K hi
 durations (recorded by the library on the launch stream, read AFTER the timed region), and
 carries the FP64 vector co-roof beside it.  `cpu_baseline` is the NumPy oracle (per-atom loop
 + numpy.fft, the reference's control flow) on one host core over an atom block of the same
-tensor.  `other_configs` (N = 1) are short driver-timed runs of the other BASELINE configs.
+tensor.  `other_configs` (N = 1) are short driver-timed runs of the other BASELINE configs; their
+`roofline.frac` is the WHOLE path's algorithmic bytes (or flops) over the whole call's device
+time, with the per-kernel split (`kernels`, from the library's event timeline of one extra,
+untimed step) beside it.  `staging` prices what the timed region leaves out: the on-device
+transposition of frame-major frames into the pair-major slab (k_relayout) and a complete
+ta_vacf_fft_dev call on a frame-major device tensor.  `host_path_by_particle` runs the drop-in
+CLASS end to end (frames staged through pinned memory, result array in pinned memory).
+N > 1 (and N = 1 under torchrun with TA_BENCH_FORCE_DIST=1): `config.rank_devices` lists the GPU
+every rank ran on (the run fails unless they are N distinct devices) and `reduce_us` is the
+all-reduce alone.
 """
 import argparse
 import hashlib
@@ -166,7 +175,20 @@ def timed(torch, dist, world, steps, warmup, fn):
     return elapsed
 
 
+def kernel_split(ctx, case, torch):
+    """[{name, ms}] of ONE extra (untimed) step, from the library's event timeline."""
+    ctx.set_option("timeline", 1)
+    try:
+        case.step()
+        torch.cuda.synchronize()
+        return [{"name": n, "ms": round(ms, 4)} for n, ms in ctx.kernel_timeline() if n != "end"]
+    finally:
+        ctx.set_option("timeline", 0)
+
+
 def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
+    """kernel_ms: device time the bytes / flops are divided by -- the dominant kernel's for a
+    path that IS one kernel (FFT lag sums, direct correlators), the whole call's otherwise."""
     T, A, D = case.T, case.A, case.D
     from transport_analysis_amd import _lib
 
@@ -261,6 +283,92 @@ def host_path(torch, _lib, dev_index, T, D):
         ctx.close()
 
 
+def staging_cost(torch, ctx, dev, T, A, D):
+    """What the timed region leaves out on the device side: (a) k_relayout, the transposition of
+    committed frame-major frames into the pair-major slab (ta_stage_commit_dev on the whole
+    tensor); (b) a complete ta_vacf_fft_dev call on a frame-major device tensor (transposition
+    into the context's scratch slab + the FFT path)."""
+    fm = torch.empty((T, A * D), dtype=torch.float64, device=dev)
+    fm.normal_()
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.stage_alloc_device(T, A, D, n_slabs=1)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ms = []
+    for _ in range(3):
+        ev[0].record()
+        ctx.stage_commit_dev(0, fm.data_ptr(), A * D, 0, T, stream=stream)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms.append(ev[0].elapsed_time(ev[1]))
+    relayout_ms = min(ms)
+    ctx.stage_free()
+    lag = torch.zeros(T, dtype=torch.float64, device=dev)
+    ctx.set_option("timeline", 1)
+    try:
+        tot = []
+        for _ in range(3):
+            ctx.vacf_fft_dev(fm.data_ptr(), T, A, D, A * D, lag.data_ptr(), 0, 0, stream)
+            torch.cuda.synchronize()
+            tot.append(ctx.last_timing()[0])
+        split = [{"name": n, "ms": round(m, 4)} for n, m in ctx.kernel_timeline() if n != "end"]
+    finally:
+        ctx.set_option("timeline", 0)
+    nbytes = T * A * D * 8
+    del fm, lag
+    ctx.trim()
+    torch.cuda.empty_cache()
+    return {"tensor": f"{T} x {A} x {D} float64 frame-major on the device ({nbytes / 1e9:.1f} GB)",
+            "k_relayout_ms": relayout_ms,
+            "k_relayout_GBps": 2 * nbytes / (relayout_ms * 1e-3) / 1e9,  # read + write
+            "vacf_fft_dev_ms": min(tot), "vacf_fft_dev_kernels": split,
+            "vacf_fft_dev_lag_points_per_s": T * A / (min(tot) * 1e-3)}
+
+
+def host_path_by_particle(dev_index, T, D):
+    """The drop-in CLASS end to end, the reference's default output included:
+    VelocityAutocorr(ArrayUniverse(...), fft=True).run() at T x 50000 x D, float32 frames through
+    pinned staging, results.vacf_by_particle in pinned memory.  The frame loop is the stand-in
+    AnalysisBase's Python loop (with MDAnalysis: the trajectory reader); `conclude_s` is what
+    the library adds after the last frame: final commit, compute, device->host."""
+    import numpy as np
+
+    from transport_analysis_amd import VelocityAutocorr
+    from transport_analysis_amd._mini_mda import ArrayUniverse
+
+    A = 50000
+    rng = np.random.default_rng(11)
+    blk = rng.standard_normal((250, A, 3), dtype=np.float32)
+    vel = np.empty((T, A, 3), dtype=np.float32)
+    for t in range(0, T, 250):
+        vel[t:t + 250] = blk[: min(250, T - t)]
+    u = ArrayUniverse(velocities=vel, positions=None)
+    res = {}
+    for rep in range(2):
+        an = VelocityAutocorr(u.atoms, fft=True, device=dev_index)
+        marks = {}
+        orig_conclude = an._conclude
+
+        def timed_conclude():
+            marks["loop_end"] = time.perf_counter()
+            orig_conclude()
+            marks["end"] = time.perf_counter()
+
+        an._conclude = timed_conclude
+        t0 = time.perf_counter()
+        an.run()
+        loop_s, conclude_s = marks["loop_end"] - t0, marks["end"] - marks["loop_end"]
+        bp = an.results.vacf_by_particle
+        res = {"what": f"VelocityAutocorr(fft=True).run() through the class, {T} x {A} x {D} float32 frames, "
+                       f"vacf_by_particle {bp.shape[0]} x {bp.shape[1]} float64 in pinned memory; second of two runs",
+               "frame_loop_s": loop_s, "conclude_s": conclude_s, "total_s": loop_s + conclude_s,
+               "bytes_in": T * A * D * 4, "bytes_out": bp.nbytes,
+               "pcie_floor_s_at_48GBps": (T * A * D * 4 + bp.nbytes) / 48e9,
+               "out_GBps_if_conclude_were_all_copy": bp.nbytes / conclude_s / 1e9,
+               "value": T * A / (loop_s + conclude_s), "unit": "lag-points/s"}
+        del an, bp
+    return res
+
+
 def main():
     args = parse()
     import numpy as np
@@ -283,12 +391,27 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # a process group for N > 1; for N = 1 only on request (TA_BENCH_FORCE_DIST=1 under torchrun:
+    # the RCCL branch of the step on a one-GPU box)
+    grouped = world > 1 or (os.environ.get("TA_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    # which GPU is this rank on?  (uuid where torch has it, else the PCI address)
+    props = torch.cuda.get_device_properties(dev)
+    dev_id = str(getattr(props, "uuid", "")) or ""
+    if not dev_id or set(dev_id) <= set("0-"):
+        dev_id = "pci:%s:%s:%s" % tuple(getattr(props, a, "?") for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    rank_devices = [f"{local_rank}|{dev_id}"]
+    if grouped:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_devices[0])
+        rank_devices = gathered
+        if not one_gpu and len(set(d.split("|", 1)[1] for d in rank_devices)) != world:
+            raise SystemExit(f"ranks share a GPU: {rank_devices}")
 
     from transport_analysis_amd import _lib
     from transport_analysis_amd.dist import atom_shard, reduce_lagsum
@@ -311,15 +434,30 @@ def main():
                 args.float32, args.helfand_fft)
 
     result = {}
+    red_events, red_host = [], []
 
     def step():
         case.step()
         if one_gpu and world > 1:
+            t0 = time.perf_counter()
             result["ts"] = reduce_lagsum(case.lagsum.cpu(), a_total)
+            red_host.append((time.perf_counter() - t0) * 1e6)
+        elif grouped:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            result["ts"] = reduce_lagsum(case.lagsum, a_total)  # device tensor in and out: RCCL
+            e1.record()
+            red_events.append((e0, e1))
         else:
-            result["ts"] = reduce_lagsum(case.lagsum, a_total)  # device tensor in and out
+            result["ts"] = reduce_lagsum(case.lagsum, a_total)
 
-    elapsed = timed(torch, dist, world, args.steps, args.warmup, step)
+    elapsed = timed(torch, dist, world if grouped else 1, args.steps, args.warmup, step)
+    reduce_us = None
+    if red_events:
+        torch.cuda.synchronize()
+        reduce_us = statistics.median(a.elapsed_time(b) * 1e3 for a, b in red_events[-args.steps:])
+    elif red_host:
+        reduce_us = statistics.median(red_host[-args.steps:])
     hist = ctx.timing_history(min(args.steps, 64))
     kernel_ms = statistics.median(m for _, m in hist)
     total_ms = statistics.median(t for t, _ in hist)
@@ -345,13 +483,20 @@ def main():
         del fm
 
     if rank != 0:
-        if world > 1:
+        if grouped:
             dist.destroy_process_group()
         return
     ms_per_step = elapsed / args.steps * 1e3
-    roof = roofline_of(case, kernel_ms, args.helfand_fft, args.float32)
-    key = f"{args.mode}_{T}x{A}x{D}" + ("_bp" if args.by_particle else "")
+    composite = args.by_particle or args.helfand_fft
+    roof = roofline_of(case, total_ms if composite else kernel_ms, args.helfand_fft, args.float32)
+    if composite:
+        roof["kernel"] = "whole call"
+    key = f"{args.mode}_{T}x{A}x{D}" + ("_bp" if args.by_particle else "") + ("_hfft" if args.helfand_fft else "")
     roof["traffic"] = recorded_traffic(key)
+    try:
+        roof["kernels"] = kernel_split(ctx, case, torch)
+    except Exception as e:
+        roof["kernels"] = {"error": str(e)[:200]}
     workload = ({"fft": "FFT VACF", "direct": "windowed (direct) VACF",
                  "helfand": "Helfand MSD (FFT option)" if args.helfand_fft else "Helfand MSD"}[args.mode]
                 + (" with the by-particle array" if args.by_particle else " timeseries")
@@ -378,11 +523,15 @@ def main():
             "mode": args.mode, "by_particle": bool(args.by_particle), "sharding": f"atoms x{world}",
             "fft_plan": _lib.fft_plan_info(T), "input": "library device slab (pair-major), ta_stage_synth",
             "library_sha16": so_sha16(),
+            "rank_devices": rank_devices,
+            "collective": (dist.get_backend() if grouped else None),
         },
         "roofline": roof,
         "device_ms": {"whole_call_median": total_ms, "dominant_kernel_median": kernel_ms},
         "check": check,
     }
+    if reduce_us is not None:
+        out["reduce_us"] = reduce_us  # the all-reduce of the (n_frames,) lag sums alone, median per step
     if world == 1 and not args.no_other_configs and args.mode == "fft" and not args.by_particle:
         out["other_configs"] = other_configs(torch, dist, _lib, ctx, dev)
     if world == 1 and not args.no_host_path and args.mode == "fft":
@@ -390,13 +539,25 @@ def main():
             del case
             ctx.stage_free()
             ctx.trim()
+            torch.cuda.empty_cache()
+            out["staging"] = staging_cost(torch, ctx, dev, T, A, D)
+        except Exception as e:
+            out["staging"] = {"error": str(e)[:200]}
+        try:
+            ctx.stage_free()
+            ctx.trim()
+            torch.cuda.empty_cache()
             out["host_path"] = host_path(torch, _lib, local_rank, T, D)
         except Exception as e:
             out["host_path"] = {"error": str(e)[:200]}
+        try:
+            out["host_path_by_particle"] = host_path_by_particle(local_rank, T, D)
+        except Exception as e:
+            out["host_path_by_particle"] = {"error": str(e)[:200]}
     if world == 1 and not args.no_cpu_baseline and args.mode == "fft":
         out["cpu_baseline"] = cpu_baseline(args, T, D, a_total * D)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 
@@ -424,10 +585,17 @@ def other_configs(torch, dist, _lib, ctx, dev):
             el = timed(torch, dist, 1, steps, warm, c.step)
             hist = ctx.timing_history(steps)
             kms = statistics.median(m for _, m in hist)
-            r = roofline_of(c, kms, hfft, f32)
-            r["traffic"] = recorded_traffic(f"{mode}_{T}x{A}x3" + ("_bp" if byp else ""))
+            tms = statistics.median(t for t, _ in hist)
+            composite = byp or hfft  # several kernels share the work: price the whole call
+            r = roofline_of(c, tms if composite else kms, hfft, f32)
+            if composite:
+                r["kernel"] = "whole call"
+            r["traffic"] = recorded_traffic(f"{mode}_{T}x{A}x3" + ("_bp" if byp else "") + ("_hfft" if hfft else "")
+                                            + ("_f32" if f32 else ""))
+            r["kernels"] = kernel_split(ctx, c, torch)
             res.append({"workload": name, "ms_per_step": el / steps * 1e3, "steps": steps,
-                        "value": T * A / (el / steps), "unit": "lag-points/s", "roofline": r})
+                        "value": T * A / (el / steps), "unit": "lag-points/s",
+                        "device_ms": {"whole_call_median": tms, "dominant_kernel_median": kms}, "roofline": r})
             del c
         except Exception as e:
             res.append({"workload": name, "error": str(e)[:300]})

@@ -117,6 +117,17 @@ int ta_stage_synth(ta_ctx *ctx, int slab, uint64_t seed, int64_t col_offset, int
  * and the product slab of the "helfand_fft" option (the input's size).                        */
 int ta_trim(ta_ctx *ctx);
 
+/* ---- pinned host memory for result arrays ---------------------------------
+ * results.vacf_by_particle / results.visc_by_particle (velocityautocorr.py:145-147,
+ * viscosity.py:117-119) are (n_frames, n_atoms) float64: 8 GB at 10000 x 100000.  Into a pageable
+ * array the device->host copy of a host-facing call runs at ~16 GB/s the first time (the runtime
+ * pins the pages on first use), into pinned memory at the link's rate.  ta_host_alloc returns
+ * page-locked host memory that does NOT belong to a context (the result outlives the analysis
+ * object); the Python side wraps it as the NumPy array it hands out and frees it with
+ * ta_host_free when the last view dies.                                                   */
+int ta_host_alloc(int64_t n_bytes, void **h_out);
+int ta_host_free(void *h);
+
 /* ---- compute on staged slabs (host-facing, blocking) -------------------
  * ta_vacf_fft     : VelocityAutocorr._conclude_fft    (velocityautocorr.py:208-215,
  *                   incl. tidynamics.acf at :211-213)
@@ -172,6 +183,12 @@ int ta_last_timing(ta_ctx *ctx, float *total_ms, float *main_kernel_ms);
  * first (a caller times K calls back to back and reads the K durations afterwards);
  * *n_out = number of entries written.  Blocks until those calls have completed.      */
 int ta_timing_history(ta_ctx *ctx, int max_n, float *total_ms, float *main_kernel_ms, int *n_out);
+/* With the "timeline" option on, every compute call records an event before each of its kernel
+ * launches.  ta_kernel_timeline returns, for the last compute call, the device time per kernel
+ * NAME in order of first appearance (a kernel launched once per block of atoms is summed):
+ * names[i] (static strings owned by the library), ms[i], *n_out entries (<= max_n).  The sum is
+ * the call's total_ms.  Blocks until the call has completed.                              */
+int ta_kernel_timeline(ta_ctx *ctx, int max_n, const char **names, float *ms, int *n_out);
 /* FFT length bookkeeping for a given n_frames: *m_out = padded half-length M
  * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1): M = R * R0 * 512 with
  * R0 in {1,...,10,12,14,16,18,20} and the outer radix R = 1 up to 10240 frames (one on-chip
@@ -208,7 +225,9 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *   "bp_spec_atoms" n : FFT path with a by-particle array: atoms per block of power spectra
  *                      (scratch = n * 16 * M bytes; 0 = as many as fit 2.5 GiB);
  *   "bp_prefetch" 0..3 : sub-series of the next atom's spectrum the inverse kernel requests
- *                      ahead (default 2).   Unknown keys return TA_E_INVALID.             */
+ *                      ahead (default 2);
+ *   "timeline" 0|1   : record an event before every kernel launch of a compute call
+ *                      (ta_kernel_timeline).   Unknown keys return TA_E_INVALID.          */
 int ta_set_option(ta_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

@@ -31,24 +31,41 @@ class OracleContext:
             pos = hi
         assert pos == self.shape[0], "not every frame was committed to the device"
 
-    def vacf_fft(self, by_particle=False):
+    class _Home:
+        def __init__(self, shape):
+            self.arr = np.empty(shape)
+
+        def get(self):
+            return self.arr
+
+    def result_home(self, shape):
+        return self._Home(shape)
+
+    @staticmethod
+    def _out(bp, by_particle, out):
+        if out is not None:
+            out[...] = bp
+            return out
+        return bp if by_particle else None
+
+    def vacf_fft(self, by_particle=False, out=None):
         self._covered()
         bp, ts = orc.vacf_fft_batched(self.slabs[0])
-        return ts, (bp if by_particle else None)
+        return ts, self._out(bp, by_particle, out)
 
-    def vacf_direct(self, by_particle=False):
+    def vacf_direct(self, by_particle=False, out=None):
         self._covered()
         bp, ts = orc.vacf_windowed(self.slabs[0])
-        return ts, (bp if by_particle else None)
+        return ts, self._out(bp, by_particle, out)
 
-    def helfand_msd(self, masses, scale, by_particle=False):
+    def helfand_msd(self, masses, scale, by_particle=False, out=None):
         self._covered()
         T = self.shape[0]
         # scale = 1/(2 kB <V> T): feed the oracle a unit denominator and rescale
         bp, ts = orc.helfand(self.slabs[0], self.slabs[1], masses, np.ones(T), temp_avg=1.0,
                              boltzmann=0.5)
         bp, ts = bp * scale, ts * scale
-        return ts, (bp if by_particle else None)
+        return ts, self._out(bp, by_particle, out)
 
     def set_option(self, key, value):
         self.options = getattr(self, 'options', {})

@@ -71,6 +71,74 @@ def test_classes_distributed_two_ranks_one_gpu(tmp_path, T, A):
             assert scale_rel_err(z["visc_bp"], hbp[:, lo:hi]) < TOL
 
 
+def _worker_nccl(rank, world, port, T, A, out_dir):
+    """One rank, nccl (= RCCL) process group: the branch every real multi-GPU run of the classes
+    takes -- lag sums produced into a device tensor on torch's stream
+    (dist.staged_timeseries_on_device), all-reduced on the device, by-particle block copied back."""
+    import torch
+    import torch.distributed as dist
+
+    from oracle import numpy_oracle as orc
+    from transport_analysis_amd import VelocityAutocorr, ViscosityHelfand, dist as tad
+    from transport_analysis_amd._mini_mda import ArrayUniverse
+
+    os.environ.pop("TA_AMD_DEVICE", None)
+    os.environ["LOCAL_RANK"] = "0"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            device_id=torch.device("cuda", 0))
+    assert tad.uses_device_reduce() and tad.default_device() == 0
+    v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=77)
+    u = ArrayUniverse(positions=x, velocities=v, masses=m, dimensions=[60, 60, 60, 90, 90, 90])
+    out = {}
+    for fft in (True, False):
+        for byp in (True, False):
+            a = VelocityAutocorr(u.atoms, fft=fft, distributed=True, by_particle=byp).run()
+            out[f"vacf_ts_{int(fft)}_{int(byp)}"] = a.results.timeseries
+            if byp:
+                out[f"vacf_bp_{int(fft)}"] = a.results.vacf_by_particle
+            out["range"] = np.array(a.results.particle_range)
+    for kw, tag in (({}, "f64"), ({"float32": True}, "f32"), ({"fft": True}, "fft")):
+        h = ViscosityHelfand(u.atoms, distributed=True, **kw).run()
+        out[f"visc_ts_{tag}"] = h.results.timeseries
+        out[f"visc_bp_{tag}"] = h.results.visc_by_particle
+    h = ViscosityHelfand(u.atoms, distributed=True, by_particle=False).run()
+    out["visc_ts_nobp"] = h.results.timeseries
+    # the collective itself, on a device tensor
+    t = torch.arange(5, dtype=torch.float64, device="cuda")
+    out["reduced"] = tad.reduce_lagsum(t, 2).cpu().numpy()
+    np.savez(os.path.join(out_dir, "nccl_0.npz"), **out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T,A", [(700, 9), (1500, 4)])
+def test_classes_distributed_rccl_world_size_one(tmp_path, T, A):
+    """The nccl branch of both classes on one GPU (world size 1): RCCL is loaded and runs the
+    all-reduce; results against the oracle to the north-star tolerance."""
+    import torch.multiprocessing as mp
+
+    from oracle import numpy_oracle as orc
+
+    port = 36500 + (os.getpid() % 2000) + A
+    mp.spawn(_worker_nccl, args=(1, port, T, A, str(tmp_path)), nprocs=1, join=True)
+    z = np.load(tmp_path / "nccl_0.npz", allow_pickle=True)
+    v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=77)
+    v32 = v.astype(np.float32).astype(np.float64)
+    x32 = x.astype(np.float32).astype(np.float64)
+    want_bp, want_ts = orc.vacf_fft_batched(v32)
+    hbp, hts = orc.helfand(v32, x32, m, np.full(T, 60.0**3), 300.0)
+    assert tuple(z["range"]) == (0, A)
+    for fft in (0, 1):
+        for byp in (0, 1):
+            assert scale_rel_err(z[f"vacf_ts_{fft}_{byp}"], want_ts) < TOL
+        assert scale_rel_err(z[f"vacf_bp_{fft}"], want_bp) < TOL
+    for tag, tol in (("f64", TOL), ("fft", TOL), ("f32", 2e-6)):
+        assert scale_rel_err(z[f"visc_ts_{tag}"], hts) < tol
+        assert scale_rel_err(z[f"visc_bp_{tag}"], hbp) < tol
+    assert scale_rel_err(z["visc_ts_nobp"], hts) < TOL
+    assert np.array_equal(z["reduced"], np.arange(5) / 2.0)
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_two_ranks_rehearsal_on_one_gpu(scaling):
     """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one JSON line from
@@ -96,3 +164,27 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(scaling):
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["config"]["n_atoms_total"] == total
     assert d["value"] == pytest.approx(2000 * total / (d["ms_per_step"] * 1e-3), rel=1e-9)
     assert d["roofline"]["frac"] > 0 and d["config"]["sharding"] == "atoms x2"
+    assert len(d["config"]["rank_devices"]) == 2 and d["reduce_us"] > 0
+
+
+def test_bench_one_rank_under_rccl():
+    """bench.py launched the way the driver launches N > 1, with ONE rank: the nccl (RCCL) branch
+    of the step -- device lag sums all-reduced on the device -- runs and is timed (`reduce_us`)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TA_BENCH_FORCE_DIST="1")
+    port = 35500 + (os.getpid() % 1000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", "1", "--steps", "3", "--warmup", "1", "--frames", "2000", "--atoms", "3000",
+           "--no-cpu-baseline", "--no-other-configs", "--no-host-path"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["collective"] == "nccl" and len(d["config"]["rank_devices"]) == 1
+    assert d["reduce_us"] > 0 and d["check"]["max_scale_rel_err_vs_torch_lags"] < 1e-10

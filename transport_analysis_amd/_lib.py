@@ -25,7 +25,8 @@ EXPORTS = (
     "ta_vacf_fft", "ta_vacf_direct", "ta_helfand_msd",
     "ta_vacf_fft_dev", "ta_vacf_direct_dev", "ta_helfand_msd_dev",
     "ta_vacf_fft_staged", "ta_vacf_direct_staged", "ta_helfand_msd_staged",
-    "ta_last_timing", "ta_timing_history", "ta_fft_plan_info", "ta_set_option",
+    "ta_last_timing", "ta_timing_history", "ta_kernel_timeline", "ta_fft_plan_info", "ta_set_option",
+    "ta_host_alloc", "ta_host_free",
 )
 
 
@@ -113,6 +114,10 @@ def lib():
     L.ta_last_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     L.ta_timing_history.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                     ctypes.POINTER(ci)]
+    L.ta_kernel_timeline.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
+                                     ctypes.POINTER(ci)]
+    L.ta_host_alloc.argtypes = [i64, ctypes.POINTER(vp)]
+    L.ta_host_free.argtypes = [vp]
     L.ta_fft_plan_info.argtypes = [i64, ctypes.POINTER(i64), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.ta_set_option.argtypes = [vp, ctypes.c_char_p, i64]
     for name in EXPORTS:
@@ -136,6 +141,62 @@ def fft_plan_info(n_frames):
 
 def _ptr(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else ctypes.c_void_p(None)
+
+
+class _PinnedBlock:
+    """Owner of one ta_host_alloc block: freed when the last NumPy view of it is gone."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().ta_host_free(ctypes.c_void_p(self.ptr))
+                self.ptr = 0
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """np.empty in page-locked host memory (ta_host_alloc): the home of results.vacf_by_particle /
+    results.visc_by_particle, so that the device->host copy runs at the link's rate the first
+    time.  The memory lives as long as the array or any view of it."""
+    shape = tuple(int(x) for x in np.atleast_1d(shape))
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    p = ctypes.c_void_p()
+    rc = lib().ta_host_alloc(nbytes, ctypes.byref(p))
+    if rc != 0:
+        raise TAError(rc, lib().ta_last_error(None).decode())
+    buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
+    buf._owner = _PinnedBlock(p.value)  # the ctypes array is the NumPy array's base
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+
+
+class PinnedResult:
+    """The pinned home of a by-particle result, allocated on a helper thread while the frames
+    are staged (page-locking 8 GB takes about as long as copying them); `get()` joins."""
+
+    def __init__(self, shape):
+        import threading
+
+        self._arr, self._err = None, None
+
+        def work():
+            try:
+                self._arr = pinned_empty(shape)
+            except Exception as e:  # surfaced by get()
+                self._err = e
+
+        self._thread = threading.Thread(target=work, daemon=True)
+        self._thread.start()
+
+    def get(self):
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+        return self._arr
 
 
 class Context:
@@ -169,6 +230,10 @@ class Context:
 
     def set_option(self, key, value):
         self._check(lib().ta_set_option(self._h, key.encode(), int(value)))
+
+    def result_home(self, shape):
+        """Start page-locking the by-particle result array of `shape`; `.get()` returns it."""
+        return PinnedResult(shape)
 
     # -- staging --------------------------------------------------------
     def stage_alloc(self, n_frames, n_atoms, dim, n_slabs=1, dtype=np.float64):
@@ -233,22 +298,30 @@ class Context:
         self._check(lib().ta_stage_free(self._h))
 
     # -- host-facing compute -------------------------------------------
-    def _host(self, fn, by_particle, *extra):
+    def _host(self, fn, by_particle, *extra, out=None):
+        """by_particle: False, True (a pinned (n_frames, n_atoms) array is allocated here) or
+        `out` = the caller's (n_frames, n_atoms) float64 C-contiguous array (pinned_empty)."""
         T, A, _ = getattr(self, "shape", None) or (1, 1, 1)  # unstaged: the library reports it
         ts = np.empty(T, dtype=np.float64)
-        bp = np.empty((T, A), dtype=np.float64) if by_particle else None
+        bp = None
+        if out is not None:
+            if out.shape != (T, A) or out.dtype != np.float64 or not out.flags.c_contiguous:
+                raise ValueError("out must be a C-contiguous float64 array of shape (n_frames, n_atoms)")
+            bp = out
+        elif by_particle:
+            bp = pinned_empty((T, A))
         self._check(fn(self._h, *extra, _ptr(ts), _ptr(bp)))
         return ts, bp
 
-    def vacf_fft(self, by_particle=False):
-        return self._host(lib().ta_vacf_fft, by_particle)
+    def vacf_fft(self, by_particle=False, out=None):
+        return self._host(lib().ta_vacf_fft, by_particle, out=out)
 
-    def vacf_direct(self, by_particle=False):
-        return self._host(lib().ta_vacf_direct, by_particle)
+    def vacf_direct(self, by_particle=False, out=None):
+        return self._host(lib().ta_vacf_direct, by_particle, out=out)
 
-    def helfand_msd(self, masses, scale, by_particle=False):
+    def helfand_msd(self, masses, scale, by_particle=False, out=None):
         m = np.ascontiguousarray(masses, dtype=np.float64)
-        return self._host(lib().ta_helfand_msd, by_particle, _ptr(m), ctypes.c_double(scale))
+        return self._host(lib().ta_helfand_msd, by_particle, _ptr(m), ctypes.c_double(scale), out=out)
 
     # -- device-pointer compute (asynchronous) --------------------------
     def vacf_fft_dev(self, d_vel, n_frames, n_atoms, dim, ld_row, d_lagsum, d_bp=0, ld_bp=0, stream=0):
@@ -283,6 +356,14 @@ class Context:
         m = (ctypes.c_float * max_n)()
         self._check(lib().ta_timing_history(self._h, max_n, t, m, ctypes.byref(n)))
         return [(t[i], m[i]) for i in range(n.value)]
+
+    def kernel_timeline(self, max_n=32):
+        """[(kernel name, ms)] of the last compute call (needs set_option("timeline", 1))."""
+        n = ctypes.c_int()
+        names = (ctypes.c_char_p * max_n)()
+        ms = (ctypes.c_float * max_n)()
+        self._check(lib().ta_kernel_timeline(self._h, max_n, names, ms, ctypes.byref(n)))
+        return [(names[i].decode(), ms[i]) for i in range(n.value)]
 
     def last_timing(self):
         t, m = ctypes.c_float(), ctypes.c_float()

@@ -53,6 +53,21 @@ struct ta_ctx {
     hipEvent_t ev_stage = nullptr;  // orders a caller's stream behind the staging stream
     long n_calls = 0;  // compute calls completed (their events recorded)
     bool timing_valid = false;
+    // kernel timeline of the last compute call ("timeline" option): an event before every
+    // launch, a last one at the end; segment i = [mark i, mark i + 1) belongs to name i
+    struct Mark {
+        const char* name;
+        hipEvent_t ev;
+    };
+    std::vector<Mark> marks;
+    std::vector<hipEvent_t> mark_pool;
+    size_t marks_used = 0;
+    int64_t opt_timeline = 0;
+    // staging: second landing buffer + stream, so that a piece crosses PCIe while the one before
+    // it is transposed
+    DevBuf bounce2;
+    hipStream_t relayout_stream = nullptr;
+    hipEvent_t ev_piece[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     // options
     int64_t opt_fft_nwg = 0;
     int64_t opt_direct_nwg = 0;
@@ -93,6 +108,22 @@ int ensure(ta_ctx* ctx, DevBuf& b, size_t bytes) {
     TA_HIP_TRY(ctx, hipMalloc(&b.p, bytes));
     b.bytes = bytes;
     return TA_OK;
+}
+
+// timeline mark: the work queued on `st` from here to the next mark is `name`'s
+void tl_mark(ta_ctx* ctx, const char* name, hipStream_t st) {
+    if (!ctx->opt_timeline) return;
+    if (ctx->marks_used == ctx->mark_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        ctx->mark_pool.push_back(e);
+    }
+    hipEvent_t e = ctx->mark_pool[ctx->marks_used++];
+    if (hipEventRecord(e, st) == hipSuccess) ctx->marks.push_back({name, e});
+}
+void tl_reset(ta_ctx* ctx) {
+    ctx->marks.clear();
+    ctx->marks_used = 0;
 }
 
 inline int64_t pm_pitch(int64_t n_frames) { return (n_frames + 7) / 8 * 8; }
@@ -188,14 +219,20 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         if ((rc = ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp))) return rc;
         bp_am = (double*)ctx->bp_scratch.p;
     }
+    tl_mark(ctx, "memset", st);
     TA_HIP_TRY(ctx, hipMemsetAsync(ctx->ts_partial.p, 0, sizeof(double) * rows * T, st));
+    tl_mark(ctx, "k_direct", st);
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     TA_HIP_TRY(ctx, launch_direct(mode, f32, src_f32, L, d_vel, d_pos, d_masses, pitch, (int)T, A, D, scale, bp_am,
                                   Tp, (double*)ctx->ts_partial.p, (int)nwg, nt, lds, stage_buf,
                                   gnt, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+    tl_mark(ctx, "k_sum_partials", st);
     TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)rows, T, d_lagsum, st));
-    if (d_bp) TA_HIP_TRY(ctx, launch_bp_transpose(bp_am, Tp, A, T, d_bp, ld_bp, nullptr, st));
+    if (d_bp) {
+        tl_mark(ctx, "k_bp_transpose", st);
+        TA_HIP_TRY(ctx, launch_bp_transpose(bp_am, Tp, A, T, d_bp, ld_bp, nullptr, st));
+    }
     return TA_OK;
 }
 
@@ -235,14 +272,17 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
             const int n_parts = (int)(4 * nwg);
             if ((rc = ensure(ctx, ctx->partial, sizeof(double) * (size_t)n_parts * L))) return rc;
             if ((rc = ensure(ctx, ctx->spec, sizeof(double) * (size_t)L))) return rc;
+            tl_mark(ctx, "k_w1_accum", st);
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
             TA_HIP_TRY(ctx, launch_w1_accum((int)nwg, st, pm, pitch, (int)T, n_pairs, tw, (double*)ctx->partial.p));
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+            tl_mark(ctx, "k_wf_sum+k_wf_fold+k_wf_lags", st);
             TA_HIP_TRY(ctx, launch_wfft_finish(R0, (const double*)ctx->partial.p, n_parts, tw, (int)T,
                                                (double*)ctx->spec.p, d_lagsum, st));
             return TA_OK;
         }
         const int64_t nwg = std::max<int64_t>(1, std::min(cap, (A + 3) / 4));  // a wave per atom
+        tl_mark(ctx, "k_w1_bp", st);
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
         TA_HIP_TRY(ctx, launch_w1_bp((int)nwg, st, pm, pitch, (int)T, A, D, tw, (double*)ctx->bp_scratch.p, Tp));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
@@ -250,12 +290,15 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         const int64_t nwg = forward_grid(n_pairs), n_tuples = nwg / (2 * R);
         if ((rc = ensure(ctx, ctx->partial, sizeof(double) * (size_t)n_tuples * L))) return rc;
         if ((rc = ensure(ctx, ctx->spec, sizeof(double) * (size_t)L))) return rc;
+        tl_mark(ctx, "k_wsplit_accum", st);
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
         TA_HIP_TRY(ctx, launch_wfft_forward(R0, R, false, (int)nwg, st, pm, pitch, (int)T, n_pairs, D, tw,
                                             (double*)ctx->partial.p));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
         // the summed spectrum -> lag sums: ONE inverse transform per launch
+        tl_mark(ctx, "k_sum_partials", st);
         TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->partial.p, (int)n_tuples, L, (double*)ctx->spec.p, st));
+        tl_mark(ctx, "k_winverse", st);
         TA_HIP_TRY(ctx, launch_wfft_inverse(R0, R, 1, st, (const double*)ctx->spec.p, (int)T, 1, tw, d_lagsum, 0, 0));
         return TA_OK;
     } else {
@@ -273,17 +316,21 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         for (int64_t a0 = 0; a0 < A; a0 += CA) {
             const int64_t ca = std::min(CA, A - a0);
             const int64_t groups = D & 1 ? (ca + 1) / 2 : ca;  // a tuple of workgroups per group of atoms
+            tl_mark(ctx, "k_wsplit_accum", st);
             TA_HIP_TRY(ctx, launch_wfft_forward(R0, R, true, (int)forward_grid(groups), st,
                                                 pm + (a0 * D / 2) * pitch * 2, pitch, (int)T, ca, D, tw,
                                                 (double*)ctx->bp_spec.p));
+            tl_mark(ctx, "k_winverse", st);
             TA_HIP_TRY(ctx, launch_wfft_inverse(R0, R, (int)std::min<int64_t>(cap, ca), st,
                                                 (const double*)ctx->bp_spec.p, (int)T, ca, tw,
                                                 (double*)ctx->bp_scratch.p + a0 * Tp, Tp, (int)ctx->opt_bp_prefetch));
         }
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     }
+    tl_mark(ctx, "k_bp_transpose", st);
     TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp,
                                         (double*)ctx->ts_partial.p, st));
+    tl_mark(ctx, "k_sum_partials", st);
     TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)n_tiles, T, d_lagsum, st));
     return TA_OK;
 }
@@ -307,9 +354,12 @@ int helfand_impl(ta_ctx* ctx, const double* pm_vel, const double* pm_pos, const 
         double* Q = Qpart + (size_t)n_parts * T;
         double* S2 = Q + T;
         double* C = S2 + T;
+        tl_mark(ctx, "k_helfand_product", st);
         TA_HIP_TRY(ctx, launch_helfand_product(pm_vel, pm_pos, d_masses, pitch, T, n_cols, D, P, Qpart, n_parts, st));
+        tl_mark(ctx, "k_sum_partials", st);
         TA_HIP_TRY(ctx, launch_sum_partials(Qpart, n_parts, T, Q, st));
         if ((rc = fft_impl(ctx, P, pitch, T, A, D, S2, nullptr, 0, st))) return rc;
+        tl_mark(ctx, "k_helfand_combine", st);
         TA_HIP_TRY(ctx, launch_helfand_combine(Q, S2, C, (int)T, scale / (double)D, d_lagsum, st));
         return TA_OK;
     }
@@ -320,9 +370,12 @@ int helfand_impl(ta_ctx* ctx, const double* pm_vel, const double* pm_pos, const 
         double* Ca = (double*)ctx->helf_small.p;
         if (n_cols & 1)  // the unpaired last column's partner is never written by the product kernel
             TA_HIP_TRY(ctx, hipMemsetAsync(P + (size_t)(n_pairs - 1) * pitch * 2, 0, (size_t)pitch * 16, st));
+        tl_mark(ctx, "k_helfand_product", st);
         TA_HIP_TRY(ctx, launch_helfand_product_bp(pm_vel, pm_pos, d_masses, pitch, T, A, D, P, Ca, st));
         if ((rc = fft_impl(ctx, P, pitch, T, A, D, d_lagsum, d_bp, ld_bp, st))) return rc;
+        tl_mark(ctx, "k_helfand_combine", st);
         TA_HIP_TRY(ctx, launch_helfand_combine_bp(Ca, A, (int)T, scale / (double)D, d_bp, ld_bp, st));
+        tl_mark(ctx, "k_row_sums", st);
         TA_HIP_TRY(ctx, launch_row_sums(d_bp, T, A, ld_bp, d_lagsum, st));
         return TA_OK;
     }
@@ -341,6 +394,7 @@ int compute_pm(ta_ctx* ctx, int which, const void* pm_vel_any, const void* pm_po
     if (record_start) {
         ctx->ev = ctx->ring[ctx->n_calls % ta_ctx::kRing];
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+        tl_reset(ctx);
     }
     // float32 device slabs are read as they are by the float32 direct correlators; every other
     // evaluation works on a float64 copy (same layout) in the context's scratch slabs
@@ -352,6 +406,7 @@ int compute_pm(ta_ctx* ctx, int which, const void* pm_vel_any, const void* pm_po
         for (int k = 0; k < 2; ++k) {
             if (!src[k]) continue;
             if ((rc = ensure(ctx, ctx->pm_in[k], n_el * sizeof(double)))) return rc;
+            tl_mark(ctx, "k_widen_f32", st);
             TA_HIP_TRY(ctx, launch_widen_f32((const float*)src[k], (double*)ctx->pm_in[k].p, (long)n_el, st));
         }
         pm_vel_any = ctx->pm_in[0].p;
@@ -371,6 +426,7 @@ int compute_pm(ta_ctx* ctx, int which, const void* pm_vel_any, const void* pm_po
                          ld_bp, st, true);
     else rc = helfand_impl(ctx, pm_vel, pm_pos, d_masses, pitch, T, A, D, scale, d_lagsum, d_bp, ld_bp, st);
     if (rc) return rc;
+    tl_mark(ctx, "end", st);
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[3], st));
     ctx->timing_valid = true;
     ++ctx->n_calls;
@@ -382,6 +438,7 @@ int relayout_input(ta_ctx* ctx, int k, const double* d_src, int64_t T, int64_t n
                    hipStream_t st, const double** out) {
     int rc = ensure(ctx, ctx->pm_in[k], pm_bytes(T, n_cols));
     if (rc) return rc;
+    tl_mark(ctx, "k_relayout", st);
     TA_HIP_TRY(ctx, launch_relayout(d_src, false, ld_row, n_cols, T, ctx->pm_in[k].p, false, pm_pitch(T), 0, st));
     *out = (const double*)ctx->pm_in[k].p;
     return TA_OK;
@@ -400,6 +457,7 @@ int dev_entry(ta_ctx* ctx, int which, const double* d_vel, const double* d_pos, 
     ctx->timing_valid = false;
     ctx->ev = ctx->ring[ctx->n_calls % ta_ctx::kRing];
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[0], st));
+    tl_reset(ctx);
     const double *pv = nullptr, *px = nullptr;
     if ((rc = relayout_input(ctx, 0, d_vel, T, A * D, ld_row, st, &pv))) return rc;
     if (which == W_HELFAND && (rc = relayout_input(ctx, 1, d_pos, T, A * D, ld_row, st, &px))) return rc;
@@ -434,7 +492,7 @@ int staged_entry(ta_ctx* ctx, int which, const double* d_masses, double scale, d
 
 extern "C" {
 
-int ta_abi_version(void) { return 2; }
+int ta_abi_version(void) { return 3; }
 
 int ta_device_count(void) {
     int n = 0;
@@ -479,6 +537,7 @@ int ta_stage_free(ta_ctx* ctx) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    if (ctx->relayout_stream) hipStreamSynchronize(ctx->relayout_stream);
     for (void* h : ctx->h_slabs)
         if (h) hipHostFree(h);
     for (double* d : ctx->d_slabs)
@@ -498,12 +557,19 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     for (auto& kv : ctx->wf_tables) hipFree(kv.second);
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
                       &ctx->masses, &ctx->bounce, &ctx->stage_buf, &ctx->helf_p,
-                      &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1], &ctx->bp_scratch, &ctx->bp_spec})
+                      &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1], &ctx->bp_scratch, &ctx->bp_spec,
+                      &ctx->bounce2})
         if (b->p) hipFree(b->p);
     for (auto& q : ctx->ring)
         for (auto& ev : q)
             if (ev) hipEventDestroy(ev);
     if (ctx->ev_stage) hipEventDestroy(ctx->ev_stage);
+    for (hipEvent_t e : ctx->mark_pool) hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->ev_piece[i]) hipEventDestroy(ctx->ev_piece[i]);
+        if (ctx->ev_done[i]) hipEventDestroy(ctx->ev_done[i]);
+    }
+    if (ctx->relayout_stream) hipStreamDestroy(ctx->relayout_stream);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -514,7 +580,7 @@ int ta_trim(ta_ctx* ctx) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
-    for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_bp, &ctx->bounce, &ctx->stage_buf,
+    for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_bp, &ctx->bounce, &ctx->bounce2, &ctx->stage_buf,
                       &ctx->helf_p, &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1],
                       &ctx->bp_scratch, &ctx->bp_spec})
         if (b->p) {
@@ -537,6 +603,7 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "bp_spec_atoms")) ctx->opt_bp_spec_atoms = value;
     else if (!strcmp(key, "bp_prefetch")) ctx->opt_bp_prefetch = value;
     else if (!strcmp(key, "stage_device_f32")) ctx->opt_stage_device_f32 = value;
+    else if (!strcmp(key, "timeline")) ctx->opt_timeline = value;
     else return fail(ctx, TA_E_INVALID, std::string("unknown option ") + key);
     return TA_OK;
 }
@@ -551,6 +618,25 @@ int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_st
     if (n_threads) *n_threads = wfft_threads(R0);
     if (n_stages) *n_stages = (R0 == 1 ? 3 : 4) + (R > 1 ? 1 : 0);
     return TA_OK;
+}
+
+/* --------------------------------------------- pinned host memory for results */
+int ta_host_alloc(int64_t n_bytes, void** h_out) {
+    if (!h_out || n_bytes < 0) return fail(nullptr, TA_E_INVALID, "bad argument");
+    *h_out = nullptr;
+    void* h = nullptr;
+    // portable: usable by every device's copy engines (the result outlives the context)
+    const hipError_t e = hipHostMalloc(&h, (size_t)std::max<int64_t>(n_bytes, 16), hipHostMallocPortable);
+    if (e != hipSuccess)
+        return fail(nullptr, TA_E_NOMEM, std::string("pinned host allocation failed: ") + hipGetErrorString(e));
+    *h_out = h;
+    return TA_OK;
+}
+
+int ta_host_free(void* h) {
+    if (!h) return TA_OK;
+    const hipError_t e = hipHostFree(h);
+    return e == hipSuccess ? TA_OK : fail(nullptr, TA_E_HIP, std::string("hipHostFree: ") + hipGetErrorString(e));
 }
 
 /* ------------------------------------------------------------------ staging */
@@ -617,22 +703,45 @@ int ta_stage_commit(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
     const size_t row = (size_t)ctx->st_A * ctx->st_D;
     const size_t esz = ctx->st_dtype == TA_F32 ? 4 : 8;
     if (frame_hi == frame_lo) return TA_OK;
-    // frames cross PCIe in their native width into a landing buffer (<= 64 MiB) and are
-    // transposed into the pair-major slab on the device (float32 widened on the way)
+    // frames cross PCIe in their native width into one of two landing buffers (<= 64 MiB each) and
+    // are transposed into the pair-major slab on the device (float32 widened on the way), on a
+    // second stream: piece i + 1 crosses PCIe while piece i is transposed
     const int64_t per = std::max<int64_t>(1, (int64_t)(((size_t)64 << 20) / (row * esz)));
     const int64_t chunk = std::min<int64_t>(per, frame_hi - frame_lo);
     int rc = ensure(ctx, ctx->bounce, (size_t)chunk * row * esz);
+    if (!rc) rc = ensure(ctx, ctx->bounce2, (size_t)chunk * row * esz);
     if (rc) return rc;
-    for (int i = 0; i < ctx->st_nslabs; ++i) {
-        for (int64_t f = frame_lo; f < frame_hi; f += chunk) {
-            const int64_t m = std::min(chunk, frame_hi - f);
-            const char* src = (const char*)ctx->h_slabs[i] + (size_t)f * row * esz;
-            TA_HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce.p, src, (size_t)m * row * esz, hipMemcpyHostToDevice,
-                                           ctx->stream));
-            TA_HIP_TRY(ctx, launch_relayout(ctx->bounce.p, ctx->st_dtype == TA_F32, (long)row, (long)row, m,
-                                            ctx->d_slabs[i], ctx->st_dev_f32, ctx->st_pitch, f, ctx->stream));
+    if (!ctx->relayout_stream) {
+        TA_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->relayout_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            TA_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_piece[i], hipEventDisableTiming));
+            TA_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
         }
     }
+    void* land[2] = {ctx->bounce.p, ctx->bounce2.p};
+    bool used[2] = {false, false};
+    // the slabs may still be read by work queued earlier on the context's stream
+    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
+    TA_HIP_TRY(ctx, hipStreamWaitEvent(ctx->relayout_stream, ctx->ev_stage, 0));
+    int piece = 0;
+    for (int i = 0; i < ctx->st_nslabs; ++i) {
+        for (int64_t f = frame_lo; f < frame_hi; f += chunk, ++piece) {
+            const int b = piece & 1;
+            const int64_t m = std::min(chunk, frame_hi - f);
+            const char* src = (const char*)ctx->h_slabs[i] + (size_t)f * row * esz;
+            if (used[b]) TA_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_done[b], 0));  // buffer free again
+            TA_HIP_TRY(ctx, hipMemcpyAsync(land[b], src, (size_t)m * row * esz, hipMemcpyHostToDevice, ctx->stream));
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev_piece[b], ctx->stream));
+            TA_HIP_TRY(ctx, hipStreamWaitEvent(ctx->relayout_stream, ctx->ev_piece[b], 0));
+            TA_HIP_TRY(ctx, launch_relayout(land[b], ctx->st_dtype == TA_F32, (long)row, (long)row, m,
+                                            ctx->d_slabs[i], ctx->st_dev_f32, ctx->st_pitch, f, ctx->relayout_stream));
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev_done[b], ctx->relayout_stream));
+            used[b] = true;
+        }
+    }
+    // whatever follows on the context's stream sees the transposed frames
+    for (int b = 0; b < 2; ++b)
+        if (used[b]) TA_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_done[b], 0));
     return TA_OK;
 }
 
@@ -739,6 +848,29 @@ int ta_timing_history(ta_ctx* ctx, int max_n, float* total_ms, float* main_kerne
         TA_HIP_TRY(ctx, hipEventElapsedTime(&m, q[1], q[2]));
         if (total_ms) total_ms[i] = t;
         if (main_kernel_ms) main_kernel_ms[i] = m;
+    }
+    *n_out = n;
+    return TA_OK;
+}
+
+int ta_kernel_timeline(ta_ctx* ctx, int max_n, const char** names, float* ms, int* n_out) {
+    if (!ctx || !n_out) return fail(ctx, TA_E_INVALID, "null argument");
+    *n_out = 0;
+    if (ctx->marks.size() < 2) return TA_OK;  // option off, or no call yet
+    TA_HIP_TRY(ctx, hipEventSynchronize(ctx->marks.back().ev));
+    std::vector<std::pair<const char*, float>> agg;  // by name, in order of first appearance
+    for (size_t i = 0; i + 1 < ctx->marks.size(); ++i) {
+        float d = 0.f;
+        TA_HIP_TRY(ctx, hipEventElapsedTime(&d, ctx->marks[i].ev, ctx->marks[i + 1].ev));
+        size_t j = 0;
+        while (j < agg.size() && strcmp(agg[j].first, ctx->marks[i].name)) ++j;
+        if (j == agg.size()) agg.push_back({ctx->marks[i].name, 0.f});
+        agg[j].second += d;
+    }
+    const int n = (int)std::min<size_t>(agg.size(), (size_t)std::max(0, max_n));
+    for (int i = 0; i < n; ++i) {
+        if (names) names[i] = agg[i].first;
+        if (ms) ms[i] = agg[i].second;
     }
     *n_out = n;
     return TA_OK;

@@ -3,6 +3,7 @@
 // VelocityAutocorr._conclude_fft, /root/reference/transport_analysis/velocityautocorr.py:208-215).
 #include "wfft.hpp"
 
+#include <algorithm>
 #include <vector>
 
 #include "ta_internal.hpp"
@@ -13,10 +14,21 @@ namespace {
 constexpr int kR0s[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20};
 constexpr int kOuter[] = {1, 2, 3, 4, 5, 8, 16};
 
+// the dynamic LDS limit of a kernel is set once per (kernel, device), not on every launch
+constexpr int kMaxDev = 16;
+inline int cur_dev() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d < 0 || d >= kMaxDev ? 0 : d;
+}
 template <class K>
-hipError_t set_lds(K kern, size_t bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes);
+hipError_t set_lds(K kern, size_t bytes, bool* done /* [kMaxDev], one array per kernel */) {
+    const int d = cur_dev();
+    if (done[d]) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done[d] = true;
+    return e;
 }
 
 template <int R0>
@@ -25,7 +37,8 @@ hipError_t launch_forward_r0(int R, bool byp, int nwg, hipStream_t st, const dou
     using P = WPlan<R0>;
     auto kern = byp ? (R > 1 ? k_wsplit_accum<P, true, true> : k_wsplit_accum<P, true, false>)
                     : (R > 1 ? k_wsplit_accum<P, false, true> : k_wsplit_accum<P, false, false>);
-    hipError_t e = set_lds(kern, P::kLds);
+    static bool done[4][kMaxDev];
+    hipError_t e = set_lds(kern, P::kLds, done[(byp ? 2 : 0) + (R > 1 ? 1 : 0)]);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_units, tw, accg, D, R, nullptr);
     return hipGetLastError();
@@ -36,25 +49,41 @@ hipError_t launch_inverse_r0(int R, int nwg, hipStream_t st, const double* spec,
                              double* out, long ld, int pf) {
     using P = WPlan<R0>;
     constexpr int NSA = P::NS1;
+    const int variant = R > 1 ? 0 : pf <= 0 ? 1 : pf == 1 ? 2 : pf == 2 ? 3 : 4;
     auto kern = R > 1    ? k_winverse<P, true, 0>
                 : pf <= 0 ? k_winverse<P, false, 0>
                 : pf == 1 ? k_winverse<P, false, 1>
                 : pf == 2 ? k_winverse<P, false, (NSA < 2 ? NSA : 2)>
                           : k_winverse<P, false, NSA>;
-    hipError_t e = set_lds(kern, P::kLds);
+    static bool done[5][kMaxDev];
+    hipError_t e = set_lds(kern, P::kLds, done[variant]);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, spec, T, n_items, tw, out, ld, R);
     return hipGetLastError();
 }
 
+// resident workgroups per compute unit of plan R0: the smallest over the forward kernel's four
+// variants (the grid of each must be fully resident: a tuple's workgroups wait for nobody, but
+// they share rows through the L2 only while they run together); asked once per device
 template <int R0>
 int max_wg_r0() {
     using P = WPlan<R0>;
-    auto kern = k_wsplit_accum<P, false, false>;
-    (void)set_lds(kern, P::kLds);
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, P::NT, P::kLds) != hipSuccess || n < 1) n = 1;
-    return n;
+    static int cached[kMaxDev];
+    const int d = cur_dev();
+    if (cached[d] > 0) return cached[d];
+    int best = 1 << 30;
+    auto ask = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)P::kLds);
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, P::NT, P::kLds) != hipSuccess || n < 1) n = 1;
+        best = std::min(best, n);
+    };
+    ask(k_wsplit_accum<P, false, false>);
+    ask(k_wsplit_accum<P, false, true>);
+    ask(k_wsplit_accum<P, true, false>);
+    ask(k_wsplit_accum<P, true, true>);
+    return cached[d] = best;
 }
 
 // spec[k] = sum over workgroups of their natural-order accumulator blocks, k < L2 = 2M
@@ -151,7 +180,7 @@ int wfft_threads(int R0) {
         case 18: return WPlan<18>::NT;
         case 20: return WPlan<20>::NT;
     }
-    return 64;
+    return W1::NT;  // R0 = 1: four independent waves per workgroup
 }
 
 int wfft_max_wg_per_cu(int R0) {
@@ -178,7 +207,8 @@ int wfft_max_wg_per_cu(int R0) {
 // R0 = 1 (n_frames <= 512): independent waves, 4 per workgroup; accg [4 nwg][1024]
 hipError_t launch_w1_accum(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
                            const cd* tw, double* accg) {
-    hipError_t e = set_lds(k_w1_accum, W1::kLds);
+    static bool done[kMaxDev];
+    hipError_t e = set_lds(k_w1_accum, W1::kLds, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_w1_accum, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_pairs, tw, accg);
     return hipGetLastError();
@@ -186,7 +216,8 @@ hipError_t launch_w1_accum(int nwg, hipStream_t st, const double* pm, long pitch
 
 hipError_t launch_w1_bp(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_atoms, int D,
                         const cd* tw, double* out, long ld) {
-    hipError_t e = set_lds(k_w1_bp, W1::kLds);
+    static bool done[kMaxDev];
+    hipError_t e = set_lds(k_w1_bp, W1::kLds, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_w1_bp, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_atoms, D, tw, out, ld);
     return hipGetLastError();

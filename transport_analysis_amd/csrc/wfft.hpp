@@ -726,7 +726,10 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
             stw.c[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + (18 + a) * 64) * 16u);
         }
     };
-    if constexpr (P::kTwResident) load_stage_tw();
+    // (the by-particle variant with an outer radix on the largest plan loads them again after every
+    // first stage instead: 32 registers it does not have while the outer rows are folded in)
+    constexpr bool kTwRes = P::kTwResident && !(BYP && LONG && R0 >= 20);
+    if constexpr (kTwRes) load_stage_tw();
     WfAddr wad;
     wad.init(lane, (unsigned)P::sub_base(wave) * kWfSubBytes);
     const WfSub wsub(wad, smem_raw);
@@ -768,16 +771,18 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                     base -= base >= L ? L : 0;
                     if (jo * M >= T) break;  // nothing but padding from here on
                     int idx = base;
-                    // four rows in flight at a time: all R0 at once would not fit next to x[]
+                    // NZ rows in flight at a time: all R0 at once would not fit next to x[] (four; the
+                    // by-particle variant with its unit kinds has room for two without scratch)
+                    constexpr int NZ = BYP ? 2 : 4;
 #pragma unroll
-                    for (int j0 = 0; j0 < R0; j0 += 4) {
-                        cd z[4];
+                    for (int j0 = 0; j0 < R0; j0 += NZ) {
+                        cd z[NZ];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < NZ; ++i)
                             if (j0 + i < R0)
                                 z[i] = load_row(crs, decltype(single)::value ? kind : 2, u, (unsigned)(N1 * (j0 + i) + M * jo));
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < NZ; ++i)
                             if (j0 + i < R0) {
                                 x[j0 + i] = wf_cfma(x[j0 + i], z[i], tw_uniform(tw2, idx));
                                 idx += sj;
@@ -824,7 +829,7 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
             }
         }
         }
-        if constexpr (!P::kTwResident) {
+        if constexpr (!kTwRes) {
             asm volatile("" : "+v"(lane));  // keeps the loads (and their registers) inside the loop
             load_stage_tw();
         }

@@ -30,7 +30,9 @@ def reduce_lagsum(lagsum, n_atoms_total, group=None):
     tensor with gloo); it is reduced in place and the mean is returned."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    # whenever a group is up, also of one rank: the collective (RCCL under the nccl backend) is
+    # then exercised by every distributed run, not only from two GPUs on
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(lagsum, op=dist.ReduceOp.SUM, group=group)
     return lagsum / float(n_atoms_total)
 

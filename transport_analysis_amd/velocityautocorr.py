@@ -128,6 +128,11 @@ class VelocityAutocorr(AnalysisBase):
         self._commit_every = max(1, _COMMIT_BYTES // frame_bytes)
         self._committed = 0
         self.results.vacf_by_particle = None
+        # the (n_frames, n_particles) result array (:145-147) lives in pinned host memory, page-locked
+        # on a helper thread while the frames are staged
+        self._bp_home = None
+        if self._want_by_particle and self._n_local and not self._device_reduce():
+            self._bp_home = self._ctx.result_home((self.n_frames, self._n_local))
         # results.timeseries is not set here (reference: :153)
 
     def _single_frame(self):
@@ -157,11 +162,18 @@ class VelocityAutocorr(AnalysisBase):
     def _conclude_simple(self):
         self._compute("direct")
 
+    def _device_reduce(self):
+        if not self._distributed:
+            return False
+        from .dist import uses_device_reduce
+
+        return uses_device_reduce()
+
     def _compute(self, which):
         if self._distributed:
-            from .dist import staged_timeseries_on_device, uses_device_reduce
+            from .dist import staged_timeseries_on_device
 
-            if uses_device_reduce():  # RCCL: the lag sums stay on the GPU through the reduce
+            if self._device_reduce():  # RCCL: the lag sums stay on the GPU through the reduce
                 ts, bp = staged_timeseries_on_device(self._ctx, which, self.n_frames, self._n_local,
                                                      self.n_particles, self._device,
                                                      by_particle=self._want_by_particle)
@@ -170,7 +182,9 @@ class VelocityAutocorr(AnalysisBase):
                 self._run_called = True
                 return
         fn = self._ctx.vacf_fft if which == "fft" else self._ctx.vacf_direct
-        ts, bp = fn(by_particle=self._want_by_particle)
+        home = self._bp_home.get() if self._bp_home is not None else None
+        self._bp_home = None
+        ts, bp = fn(by_particle=self._want_by_particle, out=home)
         self._store(ts, bp)
 
     def _store(self, ts, bp):

@@ -40,8 +40,8 @@ class ViscosityHelfand(AnalysisBase):
     fft : bool, keyword-only, default False — an extension (the reference has only the
         O(n_frames^2) loop): evaluate the mean squared differences in
         O(n_frames log n_frames) as ``S1(k) - 2 S2(k)`` (``S2`` = FFT autocorrelation of the
-        products ``m v x``, ``S1`` from prefix sums).  With the per-particle array this covers
-        n_frames <= 10240 (longer trajectories fall back to the direct correlator).  Accurate to ~1e-15 of the series' scale;
+        products ``m v x``, ``S1`` from prefix sums), with or without the per-particle array, for
+        n_frames <= 163840 (longer trajectories fall back to the direct correlator).  Accurate to ~1e-15 of the series' scale;
         lags whose mean squared difference is far below the squared products themselves lose
         relative accuracy by that ratio.
 
@@ -134,6 +134,16 @@ class ViscosityHelfand(AnalysisBase):
         self._commit_every = max(1, _COMMIT_BYTES // frame_bytes)
         self._committed = 0
         self.results.visc_by_particle = None
+        # pinned home of the (n_frames, n_particles) result (:117-119), page-locked on a helper thread
+        self._bp_home = None
+        if self._want_by_particle and self._n_local:
+            device_reduce = False
+            if self._distributed:
+                from .dist import uses_device_reduce
+
+                device_reduce = uses_device_reduce()
+            if not device_reduce:
+                self._bp_home = self._ctx.result_home((self.n_frames, self._n_local))
 
     def _single_frame(self):
         """Stage volume, velocities and positions of one frame (:167-199)."""
@@ -169,7 +179,9 @@ class ViscosityHelfand(AnalysisBase):
                                                  self.n_particles, self._device, masses=self._masses,
                                                  scale=scale, by_particle=self._want_by_particle)
         else:
-            ts, bp = self._ctx.helfand_msd(self._masses, scale, by_particle=self._want_by_particle)
+            home = self._bp_home.get() if self._bp_home is not None else None
+            self._bp_home = None
+            ts, bp = self._ctx.helfand_msd(self._masses, scale, by_particle=self._want_by_particle, out=home)
         if self._distributed and not device_reduce:
             from .dist import allreduce_mean_over_atoms
 
