@@ -143,6 +143,22 @@ def step_trajectory(nstep, start=0, stop=None, step=1):
 
 
 # ------------------------------------------------------------------- main
+OUT = HERE  # --check writes to a temporary directory instead
+
+
+def _docstring_vector(path, after, n):
+    """The n numbers of the first array(...) literal printed after the marker text `after`."""
+    import re
+
+    text = open(path, "r", encoding="utf8").read()
+    i = text.index(after)
+    j = text.index("array(", i)
+    body = text[j + 6:text.index(")", j)]
+    vals = [float(x) for x in re.findall(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?", body)]
+    assert len(vals) == n, (path, after, vals)
+    return vals
+
+
 def main():
     manifest = {}
     ref_tests = os.path.join(REF, "transport_analysis", "tests")
@@ -158,7 +174,7 @@ def main():
     VACF, VH = _import_reference_classes()
 
     def save(name, arr, source):
-        np.save(os.path.join(HERE, name), np.asarray(arr))
+        np.save(os.path.join(OUT, name), np.asarray(arr))
         manifest[name] = source
 
     # --- VACF step-trajectory polynomial (KAT), full and start/stop/step
@@ -186,7 +202,7 @@ def main():
     for (T, A, D, seed) in ((7, 1, 1, 11), (64, 5, 2, 12), (200, 33, 3, 13)):
         v = orc.synthetic_velocities(T, A, D, seed)
         tag = f"T{T}_A{A}_D{D}"
-        np.save(os.path.join(HERE, f"rand_vel_{tag}.npy"), v)
+        np.save(os.path.join(OUT, f"rand_vel_{tag}.npy"), v)
         manifest[f"rand_vel_{tag}.npy"] = f"numpy Philox({seed}) standard_normal (input)"
         bp, ts = run_ref_vacf(VACF, v, fft=False)
         save(f"ref_vacf_windowed_bp_{tag}.npy", bp, "reference _conclude_simple vacf_by_particle")
@@ -229,7 +245,7 @@ def main():
         v, x, m, vol = orc.synthetic_helfand(T, A, D, seed)
         vol = vol * (1.0 + 0.01 * np.sin(np.arange(T)))  # non-constant volume
         tag = f"T{T}_A{A}_D{D}"
-        np.savez(os.path.join(HERE, f"rand_helfand_in_{tag}.npz"), v=v, x=x, m=m, vol=vol)
+        np.savez(os.path.join(OUT, f"rand_helfand_in_{tag}.npz"), v=v, x=x, m=m, vol=vol)
         manifest[f"rand_helfand_in_{tag}.npz"] = f"synthetic_helfand(seed={seed}) (input)"
         res = run_ref_helfand(VH, v, x, m, vol, 313.0, fit_window=(2, T - 2))
         save(f"ref_helfand_bp_{tag}.npy", res.visc_by_particle,
@@ -252,13 +268,53 @@ def main():
         "helfand_notebook_step_N10_sum_over_dims": [0.0, 56426.98120794, 192868.75919739],
         # helfand_dev_toy_system.ipynb (stale: summed over dims; current code = these / 3)
         "boltzmann_kJ_per_mol_K": orc.BOLTZMANN_KJ_PER_MOL_K,
+        # BASELINE configs[0], "resname WAT and resid 1-5": the vector the reference's module
+        # docstring prints (velocityautocorr.py:39-43), read from the file
+        "ncbox_vacf_fft_WAT_resid_1_5": _docstring_vector(
+            os.path.join(REF, "transport_analysis", "velocityautocorr.py"), "wat_vacf.results.timeseries", 10),
     }
-    with open(os.path.join(HERE, "reference_constants.json"), "w") as fh:
+    with open(os.path.join(OUT, "reference_constants.json"), "w") as fh:
         json.dump(constants, fh, indent=1)
-    with open(os.path.join(HERE, "manifest.json"), "w") as fh:
+    with open(os.path.join(OUT, "manifest.json"), "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)
     print("wrote", len(manifest), "arrays")
 
 
+def check():
+    """Regenerate everything into a temporary directory and compare with the committed files:
+    arrays bit for bit, JSON by value.  Returns the list of differing file names."""
+    import filecmp
+    import tempfile
+
+    global OUT
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT = tmp
+        try:
+            main()
+        finally:
+            OUT = HERE
+        for name in sorted(os.listdir(tmp)):
+            a, b = os.path.join(tmp, name), os.path.join(HERE, name)
+            if not os.path.exists(b):
+                bad.append(name + " (not committed)")
+            elif name.endswith(".json"):
+                if json.load(open(a)) != json.load(open(b)):
+                    bad.append(name)
+            elif name.endswith(".npz"):
+                za, zb = np.load(a), np.load(b)
+                if set(za.files) != set(zb.files) or any(not np.array_equal(za[k], zb[k]) for k in za.files):
+                    bad.append(name)
+            elif not filecmp.cmp(a, b, shallow=False):
+                bad.append(name)
+        committed = {n for n in os.listdir(HERE) if n.endswith((".npy", ".npz", ".json"))}
+        bad += sorted(n + " (no longer generated)" for n in committed - set(os.listdir(tmp)))
+    return bad
+
+
 if __name__ == "__main__":
+    if "--check" in sys.argv[1:]:
+        diff = check()
+        print("golden files differ from a fresh generation:" if diff else "golden files reproduce", *diff)
+        sys.exit(1 if diff else 0)
     main()

@@ -266,6 +266,7 @@ def test_mdanalysis_parallel_backend_declaration():
         assert cls._analysis_algorithm_is_parallelizable is False
 
 
+@pytest.mark.gpu
 def test_ncbox_water_golden_vectors():
     """BASELINE configs[0]: VelocityAutocorr(fft=True) on MDAnalysisTests' PRM_NCBOX/TRJ_NCBOX
     water box through the REAL MDAnalysis AnalysisBase (plumbing).  Both vectors the reference
@@ -276,10 +277,8 @@ def test_ncbox_water_golden_vectors():
     pytest.importorskip("MDAnalysisTests")
     from MDAnalysisTests.datafiles import PRM_NCBOX, TRJ_NCBOX
 
-    from transport_analysis_amd import VelocityAutocorr, _lib
+    from transport_analysis_amd import VelocityAutocorr
 
-    if _lib.device_count() < 1:
-        pytest.skip("needs a GPU: the HIP path has no CPU fallback")
     import json
 
     const = json.load(open(os.path.join(GOLDEN, "reference_constants.json")))

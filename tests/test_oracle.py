@@ -194,3 +194,17 @@ def test_parallel_numpy_oracle_matches_one_core():
     assert n == 3 and seconds > 0
     np.testing.assert_allclose(lag, bp.sum(axis=1), rtol=0, atol=1e-12 * float(np.max(np.abs(bp))) * A)
     assert parallel.usable_cpus() >= 1
+
+
+def test_golden_files_reproduce_from_the_reference():
+    """tests/golden/make_golden.py --check: a fresh run of the reference's own code (build
+    container only: /root/reference does not exist on the GPU box) reproduces every committed
+    array bit for bit and every constant -- the fixtures and their generator do not drift."""
+    if not os.path.isdir("/root/reference/transport_analysis"):
+        pytest.skip("the reference is only present in the build container")
+    import subprocess
+    import sys
+
+    res = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py"), "--check"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
