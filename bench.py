@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-kernel-split", action="store_true",
+                    help="skip the extra untimed step that records the per-kernel event timeline")
     ap.add_argument("--cpu-sample-atoms", type=int, default=0)
     return ap.parse_args()
 
@@ -491,12 +493,14 @@ def main():
     roof = roofline_of(case, total_ms if composite else kernel_ms, args.helfand_fft, args.float32)
     if composite:
         roof["kernel"] = "whole call"
-    key = f"{args.mode}_{T}x{A}x{D}" + ("_bp" if args.by_particle else "") + ("_hfft" if args.helfand_fft else "")
+    key = (f"{args.mode}_{T}x{A}x{D}" + ("_bp" if args.by_particle else "") + ("_hfft" if args.helfand_fft else "")
+           + ("_f32" if args.float32 else ""))
     roof["traffic"] = recorded_traffic(key)
-    try:
-        roof["kernels"] = kernel_split(ctx, case, torch)
-    except Exception as e:
-        roof["kernels"] = {"error": str(e)[:200]}
+    if not args.no_kernel_split:
+        try:
+            roof["kernels"] = kernel_split(ctx, case, torch)
+        except Exception as e:
+            roof["kernels"] = {"error": str(e)[:200]}
     workload = ({"fft": "FFT VACF", "direct": "windowed (direct) VACF",
                  "helfand": "Helfand MSD (FFT option)" if args.helfand_fft else "Helfand MSD"}[args.mode]
                 + (" with the by-particle array" if args.by_particle else " timeseries")

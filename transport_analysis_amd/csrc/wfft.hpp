@@ -300,6 +300,17 @@ struct WPlan {
     static constexpr int K1 = (N1 + NT - 1) / NT;
     // (measured: trading the resident stage twiddles for a fourth wave per SIMD in the small plans
     // costs 5-10 %: 1000 frames 9.96 vs 9.26 ms, 2000 frames 10.56 vs 9.62 ms per 24 GB)
+    // Row requests of the next unit spread over S2 instead of one burst behind it (the burst: 20
+    // requests of 1 KiB per wave, 16 cycles each in the texture addresser, queue up in front of the
+    // barrier).  Measured per plan, same box (tools/wfft, -DWF_SPREAD_ALL=0/1): pays where ONE
+    // 8-wave workgroup owns the compute unit and two sub-series plus all row registers fit;
+    // the plans with several workgroups per unit overlap across workgroups already and lose
+    // 3-6 %; R0 = 18, 20 have no registers for it (three sub-series in flight, 96 registers).
+#ifndef WF_SPREAD_ALL
+    static constexpr bool kSpreadRows = R0 >= 9 && R0 <= 16;
+#else
+    static constexpr bool kSpreadRows = WF_SPREAD_ALL && R0 < 18;
+#endif
     static constexpr int kMinWavesPerSimd = 1;
     static constexpr bool kTwResident = true;
     static constexpr int M = R0 * N1;
@@ -541,53 +552,77 @@ struct WfSub {
 
 constexpr unsigned kWfSubBytes = 512 * sizeof(cd);  // one sub-series in LDS
 
+// `hook(part)`, part = integral_constant 0..3, is called at four points spread over the wave's
+// S2: the forward kernel requests a quarter of the next unit's rows at each (issued in one burst
+// behind S2, the 20 requests of every wave queue up in front of the barrier: the texture
+// addresser takes 16 cycles per 1-KiB request, 2.5k cycles per workgroup and unit)
+struct WfNoHook {
+    template <class T>
+    __device__ __forceinline__ void operator()(T) const {}
+};
+template <int I>
+using wf_part = std::integral_constant<int, I>;
+
 // sub-series S0 of the wave (its first one is 0)
-template <int S0>
-__device__ __forceinline__ void wf_sub512(const WfSub& w, const WfTw& tw, double (&acc)[8]) {
+template <int S0, class Hook = WfNoHook>
+__device__ __forceinline__ void wf_sub512(const WfSub& w, const WfTw& tw, double (&acc)[8], Hook&& hook = Hook{}) {
     cd v[8];
     w.read_a<S0 * kWfSubBytes>(v);
+    hook(wf_part<0>{});
     w.stage_a<S0 * kWfSubBytes>(v);
+    hook(wf_part<1>{});
     w.stage_b<S0 * kWfSubBytes>(v, tw);
+    hook(wf_part<2>{});
     w.stage_c(v, tw, acc);
+    hook(wf_part<3>{});
 }
 
 // Two sub-series (S0, S0 + 1) interleaved: while one's butterflies run, the other's exchange
 // (eight 16-byte stores, eight loads, ~300 cycles of LDS round trip) is in flight.
-template <int S0>
+template <int S0, class Hook = WfNoHook>
 __device__ __forceinline__ void wf_sub512_x2(const WfSub& w, const WfTw& tw, double (&acc0)[8],
-                                             double (&acc1)[8]) {
+                                             double (&acc1)[8], Hook&& hook = Hook{}) {
     constexpr unsigned A = S0 * kWfSubBytes, B = A + kWfSubBytes;
     cd v0[8], v1[8];
     w.read_a<A>(v0);
     w.read_a<B>(v1);
     __builtin_amdgcn_wave_barrier();
+    hook(wf_part<0>{});
     w.stage_a<A>(v0);
     w.stage_a<B>(v1);
+    hook(wf_part<1>{});
     w.stage_b<A>(v0, tw);
     w.stage_b<B>(v1, tw);
+    hook(wf_part<2>{});
     w.stage_c(v0, tw, acc0);
     w.stage_c(v1, tw, acc1);
+    hook(wf_part<3>{});
 }
 
 // Three sub-series interleaved (the waves that own one more than the others: they then finish
 // together with their SIMD partner's two instead of running a third alone).
+template <class Hook = WfNoHook>
 __device__ __forceinline__ void wf_sub512_x3(const WfSub& w, const WfTw& tw, double (&acc0)[8],
-                                             double (&acc1)[8], double (&acc2)[8]) {
+                                             double (&acc1)[8], double (&acc2)[8], Hook&& hook = Hook{}) {
     constexpr unsigned A = 0, B = kWfSubBytes, C = 2 * kWfSubBytes;
     cd v0[8], v1[8], v2[8];
     w.read_a<A>(v0);
     w.read_a<B>(v1);
     w.read_a<C>(v2);
     __builtin_amdgcn_wave_barrier();
+    hook(wf_part<0>{});
     w.stage_a<A>(v0);
     w.stage_a<B>(v1);
     w.stage_a<C>(v2);
+    hook(wf_part<1>{});
     w.stage_b<A>(v0, tw);
     w.stage_b<B>(v1, tw);
     w.stage_b<C>(v2, tw);
+    hook(wf_part<2>{});
     w.stage_c(v0, tw, acc0);
     w.stage_c(v1, tw, acc1);
     w.stage_c(v2, tw, acc2);
+    hook(wf_part<3>{});
 }
 
 // pm: pair-major slab, pair p at pm + p*pitch*2 doubles; T rows are valid, the rest of the
@@ -711,6 +746,27 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                 for (int j = 0; j < R0; ++j) xx[k1][j] = load_row(rs, kd, u, (unsigned)(N1 * j));
             }
         }
+    };
+#ifndef WF_LOAD_PARTS
+#define WF_LOAD_PARTS 4  // 1: all of the next unit's rows in one burst behind S2 (as before round 3)
+#endif
+    // Rows with linear index i = k1 R0 + j.  Plans with kSpreadRows request them along S2, a quarter
+    // at each hook point of the wave's first call; the others in one burst behind S2.
+    constexpr int NR = K1 * R0;
+    constexpr int NSPREAD = WF_LOAD_PARTS != 4 ? 0 : (P::kSpreadRows ? NR : 0);
+    auto issue_row = [&](auto ii, __amdgpu_buffer_rsrc_t rs, int kd) {
+        constexpr int i = decltype(ii)::value, k1 = i / R0, j = i % R0;
+        const int u = tid + NT * k1;
+        if (K1 * NT != N1 && u >= N1) return;
+        if (!BYP || kd == 2) xx[k1][j] = load_row(rs, 2, u, (unsigned)(N1 * j));
+        else xx[k1][j] = load_row(rs, kd, u, (unsigned)(N1 * j));
+    };
+    auto issue_loads_part = [&](auto part_c, __amdgpu_buffer_rsrc_t rs, int kd) {
+        constexpr int PART = decltype(part_c)::value;
+        static_for_range<PART * NSPREAD / 4, (PART + 1) * NSPREAD / 4>([&](auto ii) { issue_row(ii, rs, kd); });
+    };
+    auto issue_loads_tail = [&](__amdgpu_buffer_rsrc_t rs, int kd) {
+        static_for_range<NSPREAD, NR>([&](auto ii) { issue_row(ii, rs, kd); });
     };
     int kind = 2, nkind = 2;
     __amdgpu_buffer_rsrc_t crs = unit_rsrc(tuple * grp, 0, &kind);
@@ -852,12 +908,19 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
         }
         const int nk = last_of_item ? 0 : k + 1;
         const __amdgpu_buffer_rsrc_t nrs = unit_rsrc(nitem, nk, &nkind);
+        // the next unit's rows: a quarter at each of four points of the wave's (first) S2 call
+        auto row_hook = [&](auto part_c) {
+#if WF_LOAD_PARTS == 4 && WF_ABL != 3
+            issue_loads_part(part_c, nrs, nkind);
+#endif
+        };
 #if WF_ABL == 1
         if (T < 0)
 #endif
         if constexpr (NS1 == 3 && P::NLO == 2 && P::REM != 0) {
             // two full slots and a partial third: the waves that own three sub-series take them
-            // three at a time, the others two at a time
+            // three at a time, the others two at a time (no row requests along S2 in these plans:
+            // NSPREAD = 0)
             if (wave < P::REM) wf_sub512_x3(wsub, stw, acc[0], acc[1], acc[2]);
             else wf_sub512_x2<0>(wsub, stw, acc[0], acc[1]);
         } else {
@@ -867,10 +930,13 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                 constexpr bool nfull = s + 1 < P::NLO;                  // ... and the next one
                 constexpr bool head = full && nfull && (s % 2 == 0);
                 constexpr bool tail = full && s > 0 && (s % 2 == 1);
+                // (the row requests ride on the wave's first call: every wave has slot 0)
                 if constexpr (head) {
-                    wf_sub512_x2<s>(wsub, stw, acc[s], acc[s + 1]);
+                    if constexpr (s == 0) wf_sub512_x2<s>(wsub, stw, acc[s], acc[s + 1], row_hook);
+                    else wf_sub512_x2<s>(wsub, stw, acc[s], acc[s + 1]);
                 } else if constexpr (!tail) {
-                    if (full || wave < P::REM) wf_sub512<s>(wsub, stw, acc[s]);
+                    if constexpr (s == 0) wf_sub512<s>(wsub, stw, acc[s], row_hook);
+                    else if (full || wave < P::REM) wf_sub512<s>(wsub, stw, acc[s]);
                 }
             });
         }
@@ -905,7 +971,7 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
         }
         __builtin_amdgcn_sched_barrier(0);
 #if WF_ABL != 3
-        issue_loads(nrs, nkind);
+        issue_loads_tail(nrs, nkind);
 #endif
         kind = nkind, item = nitem, k = nk, crs = nrs;
         WF_STAMP(1)
