@@ -1010,3 +1010,94 @@ def test_vacf_by_particle_prefetch_depths(ctx, T, A, D):
         assert np.array_equal(bp, got[0][1]) and np.array_equal(ts, got[0][0])
     assert scale_rel_err(got[0][1], want_bp) < TOL
     assert scale_rel_err(got[0][0], want_ts) < TOL
+
+
+# ------------------------------------------- round 3: boundary additions
+def test_kernel_timeline_sums_to_the_call(ctx):
+    """ta_kernel_timeline ("timeline" option): per-kernel device time of the last call, named,
+    inside the call's total (events on the launch stream); off by default."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(3000, 300, 3, seed=3)
+    run_vacf(ctx, v, True, True)
+    assert ctx.kernel_timeline() == []  # option off: nothing recorded
+    ctx.set_option("timeline", 1)
+    try:
+        ts, bp = ctx.vacf_fft(by_particle=True)
+        tl = ctx.kernel_timeline()
+        names = [n for n, _ in tl]
+        assert names == ["k_wsplit_accum", "k_winverse", "k_bp_transpose", "k_sum_partials"]
+        total, _ = ctx.last_timing()
+        # the marks sit inside the call's own start / end events
+        assert 0.5 * total < sum(ms for _, ms in tl) <= 1.02 * total
+        ts2, _ = ctx.vacf_direct(by_particle=False)
+        assert [n for n, _ in ctx.kernel_timeline()] == ["memset", "k_direct", "k_sum_partials"]
+    finally:
+        ctx.set_option("timeline", 0)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
+    assert scale_rel_err(ts, want_ts) < TOL and scale_rel_err(bp, want_bp) < TOL
+
+
+def test_pinned_result_home(ctx):
+    """The by-particle array of a host-facing call lives in ta_host_alloc memory: written through
+    a caller-provided `out`, outliving the context's slabs, freed with its last view."""
+    import gc
+    import weakref
+
+    from oracle import numpy_oracle as orc
+    from transport_analysis_amd import _lib
+
+    T, A = 700, 130
+    v = orc.synthetic_velocities(T, A, 3, seed=8)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
+    home = _lib.pinned_empty((T, A))
+    assert home.shape == (T, A) and home.dtype == np.float64 and home.flags.c_contiguous
+    (slab,) = ctx.stage_alloc(T, A, 3)
+    slab[...] = v
+    ctx.stage_commit(0, T)
+    ts, bp = ctx.vacf_fft(out=home)
+    assert bp is home and scale_rel_err(bp, want_bp) < TOL and scale_rel_err(ts, want_ts) < TOL
+    ts, bp2 = ctx.vacf_direct(by_particle=True)  # allocated by the binding: pinned as well
+    assert scale_rel_err(bp2, want_bp) < TOL
+    with pytest.raises(ValueError):
+        ctx.vacf_fft(out=np.empty((T, A + 1)))
+    ctx.stage_free()
+    view = bp2[5:9, 3:7]
+    root = bp2
+    while isinstance(root, np.ndarray):  # reshape -> frombuffer -> the ctypes block
+        root = root.base
+    owner = weakref.ref(root._owner)
+    del bp2, root
+    gc.collect()
+    assert owner() is not None  # a view keeps the block alive
+    assert scale_rel_err(view, want_bp[5:9, 3:7]) < TOL
+    del view
+    gc.collect()
+    assert owner() is None
+    z = _lib.pinned_empty((0, 4))
+    assert z.shape == (0, 4)
+
+
+def test_stage_commit_through_both_landing_buffers(ctx):
+    """ta_stage_commit with more than two 64 MiB pieces per call and frames committed in several
+    calls: pieces alternate between two landing buffers, the transposition runs on its own stream;
+    every frame must land where the one-piece path puts it (read back bit for bit)."""
+    import torch
+
+    T, A, D = 120, 90000, 3  # 2.16 MB per float64 frame: 31 frames per piece
+    rng = np.random.default_rng(17)
+    (slab,) = ctx.stage_alloc(T, A, D)
+    slab[...] = rng.standard_normal((T, A, D))
+    keep = slab.copy()
+    ctx.stage_commit(0, 70)   # three pieces
+    ctx.stage_commit(70, 75)  # one small piece right behind
+    ctx.stage_commit(75, T)   # two pieces
+    back = torch.empty((T, A * D), dtype=torch.float64, device="cuda")
+    ctx.stage_read_dev(0, back.data_ptr(), A * D, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(back.cpu().numpy().reshape(T, A, D), keep)
+    ts, _ = ctx.vacf_fft(by_particle=False)
+    ref = (keep[:1] * keep[:1]).sum() / A  # lag T-1 has one term: <v0 . v_{T-1}>
+    assert ts[0] == pytest.approx((keep * keep).sum() / (T * A), rel=1e-12)
+    assert ts[T - 1] == pytest.approx((keep[0] * keep[T - 1]).sum() / A, rel=1e-10, abs=1e-12 * abs(ref))
+    ctx.stage_free()
