@@ -239,7 +239,10 @@ def cpu_baseline(args, T, D, n_cols_total):
     what = (f"oracle.numpy_oracle.vacf_fft on {T} frames x the first {a} atoms x {D} of the benchmark tensor "
             f"(oracle.synth, seed {SEED + 3})")
     out = {"value": T * a / dt, "unit": "lag-points/s", "cores": 1, "kind": "port", "sample": what,
-           "seconds": round(dt, 2)}
+           "seconds": round(dt, 2),
+           "note": "the reference itself cannot be timed here: it imports MDAnalysis and tidynamics, neither of "
+                   "which is installed on any box of this pool; the port restates its _conclude_fft (per-atom "
+                   "loop over tidynamics-style FFT autocorrelations) and is pinned by the reference's fixtures"}
     # second line, the "best CPU" figure: the same NumPy code in one process per usable CPU
     # (affinity mask capped by the cgroup quota), each on its own atoms of the same tensor
     try:
