@@ -22,8 +22,9 @@
 //   S2  512-point transforms of the R0 sub-series, ONE WAVE each, radix 8 x 8 x 8 with the data
 //       of a lane in registers and two exchanges through the sub-series' own 8 KiB of LDS: no
 //       workgroup barrier inside S2, so the waves of a SIMD drift apart and the LDS stores of
-//       one hide under the arithmetic of the other; the last radix-8 stage adds |.|^2 into the
-//       wave's register accumulators (bin s = q + R0 (a + 8 b + 64 cc) of the pass).
+//       one hide under the arithmetic of the other; the second and third stage take their
+//       twiddles BEFORE the butterfly, in tangent form (wf_dft8_tw); the last stage adds |.|^2
+//       into the wave's register accumulators (bin s = q + R0 (a + 8 b + 64 cc) of the pass).
 // A workgroup runs ONE pass; the 2R workgroups of a "tuple" (same XCD) walk the same units.
 // n_frames <= 512 has its own wave-independent kernels (end of this file).
 #pragma once
@@ -55,10 +56,6 @@ __device__ __forceinline__ void static_for_range(F&& f) {
 typedef unsigned int wf_u32x4 __attribute__((ext_vector_type(4)));
 
 #include "wfft_twist.inc"
-
-// the value is computed HERE: keeps the optimiser from sinking register-only work of one phase
-// of the forward kernel's software pipeline below the barrier that ends the phase
-__device__ __forceinline__ void wf_pin(double& a) { asm volatile("" : "+v"(a)); }
 
 // ---- first-stage DFTs that fft_engine.hpp does not have: radix 3 and the prime-factor
 // butterflies 2x3, 4x3, 2x5, 4x5 (no internal twiddles) --------------------------------------------
@@ -625,18 +622,16 @@ __device__ __forceinline__ void wf_sub512_x3(const WfSub& w, const WfTw& tw, dou
     hook(wf_part<3>{});
 }
 
-// pm: pair-major slab, pair p at pm + p*pitch*2 doubles; T rows are valid, the rest of the
-// transform length is zero padding.  accg: [gridDim.x][2M] float64, natural bin order.
-// tw2: W_2M^n, n < 2M, followed (at tw2 + 2M) by the wave-local stage twiddles [14][64]:
-// rows 0..6 = W_512^{lane (r+1)}, rows 7..13 = W_64^{(lane&7) (r-6)}.
-//
-// Software pipeline over (pair, pass): the 20 row loads of the NEXT pass are issued before the
-// barrier that ends the current one (they land while the slowest wave finishes), the 14 stage
-// twiddles of a wave are re-loaded from L2 after each first stage instead of being kept across
-// it: a first-stage butterfly's 80 data registers, the 80 accumulator registers and the 56
-// twiddle registers do not fit 256 together.
-// what the library instantiates (measured per build on the GPU: tools/wfft/wfft_test)
 // ================================================================================================
+// pm: pair-major slab, pair p at pm + p*pitch*2 doubles; T rows are valid, the rest of the
+// transform length is zero padding.  tw2: the plan's table (wf_fill_table): W_L^n, n < L, then
+// the stage constants.  accg: partial spectra (see below).
+//
+// Per unit: S1 (rows -> radix-R0 butterfly -> output twiddles -> LDS), barrier, S2 (the wave's
+// sub-series, |.|^2 into its accumulators), barrier.  The rows of the NEXT unit are requested
+// during S2 -- spread over it where the plan has the registers (WPlan::kSpreadRows), else in one
+// burst behind it -- and land while the slowest wave finishes.  The tangent-form constants of the
+// second and third radix-8 stage (32 registers per lane) stay resident for the whole launch.
 // Forward kernel: |transform|^2 of column units, accumulated per pass in registers.
 //
 // grid: a multiple of 16 R blocks, all resident.  Block b: XCD x = b & 7 (round-robin placement,

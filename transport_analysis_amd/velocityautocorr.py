@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._base import AnalysisBase, NoDataError, UpdatingAtomGroup, parse_dim_type
+from ._base import stage_columns, AnalysisBase, NoDataError, UpdatingAtomGroup, parse_dim_type
 
 #: frames staged on the host before an asynchronous host->device copy is queued
 _COMMIT_BYTES = 32 << 20
@@ -142,7 +142,7 @@ class VelocityAutocorr(AnalysisBase):
         i = self._frame_index
         vel = self.atomgroup.velocities
         if self._n_local:
-            self._velocities[i, : self._n_local] = vel[self._lo:self._hi][:, self._dim]
+            stage_columns(self._velocities[i], np.asarray(vel), self._lo, self._hi, self._dim)
         if i + 1 - self._committed >= self._commit_every:
             self._ctx.stage_commit(self._committed, i + 1)
             self._committed = i + 1

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._base import BOLTZMANN, AnalysisBase, NoDataError, UpdatingAtomGroup, parse_dim_type
+from ._base import stage_columns, BOLTZMANN, AnalysisBase, NoDataError, UpdatingAtomGroup, parse_dim_type
 
 _COMMIT_BYTES = 32 << 20
 
@@ -156,8 +156,8 @@ class ViscosityHelfand(AnalysisBase):
         i = self._frame_index
         self._volumes[i] = ts.volume
         if self._n_local:
-            self._velocities[i, : self._n_local] = self.atomgroup.velocities[self._lo:self._hi][:, self._dim]
-            self._positions[i, : self._n_local] = self.atomgroup.positions[self._lo:self._hi][:, self._dim]
+            stage_columns(self._velocities[i], np.asarray(self.atomgroup.velocities), self._lo, self._hi, self._dim)
+            stage_columns(self._positions[i], np.asarray(self.atomgroup.positions), self._lo, self._hi, self._dim)
         if i + 1 - self._committed >= self._commit_every:
             self._ctx.stage_commit(self._committed, i + 1)
             self._committed = i + 1
