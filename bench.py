@@ -529,7 +529,9 @@ def main():
         "config": {
             "workload": workload, "n_frames": T, "n_atoms_total": a_total, "n_atoms_this_rank": A, "dim": D,
             "mode": args.mode, "by_particle": bool(args.by_particle), "sharding": f"atoms x{world}",
-            "fft_plan": _lib.fft_plan_info(T), "input": "library device slab (pair-major), ta_stage_synth",
+            "fft_plan": _lib.fft_plan_info(T), "input": "library device slab (pair-major), ta_stage_synth: zero-mean unit-variance Irwin-Hall(8) "
+                                                        "variates of splitmix64 fields (integer sums: bit-identical "
+                                                        "NumPy twin oracle/synth.py), not SURVEY 8(d)'s Box-Muller normal",
             "library_sha16": so_sha16(),
             "rank_devices": rank_devices,
             "collective": (dist.get_backend() if grouped else None),
