@@ -915,7 +915,8 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
         if constexpr (NS1 == 3 && P::NLO == 2 && P::REM != 0) {
             // two full slots and a partial third: the waves that own three sub-series take them
             // three at a time, the others two at a time (no row requests along S2 in these plans:
-            // NSPREAD = 0)
+            // NSPREAD = 0.  Measured instead, R0 = 20, same box: every wave two at a time with 8 of
+            // the 20 requests spread, the third alone afterwards -- correct, 2.12 against 2.11 ms.)
             if (wave < P::REM) wf_sub512_x3(wsub, stw, acc[0], acc[1], acc[2]);
             else wf_sub512_x2<0>(wsub, stw, acc[0], acc[1]);
         } else {
