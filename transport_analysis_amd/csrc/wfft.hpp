@@ -822,9 +822,12 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                     base -= base >= L ? L : 0;
                     if (jo * M >= T) break;  // nothing but padding from here on
                     int idx = base;
-                    // NZ rows in flight at a time: all R0 at once would not fit next to x[] (four; the
-                    // by-particle variant with its unit kinds has room for two without scratch)
-                    constexpr int NZ = BYP ? 2 : 4;
+                    // NZ rows in flight at a time (these requests are NOT prefetched: each group is a
+                    // round trip to L2 / HBM in the middle of S1, so as many per group as the registers
+                    // next to x[] allow: ten -- R0 = 20, R = 2: 2.57 -> 2.46 ms per 15000 pairs, R = 3:
+                    // 3.28 -> 3.00 ms, same box; all twenty spill -- and two in the by-particle variant
+                    // with its unit kinds)
+                    constexpr int NZ = BYP ? 2 : 10;
 #pragma unroll
                     for (int j0 = 0; j0 < R0; j0 += NZ) {
                         cd z[NZ];
