@@ -777,9 +777,9 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
             stw.c[a] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(L + (18 + a) * 64) * 16u);
         }
     };
-    // (the by-particle variant with an outer radix on the largest plan loads them again after every
-    // first stage instead: 32 registers it does not have while the outer rows are folded in)
-    constexpr bool kTwRes = P::kTwResident && !(BYP && LONG && R0 >= 20);
+    // (the by-particle variant with an outer radix on the two largest plans loads them again after
+    // every first stage instead: 32 registers it does not have while the outer rows are folded in)
+    constexpr bool kTwRes = P::kTwResident && !(BYP && LONG && R0 >= 18);
     if constexpr (kTwRes) load_stage_tw();
     WfAddr wad;
     wad.init(lane, (unsigned)P::sub_base(wave) * kWfSubBytes);
@@ -825,9 +825,9 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                     // NZ rows in flight at a time (these requests are NOT prefetched: each group is a
                     // round trip to L2 / HBM in the middle of S1, so as many per group as the registers
                     // next to x[] allow: ten -- R0 = 20, R = 2: 2.57 -> 2.46 ms per 15000 pairs, R = 3:
-                    // 3.28 -> 3.00 ms, same box; all twenty spill -- and two in the by-particle variant
-                    // with its unit kinds)
-                    constexpr int NZ = BYP ? 2 : 10;
+                    // 3.28 -> 3.00 ms, same box; all twenty spill; the by-particle variant, which had
+                    // two: 20000 x 25000 x 3 with the per-particle array 18.4 -> 16.5 ms)
+                    constexpr int NZ = 10;
 #pragma unroll
                     for (int j0 = 0; j0 < R0; j0 += NZ) {
                         cd z[NZ];
