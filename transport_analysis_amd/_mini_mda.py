@@ -81,6 +81,9 @@ class AtomGroup:
     def __init__(self, universe, indices):
         self.universe = universe
         self.indices = np.asarray(indices, dtype=np.int64)
+        n = universe._n_atoms
+        # the whole universe in order: a frame is handed out by one plain copy, not a gather
+        self._everything = len(self.indices) == n and bool(np.array_equal(self.indices, np.arange(n)))
 
     def __len__(self):
         return len(self.indices)
@@ -97,7 +100,10 @@ class AtomGroup:
             from ._base import NoDataError
 
             raise NoDataError(f"This Timestep has no {what}")
-        return np.array(arr[self.universe.trajectory.ts.frame][self.indices], dtype=np.float32)
+        frame = arr[self.universe.trajectory.ts.frame]
+        if self._everything:
+            return np.array(frame, dtype=np.float32)
+        return np.array(frame[self.indices], dtype=np.float32)
 
     @property
     def velocities(self):
