@@ -308,6 +308,15 @@ struct WPlan {
 #else
     static constexpr bool kSpreadRows = WF_SPREAD_ALL && R0 < 18;
 #endif
+    // One of two (three) sub-series in flight takes its first exchange through the register file
+    // (gfx950 permlane swaps + DPP) instead of the LDS: same-box A/B per 30000 pairs R0 = 16: 1.63
+    // -> 1.575 ms, R0 = 18: 1.91 -> 1.84, R0 = 20: 2.07 -> 2.02 ms, R0 = 14: -2 %; R0 = 9, 10, 12: no change; all sub-series that way: R0 = 12
+    // -4 %, R0 = 8 +5 %, R0 = 20 +5 % (spills).  (-DWF_REG_EXCHANGE=0/1 overrides.)
+#ifndef WF_REG_EXCHANGE
+    static constexpr bool kRegExchange = R0 >= 14;
+#else
+    static constexpr bool kRegExchange = WF_REG_EXCHANGE;
+#endif
     static constexpr int kMinWavesPerSimd = 1;
     static constexpr bool kTwResident = true;
     static constexpr int M = R0 * N1;
@@ -445,6 +454,52 @@ __device__ __forceinline__ void wf_dft8_tw(cd (&v)[8], const cd (&t)[4]) {
 struct WfTw {
     cd b[4], c[4];  // tangent-form constants of the second and third stage (table rows 14..21)
 };
+// Register-file transposition between the register index (3 bits) and lane bits 3..5 of eight
+// complex values per lane (gfx950 cross-lane swaps; experiment, see WfSub::stage_a).
+typedef unsigned wf_u32pair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wf_transpose_hi(cd (&v)[8]) {
+    unsigned w[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const wf_u32x4 t = __builtin_bit_cast(wf_u32x4, v[a]);
+        w[a][0] = t.x, w[a][1] = t.y, w[a][2] = t.z, w[a][3] = t.w;
+    }
+    // register bit 2 <-> lane bit 5
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+        if (!(a & 4))
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const wf_u32pair r = __builtin_amdgcn_permlane32_swap(w[a][d], w[a | 4][d], false, false);
+                w[a][d] = r.x, w[a | 4][d] = r.y;
+            }
+    // register bit 1 <-> lane bit 4
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+        if (!(a & 2))
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const wf_u32pair r = __builtin_amdgcn_permlane16_swap(w[a][d], w[a | 2][d], false, false);
+                w[a][d] = r.x, w[a | 2][d] = r.y;
+            }
+    // register bit 0 <-> lane bit 3
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+        if (!(a & 1))
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned lo = w[a][d], hi = w[a | 1][d];
+                w[a][d] = __builtin_amdgcn_update_dpp(lo, hi, 0x128, 0xF, 0xC, false);      // lanes with bit 3 set
+                w[a | 1][d] = __builtin_amdgcn_update_dpp(hi, lo, 0x128, 0xF, 0x3, false);  // lanes with bit 3 clear
+            }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        wf_u32x4 t;
+        t.x = w[a][0], t.y = w[a][1], t.z = w[a][2], t.w = w[a][3];
+        v[a] = __builtin_bit_cast(cd, t);
+    }
+}
+
 // LDS byte addresses of a wave's first sub-series, formed once per launch: every access of S2 is
 // one of these registers plus an instruction offset (the wave's sub-series s sits s * 8 KiB
 // further on).  Exchange 1 writes a*64 + (l ^ 8 (a&1)): base `we` for even a, `wo` for odd a;
@@ -507,10 +562,21 @@ struct WfSub {
 #endif
         __builtin_amdgcn_wave_barrier();
     }
-    template <unsigned SO>
+    // XV: exchange 1 (register index a <-> lane bits 3..5) in the register file instead of the
+    // LDS -- three rounds of pairwise swaps: v_permlane32_swap (lane bit 5), v_permlane16_swap
+    // (bit 4), v_mov_b32_dpp row_ror:8 under a bank mask (bit 3); 80 instructions, 112 issue slots
+    // (the permlane swaps take two) against 8 stores + 8 loads
+    template <unsigned SO, bool XV = false>
     __device__ __forceinline__ void stage_a(cd (&v)[8]) const {
-        stage_a_w<SO>(v);
-        stage_a_r<SO>(v);
+        if constexpr (XV) {
+#if WF_ABL != 4
+            Dft<8>::run(v);
+#endif
+            wf_transpose_hi(v);
+        } else {
+            stage_a_w<SO>(v);
+            stage_a_r<SO>(v);
+        }
     }
     template <unsigned SO>
     __device__ __forceinline__ void stage_b_w(cd (&v)[8], const WfTw& tw) const {
@@ -576,7 +642,10 @@ __device__ __forceinline__ void wf_sub512(const WfSub& w, const WfTw& tw, double
 
 // Two sub-series (S0, S0 + 1) interleaved: while one's butterflies run, the other's exchange
 // (eight 16-byte stores, eight loads, ~300 cycles of LDS round trip) is in flight.
-template <int S0, class Hook = WfNoHook>
+// XV: the second sub-series takes exchange 1 through the register file (WfSub::stage_a) while
+// the first one's is in the LDS pipe: one sixth of the wave's LDS exchange traffic becomes vector
+// work (WPlan::kRegExchange; both of them that way is slower: the vector pipe becomes the limit)
+template <int S0, bool XV = false, class Hook = WfNoHook>
 __device__ __forceinline__ void wf_sub512_x2(const WfSub& w, const WfTw& tw, double (&acc0)[8],
                                              double (&acc1)[8], Hook&& hook = Hook{}) {
     constexpr unsigned A = S0 * kWfSubBytes, B = A + kWfSubBytes;
@@ -585,8 +654,8 @@ __device__ __forceinline__ void wf_sub512_x2(const WfSub& w, const WfTw& tw, dou
     w.read_a<B>(v1);
     __builtin_amdgcn_wave_barrier();
     hook(wf_part<0>{});
-    w.stage_a<A>(v0);
-    w.stage_a<B>(v1);
+    w.template stage_a<A>(v0);
+    w.template stage_a<B, XV>(v1);
     hook(wf_part<1>{});
     w.stage_b<A>(v0, tw);
     w.stage_b<B>(v1, tw);
@@ -598,7 +667,7 @@ __device__ __forceinline__ void wf_sub512_x2(const WfSub& w, const WfTw& tw, dou
 
 // Three sub-series interleaved (the waves that own one more than the others: they then finish
 // together with their SIMD partner's two instead of running a third alone).
-template <class Hook = WfNoHook>
+template <bool XV = false, class Hook = WfNoHook>
 __device__ __forceinline__ void wf_sub512_x3(const WfSub& w, const WfTw& tw, double (&acc0)[8],
                                              double (&acc1)[8], double (&acc2)[8], Hook&& hook = Hook{}) {
     constexpr unsigned A = 0, B = kWfSubBytes, C = 2 * kWfSubBytes;
@@ -608,9 +677,9 @@ __device__ __forceinline__ void wf_sub512_x3(const WfSub& w, const WfTw& tw, dou
     w.read_a<C>(v2);
     __builtin_amdgcn_wave_barrier();
     hook(wf_part<0>{});
-    w.stage_a<A>(v0);
-    w.stage_a<B>(v1);
-    w.stage_a<C>(v2);
+    w.template stage_a<A>(v0);
+    w.template stage_a<B>(v1);
+    w.template stage_a<C, XV>(v2);
     hook(wf_part<1>{});
     w.stage_b<A>(v0, tw);
     w.stage_b<B>(v1, tw);
@@ -920,8 +989,8 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
             // three at a time, the others two at a time (no row requests along S2 in these plans:
             // NSPREAD = 0.  Measured instead, R0 = 20, same box: every wave two at a time with 8 of
             // the 20 requests spread, the third alone afterwards -- correct, 2.12 against 2.11 ms.)
-            if (wave < P::REM) wf_sub512_x3(wsub, stw, acc[0], acc[1], acc[2]);
-            else wf_sub512_x2<0>(wsub, stw, acc[0], acc[1]);
+            if (wave < P::REM) wf_sub512_x3<P::kRegExchange>(wsub, stw, acc[0], acc[1], acc[2]);
+            else wf_sub512_x2<0, P::kRegExchange>(wsub, stw, acc[0], acc[1]);
         } else {
             static_for_range<0, NS1>([&](auto ss) {
                 constexpr int s = decltype(ss)::value;
@@ -931,8 +1000,8 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                 constexpr bool tail = full && s > 0 && (s % 2 == 1);
                 // (the row requests ride on the wave's first call: every wave has slot 0)
                 if constexpr (head) {
-                    if constexpr (s == 0) wf_sub512_x2<s>(wsub, stw, acc[s], acc[s + 1], row_hook);
-                    else wf_sub512_x2<s>(wsub, stw, acc[s], acc[s + 1]);
+                    if constexpr (s == 0) wf_sub512_x2<s, P::kRegExchange>(wsub, stw, acc[s], acc[s + 1], row_hook);
+                    else wf_sub512_x2<s, P::kRegExchange>(wsub, stw, acc[s], acc[s + 1]);
                 } else if constexpr (!tail) {
                     if constexpr (s == 0) wf_sub512<s>(wsub, stw, acc[s], row_hook);
                     else if (full || wave < P::REM) wf_sub512<s>(wsub, stw, acc[s]);
