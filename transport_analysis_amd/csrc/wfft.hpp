@@ -310,12 +310,21 @@ struct WPlan {
 #endif
     // One of two (three) sub-series in flight takes its first exchange through the register file
     // (gfx950 permlane swaps + DPP) instead of the LDS: same-box A/B per 30000 pairs R0 = 16: 1.63
-    // -> 1.575 ms, R0 = 18: 1.91 -> 1.84, R0 = 20: 2.07 -> 2.02 ms, R0 = 14: -2 %; R0 = 9, 10, 12: no change; all sub-series that way: R0 = 12
-    // -4 %, R0 = 8 +5 %, R0 = 20 +5 % (spills).  (-DWF_REG_EXCHANGE=0/1 overrides.)
+    // -> 1.575 ms, R0 = 18: 1.91 -> 1.84, R0 = 20: 2.07 -> 2.02 ms; both sub-series that way: R0 = 16 +-0,
+    // R0 = 20 +5 % (spills).  (-DWF_REG_EXCHANGE=0/1 overrides.)
 #ifndef WF_REG_EXCHANGE
-    static constexpr bool kRegExchange = R0 >= 14;
+    static constexpr bool kRegExchange = R0 >= 16;
 #else
     static constexpr bool kRegExchange = WF_REG_EXCHANGE;
+#endif
+    // ... and where a wave runs its sub-series one at a time (one full slot per wave), every one of
+    // them, on the plans where the same-box A/B says so (per ~24 GB: R0 = 2 -4 %, 7 -2 %, 9 -1.5 %,
+    // 10 -2.4 %, 12 -1.5..-3 %, 14 -3.7 %; R0 = 3..6 +-1 %, R0 = 8 +5..13 %: two workgroups per unit
+    // there, the vector pipe is the busier one)
+#ifndef WF_REG_EXCHANGE_SINGLE
+    static constexpr bool kRegExchangeSingle = R0 == 2 || R0 == 7 || R0 == 9 || R0 == 10 || R0 == 12 || R0 == 14;
+#else
+    static constexpr bool kRegExchangeSingle = (WF_REG_EXCHANGE_SINGLE >> (R0 - 1)) & 1;  // bit mask over R0
 #endif
     static constexpr int kMinWavesPerSimd = 1;
     static constexpr bool kTwResident = true;
@@ -627,12 +636,12 @@ template <int I>
 using wf_part = std::integral_constant<int, I>;
 
 // sub-series S0 of the wave (its first one is 0)
-template <int S0, class Hook = WfNoHook>
+template <int S0, bool XV = false, class Hook = WfNoHook>
 __device__ __forceinline__ void wf_sub512(const WfSub& w, const WfTw& tw, double (&acc)[8], Hook&& hook = Hook{}) {
     cd v[8];
     w.read_a<S0 * kWfSubBytes>(v);
     hook(wf_part<0>{});
-    w.stage_a<S0 * kWfSubBytes>(v);
+    w.template stage_a<S0 * kWfSubBytes, XV>(v);
     hook(wf_part<1>{});
     w.stage_b<S0 * kWfSubBytes>(v, tw);
     hook(wf_part<2>{});
@@ -1003,8 +1012,8 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                     if constexpr (s == 0) wf_sub512_x2<s, P::kRegExchange>(wsub, stw, acc[s], acc[s + 1], row_hook);
                     else wf_sub512_x2<s, P::kRegExchange>(wsub, stw, acc[s], acc[s + 1]);
                 } else if constexpr (!tail) {
-                    if constexpr (s == 0) wf_sub512<s>(wsub, stw, acc[s], row_hook);
-                    else if (full || wave < P::REM) wf_sub512<s>(wsub, stw, acc[s]);
+                    if constexpr (s == 0) wf_sub512<s, P::kRegExchangeSingle>(wsub, stw, acc[s], row_hook);
+                    else if (full || wave < P::REM) wf_sub512<s, P::kRegExchangeSingle>(wsub, stw, acc[s]);
                 }
             });
         }
