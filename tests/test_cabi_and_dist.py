@@ -165,3 +165,22 @@ def test_classes_distributed_gloo_world2(tmp_path, A):
         if hi > lo:
             assert scale_rel_err(z["visc_bp"], hbp[:, lo:hi]) < 1e-12
         np.testing.assert_allclose(z["visc"], orc.helfand_fit(hts, (2, T - 2)), rtol=1e-9)
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """ta_host_alloc / ta_kernel_timeline argument checks (no GPU needed for the rejections); on a
+    GPU-less host a pinned allocation fails loudly -- there is no pageable fallback behind it."""
+    import ctypes
+
+    from transport_analysis_amd import _lib
+
+    L = _lib.lib()
+    p = ctypes.c_void_p()
+    assert L.ta_host_alloc(-1, ctypes.byref(p)) != 0
+    assert L.ta_host_alloc(16, None) != 0
+    assert L.ta_host_free(None) == 0
+    n = ctypes.c_int(7)
+    assert L.ta_kernel_timeline(None, 4, None, None, ctypes.byref(n)) != 0
+    if _lib.device_count() == 0:
+        with pytest.raises(_lib.TAError, match="pinned host allocation failed"):
+            _lib.pinned_empty((4, 4))
