@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../transport_analysis_amd/csrc/wfft.hpp"
+#include "experiments/wspec20.hpp"
 
 using namespace ta;
 #define CK(x)                                                                       \
@@ -98,7 +99,16 @@ static int run(int R, int argc, char** argv) {
     CK(hipMalloc(&d_st, (size_t)nwg * 8 * 8));
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, d_pm, n_el, 12345ull);
     CK(hipDeviceSynchronize());
+    const bool spec = getenv("WF_SPEC") && atoi(getenv("WF_SPEC")) && R0 == 20 && R == 1;  // experiments/wspec20.hpp
     auto launch = [&]() {
+        if (spec) {
+            auto kern = stamp ? k_wspec20<true> : k_wspec20<false>;
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)P::kLds));
+            hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), P::kLds, 0, d_pm, pitch, T, n_pairs, d_tw, d_acc, d_st);
+            CK(hipGetLastError());
+            return;
+        }
         auto go = [&](auto kern) {
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)P::kLds));
