@@ -17,7 +17,6 @@
 #include <vector>
 
 #include "../../transport_analysis_amd/csrc/wfft.hpp"
-#include "experiments/wspec20.hpp"
 
 using namespace ta;
 #define CK(x)                                                                       \
@@ -81,6 +80,7 @@ static int run(int R, int argc, char** argv) {
                                (int)P::kLds));
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, P::NT, P::kLds) != hipSuccess || per_cu < 1)
             per_cu = 1;
+        if (getenv("WF_PERCU")) per_cu = std::min(per_cu, atoi(getenv("WF_PERCU")));  // fewer workgroups per unit than fit
     }
     const int nwg = std::max<long>(gran, std::min<long>((long)ncu * per_cu, 2 * R * n_pairs) / gran * gran);
     const int n_tuples = nwg / (2 * R);
@@ -99,16 +99,7 @@ static int run(int R, int argc, char** argv) {
     CK(hipMalloc(&d_st, (size_t)nwg * 8 * 8));
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, d_pm, n_el, 12345ull);
     CK(hipDeviceSynchronize());
-    const bool spec = getenv("WF_SPEC") && atoi(getenv("WF_SPEC")) && R0 == 20 && R == 1;  // experiments/wspec20.hpp
     auto launch = [&]() {
-        if (spec) {
-            auto kern = stamp ? k_wspec20<true> : k_wspec20<false>;
-            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)P::kLds));
-            hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), P::kLds, 0, d_pm, pitch, T, n_pairs, d_tw, d_acc, d_st);
-            CK(hipGetLastError());
-            return;
-        }
         auto go = [&](auto kern) {
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)P::kLds));
@@ -203,14 +194,11 @@ static int run(int R, int argc, char** argv) {
             for (int w = 0; w < nwg; ++w)
                 for (int i = 0; i < 4; ++i) s[i] += (double)st[(size_t)w * 8 + h * 4 + i];
             const double per = (double)nwg * ((double)n_pairs / n_tuples);  // unit-passes
-            // library kernel: two stamps (S1 incl. waiting for its rows, S2 incl. the barrier before it);
-            // the pipelined experiment (tools/wfft/experiments) fills all four: P1, wait A, P2, wait B
-            if (s[2] + s[3] == 0)
-                printf("cycles per unit and pass (wave %d): S1 %.0f  S2 %.0f  total %.0f\n", 4 * h, s[0] / per, s[1] / per,
-                       (s[0] + s[1]) / per);
-            else
-                printf("cycles per unit and pass (wave %d): P1 %.0f  wait A %.0f  P2 %.0f  wait B %.0f  total %.0f\n", 4 * h,
-                       s[0] / per, s[2] / per, s[1] / per, s[3] / per, (s[0] + s[1] + s[2] + s[3]) / per);
+            // two stamps per unit: S1 incl. waiting for its rows, S2 incl. the barrier before it
+            {  // [2] / [3] = the kernel's span in shader cycles / 100 MHz ticks
+                printf("cycles per unit and pass (wave %d): S1 %.0f  S2 %.0f  total %.0f   in-kernel clock %.0f MHz\n", 4 * h,
+                       s[0] / per, s[1] / per, (s[0] + s[1]) / per, s[2] / s[3] * 100.0);
+            }
         }
     }
     return 0;

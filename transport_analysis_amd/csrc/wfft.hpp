@@ -326,7 +326,11 @@ struct WPlan {
 #else
     static constexpr bool kRegExchangeSingle = (WF_REG_EXCHANGE_SINGLE >> (R0 - 1)) & 1;  // bit mask over R0
 #endif
+#ifndef WF_MINW_R0
     static constexpr int kMinWavesPerSimd = 1;
+#else  // experiment: plan R0 = WF_MINW_R0 is compiled for WF_MINW_VAL waves per SIMD
+    static constexpr int kMinWavesPerSimd = R0 == WF_MINW_R0 ? WF_MINW_VAL : 1;
+#endif
     static constexpr bool kTwResident = true;
     static constexpr int M = R0 * N1;
     // sub-series of a wave (forward kernel): consecutive ones, q = sub_base(wave) + s, s < sub_count(wave);
@@ -775,8 +779,14 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
     for (int s = 0; s < NS1; ++s)
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[s][c] = 0.0;
-    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
-    if constexpr (STAMP) st_prev = __builtin_amdgcn_s_memtime();
+    // STAMP (diagnostic builds only): st_acc[0] / [1] = shader cycles in S1 / S2, [2] / [3] = the
+    // kernel's whole span in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime): their
+    // quotient x 100 MHz is the clock the kernel ran at (MI355X_MICROARCH.md, DVFS item 6)
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0, st_t0 = 0, st_r0 = 0;
+    if constexpr (STAMP) {
+        st_prev = st_t0 = __builtin_amdgcn_s_memtime();
+        st_r0 = __builtin_amdgcn_s_memrealtime();
+    }
 #define WF_STAMP(i)                                                   \
     if constexpr (STAMP) {                                            \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -1073,6 +1083,8 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
         }
     }
     if constexpr (STAMP) {
+        st_acc[2] = __builtin_amdgcn_s_memtime() - st_t0;
+        st_acc[3] = __builtin_amdgcn_s_memrealtime() - st_r0;
         if (lane == 0 && (wave == 0 || wave == NW / 2))
             for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + (wave ? 4 : 0) + i] = st_acc[i];
     }
