@@ -126,6 +126,10 @@ int ta_trim(ta_ctx *ctx);
  * object); the Python side wraps it as the NumPy array it hands out and frees it with
  * ta_host_free when the last view dies.                                                   */
 int ta_host_alloc(int64_t n_bytes, void **h_out);
+/* the same with the calling thread bound to `device` first (hipSetDevice): a helper thread that
+ * page-locks the array while frames are staged would otherwise create a HIP context on GPU 0 from
+ * every rank.  device < 0: the calling thread's current device, as ta_host_alloc.            */
+int ta_host_alloc_on(int device, int64_t n_bytes, void **h_out);
 int ta_host_free(void *h);
 
 /* ---- compute on staged slabs (host-facing, blocking) -------------------

@@ -41,6 +41,8 @@ class OracleContext:
     def result_home(self, shape):
         return self._Home(shape)
 
+    device = 0
+
     @staticmethod
     def _out(bp, by_particle, out):
         if out is not None:

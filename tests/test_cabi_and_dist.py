@@ -18,7 +18,7 @@ def test_library_exports_header_symbols():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ta_abi_version() == 3
+    assert L.ta_abi_version() == 4
 
 
 def test_no_cpu_fallback():
@@ -169,7 +169,9 @@ def test_classes_distributed_gloo_world2(tmp_path, A):
 
 def test_new_entry_points_reject_bad_arguments():
     """ta_host_alloc / ta_kernel_timeline argument checks (no GPU needed for the rejections); on a
-    GPU-less host a pinned allocation fails loudly -- there is no pageable fallback behind it."""
+    GPU-less host the explicit pinned allocation fails loudly, while the RESULT array of an analysis
+    degrades to pageable memory with a warning (the run is not lost in _conclude because
+    page-locking failed: ADVICE r03) and $TA_AMD_PINNED_RESULTS=0 skips pinning altogether."""
     import ctypes
 
     from transport_analysis_amd import _lib
@@ -178,9 +180,28 @@ def test_new_entry_points_reject_bad_arguments():
     p = ctypes.c_void_p()
     assert L.ta_host_alloc(-1, ctypes.byref(p)) != 0
     assert L.ta_host_alloc(16, None) != 0
+    assert L.ta_host_alloc_on(-1, -1, ctypes.byref(p)) != 0 and L.ta_host_alloc_on(0, 16, None) != 0
     assert L.ta_host_free(None) == 0
     n = ctypes.c_int(7)
     assert L.ta_kernel_timeline(None, 4, None, None, ctypes.byref(n)) != 0
     if _lib.device_count() == 0:
-        with pytest.raises(_lib.TAError, match="pinned host allocation failed"):
+        with pytest.raises(_lib.TAError, match="pinned host allocation failed|hipSetDevice"):
             _lib.pinned_empty((4, 4))
+        with pytest.warns(RuntimeWarning, match="page-locked result array unavailable"):
+            a = _lib.result_empty((4, 5))
+        assert a.shape == (4, 5) and a.dtype == np.float64 and a.flags.c_contiguous
+        with pytest.warns(RuntimeWarning):
+            b = _lib.PinnedResult((3, 2), device=0).get()
+        assert b.shape == (3, 2)
+
+
+def test_pinned_results_opt_out(monkeypatch):
+    import warnings
+
+    from transport_analysis_amd import _lib
+
+    monkeypatch.setenv("TA_AMD_PINNED_RESULTS", "0")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # no allocation attempt, so nothing to warn about
+        a = _lib.result_empty((2, 3))
+    assert a.shape == (2, 3) and a.dtype == np.float64

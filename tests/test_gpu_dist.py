@@ -84,6 +84,8 @@ def _worker_nccl(rank, world, port, T, A, out_dir):
 
     os.environ.pop("TA_AMD_DEVICE", None)
     os.environ["LOCAL_RANK"] = "0"
+    # a group of one rank reduces nothing unless asked: here RCCL is to run the collective
+    os.environ["TA_AMD_FORCE_COLLECTIVE"] = "1"
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
                             device_id=torch.device("cuda", 0))
@@ -106,7 +108,10 @@ def _worker_nccl(rank, world, port, T, A, out_dir):
     out["visc_ts_nobp"] = h.results.timeseries
     # the collective itself, on a device tensor
     t = torch.arange(5, dtype=torch.float64, device="cuda")
-    out["reduced"] = tad.reduce_lagsum(t, 2).cpu().numpy()
+    out["reduced"] = tad.reduce_lagsum(t, 2, force=True).cpu().numpy()
+    # ... and without the request a one-rank group launches nothing: a CPU tensor stays legal under nccl
+    os.environ.pop("TA_AMD_FORCE_COLLECTIVE")
+    out["cpu_noop"] = tad.reduce_lagsum(torch.arange(5, dtype=torch.float64), 2).numpy()
     np.savez(os.path.join(out_dir, "nccl_0.npz"), **out)
     dist.destroy_process_group()
 
@@ -136,7 +141,7 @@ def test_classes_distributed_rccl_world_size_one(tmp_path, T, A):
         assert scale_rel_err(z[f"visc_ts_{tag}"], hts) < tol
         assert scale_rel_err(z[f"visc_bp_{tag}"], hbp) < tol
     assert scale_rel_err(z["visc_ts_nobp"], hts) < TOL
-    assert np.array_equal(z["reduced"], np.arange(5) / 2.0)
+    assert np.array_equal(z["reduced"], np.arange(5) / 2.0) and np.array_equal(z["cpu_noop"], np.arange(5) / 2.0)
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])

@@ -9,7 +9,7 @@ from numpy.testing import assert_allclose, assert_almost_equal, assert_approx_eq
 from scipy import integrate
 
 from oracle import numpy_oracle as orc
-from conftest import GOLDEN, scale_rel_err
+from conftest import GOLDEN, REPO, scale_rel_err
 
 
 def g(name):
@@ -208,3 +208,19 @@ def test_golden_files_reproduce_from_the_reference():
     res = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py"), "--check"],
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_c_oracle_kats_under_sanitizers():
+    """ASan/UBSan on the CPU C restatement.  `make -C oracle/c asan` builds
+    ta_oracle.c + kat_main.c with -fsanitize=address,undefined and runs the known-answer cases
+    (step-trajectory closed form, FFT == windowed on ragged shapes, Helfand against a long-double
+    loop); any sanitizer report or mismatch fails the make."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None and shutil.which("cc") is None:
+        pytest.skip("no C compiler")
+    cdir = os.path.join(REPO, "oracle", "c")
+    r = subprocess.run(["make", "-s", "-C", cdir, "-B", "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "oracle KATs under ASan/UBSan: ok" in r.stdout

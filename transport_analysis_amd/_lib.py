@@ -26,7 +26,7 @@ EXPORTS = (
     "ta_vacf_fft_dev", "ta_vacf_direct_dev", "ta_helfand_msd_dev",
     "ta_vacf_fft_staged", "ta_vacf_direct_staged", "ta_helfand_msd_staged",
     "ta_last_timing", "ta_timing_history", "ta_kernel_timeline", "ta_fft_plan_info", "ta_set_option",
-    "ta_host_alloc", "ta_host_free",
+    "ta_host_alloc", "ta_host_alloc_on", "ta_host_free",
 )
 
 
@@ -117,6 +117,7 @@ def lib():
     L.ta_kernel_timeline.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
                                      ctypes.POINTER(ci)]
     L.ta_host_alloc.argtypes = [i64, ctypes.POINTER(vp)]
+    L.ta_host_alloc_on.argtypes = [ctypes.c_int, i64, ctypes.POINTER(vp)]
     L.ta_host_free.argtypes = [vp]
     L.ta_fft_plan_info.argtypes = [i64, ctypes.POINTER(i64), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.ta_set_option.argtypes = [vp, ctypes.c_char_p, i64]
@@ -158,15 +159,17 @@ class _PinnedBlock:
             pass
 
 
-def pinned_empty(shape, dtype=np.float64):
-    """np.empty in page-locked host memory (ta_host_alloc): the home of results.vacf_by_particle /
+def pinned_empty(shape, dtype=np.float64, device=-1):
+    """np.empty in page-locked host memory (ta_host_alloc_on): the home of results.vacf_by_particle /
     results.visc_by_particle, so that the device->host copy runs at the link's rate the first
-    time.  The memory lives as long as the array or any view of it."""
+    time.  The memory lives as long as the array or any view of it.  `device`: the GPU the calling
+    thread is bound to before allocating (-1: its current one).  Raises TAError when the
+    allocation fails; `result_empty` is the variant that falls back to pageable memory."""
     shape = tuple(int(x) for x in np.atleast_1d(shape))
     dt = np.dtype(dtype)
     nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
     p = ctypes.c_void_p()
-    rc = lib().ta_host_alloc(nbytes, ctypes.byref(p))
+    rc = lib().ta_host_alloc_on(int(device), nbytes, ctypes.byref(p))
     if rc != 0:
         raise TAError(rc, lib().ta_last_error(None).decode())
     buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
@@ -174,18 +177,44 @@ def pinned_empty(shape, dtype=np.float64):
     return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
 
 
-class PinnedResult:
-    """The pinned home of a by-particle result, allocated on a helper thread while the frames
-    are staged (page-locking 8 GB takes about as long as copying them); `get()` joins."""
+def pinned_results_enabled():
+    """$TA_AMD_PINNED_RESULTS=0 keeps result arrays in pageable memory (np.empty, as the reference's
+    np.zeros): for hosts whose RLIMIT_MEMLOCK / cgroup leaves no room for 8 GB more of pinned pages
+    beside the staging slabs."""
+    return os.environ.get("TA_AMD_PINNED_RESULTS", "1") != "0"
 
-    def __init__(self, shape):
+
+def result_empty(shape, device=-1):
+    """Home of a by-particle result: pinned when possible, else -- with a warning -- a pageable
+    np.empty (the device->host copy is then slower the first time, the values are the same).  The
+    analysis must not be lost in _conclude, after every frame has been read, because page-locking
+    failed (hipHostMalloc under a memlock limit)."""
+    if not pinned_results_enabled():
+        return np.empty(tuple(int(x) for x in np.atleast_1d(shape)), dtype=np.float64)
+    try:
+        return pinned_empty(shape, device=device)
+    except TAError as e:
+        import warnings
+
+        warnings.warn(f"page-locked result array unavailable ({e}); using pageable memory "
+                      "(slower device->host copy, same values)", RuntimeWarning, stacklevel=2)
+        return np.empty(tuple(int(x) for x in np.atleast_1d(shape)), dtype=np.float64)
+
+
+class PinnedResult:
+    """The home of a by-particle result, page-locked on a helper thread while the frames are staged
+    (page-locking 8 GB takes about as long as copying them); `get()` joins.  The helper thread is
+    bound to the analysis' GPU; a failed pinned allocation degrades to pageable memory with a
+    warning (result_empty)."""
+
+    def __init__(self, shape, device=-1):
         import threading
 
         self._arr, self._err = None, None
 
         def work():
             try:
-                self._arr = pinned_empty(shape)
+                self._arr = result_empty(shape, device=device)
             except Exception as e:  # surfaced by get()
                 self._err = e
 
@@ -233,7 +262,7 @@ class Context:
 
     def result_home(self, shape):
         """Start page-locking the by-particle result array of `shape`; `.get()` returns it."""
-        return PinnedResult(shape)
+        return PinnedResult(shape, device=self.device)
 
     # -- staging --------------------------------------------------------
     def stage_alloc(self, n_frames, n_atoms, dim, n_slabs=1, dtype=np.float64):
@@ -309,7 +338,7 @@ class Context:
                 raise ValueError("out must be a C-contiguous float64 array of shape (n_frames, n_atoms)")
             bp = out
         elif by_particle:
-            bp = pinned_empty((T, A))
+            bp = result_empty((T, A), device=self.device)
         self._check(fn(self._h, *extra, _ptr(ts), _ptr(bp)))
         return ts, bp
 

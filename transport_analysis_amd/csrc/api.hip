@@ -492,7 +492,7 @@ int staged_entry(ta_ctx* ctx, int which, const double* d_masses, double scale, d
 
 extern "C" {
 
-int ta_abi_version(void) { return 3; }
+int ta_abi_version(void) { return 4; }
 
 int ta_device_count(void) {
     int n = 0;
@@ -621,10 +621,17 @@ int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_st
 }
 
 /* --------------------------------------------- pinned host memory for results */
-int ta_host_alloc(int64_t n_bytes, void** h_out) {
+int ta_host_alloc_on(int device, int64_t n_bytes, void** h_out) {
     if (!h_out || n_bytes < 0) return fail(nullptr, TA_E_INVALID, "bad argument");
     *h_out = nullptr;
     void* h = nullptr;
+    // the allocating thread may be a fresh helper thread whose current device is 0: bind it to the
+    // analysis' own GPU first, so that no context is created on a device the rank does not use
+    if (device >= 0) {
+        const hipError_t es = hipSetDevice(device);
+        if (es != hipSuccess)
+            return fail(nullptr, TA_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(es));
+    }
     // portable: usable by every device's copy engines (the result outlives the context)
     const hipError_t e = hipHostMalloc(&h, (size_t)std::max<int64_t>(n_bytes, 16), hipHostMallocPortable);
     if (e != hipSuccess)
@@ -632,6 +639,8 @@ int ta_host_alloc(int64_t n_bytes, void** h_out) {
     *h_out = h;
     return TA_OK;
 }
+
+int ta_host_alloc(int64_t n_bytes, void** h_out) { return ta_host_alloc_on(-1, n_bytes, h_out); }
 
 int ta_host_free(void* h) {
     if (!h) return TA_OK;

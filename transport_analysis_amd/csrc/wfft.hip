@@ -4,6 +4,7 @@
 #include "wfft.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "ta_internal.hpp"
@@ -14,20 +15,25 @@ namespace {
 constexpr int kR0s[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20};
 constexpr int kOuter[] = {1, 2, 3, 4, 5, 8, 16};
 
-// the dynamic LDS limit of a kernel is set once per (kernel, device), not on every launch
+// the dynamic LDS limit of a kernel is set once per (kernel, device), not on every launch.
+// Contexts of several devices may launch from several host threads: the flags are atomics
+// (setting the attribute twice is harmless, skipping it is not), and a device index outside the
+// cache takes the uncached path every time.
 constexpr int kMaxDev = 16;
-inline int cur_dev() {
+using DevFlag = std::atomic<bool>;
+using DevCount = std::atomic<int>;
+inline int cur_dev() {  // -1: not cacheable
     int d = 0;
-    (void)hipGetDevice(&d);
-    return d < 0 || d >= kMaxDev ? 0 : d;
+    if (hipGetDevice(&d) != hipSuccess) return -1;
+    return d < 0 || d >= kMaxDev ? -1 : d;
 }
 template <class K>
-hipError_t set_lds(K kern, size_t bytes, bool* done /* [kMaxDev], one array per kernel */) {
+hipError_t set_lds(K kern, size_t bytes, DevFlag* done /* [kMaxDev], one array per kernel */) {
     const int d = cur_dev();
-    if (done[d]) return hipSuccess;
+    if (d >= 0 && done[d].load(std::memory_order_acquire)) return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) done[d] = true;
+    if (e == hipSuccess && d >= 0) done[d].store(true, std::memory_order_release);
     return e;
 }
 
@@ -37,7 +43,7 @@ hipError_t launch_forward_r0(int R, bool byp, int nwg, hipStream_t st, const dou
     using P = WPlan<R0>;
     auto kern = byp ? (R > 1 ? k_wsplit_accum<P, true, true> : k_wsplit_accum<P, true, false>)
                     : (R > 1 ? k_wsplit_accum<P, false, true> : k_wsplit_accum<P, false, false>);
-    static bool done[4][kMaxDev];
+    static DevFlag done[4][kMaxDev];
     hipError_t e = set_lds(kern, P::kLds, done[(byp ? 2 : 0) + (R > 1 ? 1 : 0)]);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_units, tw, accg, D, R, nullptr);
@@ -55,7 +61,7 @@ hipError_t launch_inverse_r0(int R, int nwg, hipStream_t st, const double* spec,
                 : pf == 1 ? k_winverse<P, false, 1>
                 : pf == 2 ? k_winverse<P, false, (NSA < 2 ? NSA : 2)>
                           : k_winverse<P, false, NSA>;
-    static bool done[5][kMaxDev];
+    static DevFlag done[5][kMaxDev];
     hipError_t e = set_lds(kern, P::kLds, done[variant]);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, spec, T, n_items, tw, out, ld, R);
@@ -68,9 +74,12 @@ hipError_t launch_inverse_r0(int R, int nwg, hipStream_t st, const double* spec,
 template <int R0>
 int max_wg_r0() {
     using P = WPlan<R0>;
-    static int cached[kMaxDev];
+    static DevCount cached[kMaxDev];
     const int d = cur_dev();
-    if (cached[d] > 0) return cached[d];
+    if (d >= 0) {
+        const int c = cached[d].load(std::memory_order_acquire);
+        if (c > 0) return c;
+    }
     int best = 1 << 30;
     auto ask = [&](auto kern) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -83,7 +92,8 @@ int max_wg_r0() {
     ask(k_wsplit_accum<P, false, true>);
     ask(k_wsplit_accum<P, true, false>);
     ask(k_wsplit_accum<P, true, true>);
-    return cached[d] = best;
+    if (d >= 0) cached[d].store(best, std::memory_order_release);
+    return best;
 }
 
 // spec[k] = sum over workgroups of their natural-order accumulator blocks, k < L2 = 2M
@@ -207,7 +217,7 @@ int wfft_max_wg_per_cu(int R0) {
 // R0 = 1 (n_frames <= 512): independent waves, 4 per workgroup; accg [4 nwg][1024]
 hipError_t launch_w1_accum(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
                            const cd* tw, double* accg) {
-    static bool done[kMaxDev];
+    static DevFlag done[kMaxDev];
     hipError_t e = set_lds(k_w1_accum, W1::kLds, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_w1_accum, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_pairs, tw, accg);
@@ -216,7 +226,7 @@ hipError_t launch_w1_accum(int nwg, hipStream_t st, const double* pm, long pitch
 
 hipError_t launch_w1_bp(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_atoms, int D,
                         const cd* tw, double* out, long ld) {
-    static bool done[kMaxDev];
+    static DevFlag done[kMaxDev];
     hipError_t e = set_lds(k_w1_bp, W1::kLds, done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_w1_bp, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_atoms, D, tw, out, ld);

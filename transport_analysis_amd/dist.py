@@ -23,17 +23,26 @@ def atom_shard(n_atoms, rank, world_size):
     return lo, hi
 
 
-def reduce_lagsum(lagsum, n_atoms_total, group=None):
+def _force_collective():
+    import os
+
+    return os.environ.get("TA_AMD_FORCE_COLLECTIVE", "") == "1" or os.environ.get("TA_BENCH_FORCE_DIST", "") == "1"
+
+
+def reduce_lagsum(lagsum, n_atoms_total, group=None, force=False):
     """Sum the per-rank lag sums across ranks and divide by the total atom count.
 
     `lagsum` is a torch tensor (device tensor with the nccl/RCCL backend, CPU
-    tensor with gloo); it is reduced in place and the mean is returned."""
+    tensor with gloo); it is reduced in place and the mean is returned.  A group of one rank
+    reduces nothing (no collective is launched, and a tensor the backend could not reduce --
+    a CPU tensor under nccl -- stays legal) unless `force` or $TA_AMD_FORCE_COLLECTIVE=1 /
+    $TA_BENCH_FORCE_DIST=1 asks for the collective anyway: the tests and the one-GPU rehearsal of
+    bench.py use that to run RCCL on a box with a single GPU."""
     import torch.distributed as dist
 
-    # whenever a group is up, also of one rank: the collective (RCCL under the nccl backend) is
-    # then exercised by every distributed run, not only from two GPUs on
     if dist.is_available() and dist.is_initialized():
-        dist.all_reduce(lagsum, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_world_size(group) > 1 or force or _force_collective():
+            dist.all_reduce(lagsum, op=dist.ReduceOp.SUM, group=group)
     return lagsum / float(n_atoms_total)
 
 
