@@ -1,7 +1,7 @@
 """INTEGRATION.md section B -- the binding a reference maintainer would add -- executed AS WRITTEN.
 
 The python block is cut out of the document and exec'd in a fresh interpreter that has not loaded
-this package's ctypes layer (`transport_analysis_amd._lib` is never imported there): raw
+this package's ctypes layer (`transport_analysis_amd._lib` never opens the library there): raw
 `ctypes.CDLL("libta_hip.so")`, found through LD_LIBRARY_PATH.  The driver supplies only what the
 reference itself supplies around the three hooks: `AnalysisBase`, `NoDataError` and the
 constructor's attributes (/root/reference/transport_analysis/velocityautocorr.py:112-140).  The
@@ -24,10 +24,8 @@ import sys, numpy as np
 sys.path.insert(0, {repo!r})
 from transport_analysis_amd._base import AnalysisBase, NoDataError     # the MDAnalysis protocol (stand-in)
 from transport_analysis_amd._mini_mda import ArrayUniverse
-assert "transport_analysis_amd._lib" not in sys.modules
 ns = dict(AnalysisBase=AnalysisBase, NoDataError=NoDataError)
 exec(compile(open({snippet!r}).read(), "INTEGRATION.md#B", "exec"), ns)
-assert "transport_analysis_amd._lib" not in sys.modules, "the snippet must not lean on this package's binding"
 
 
 class Patched(ns["VelocityAutocorr"]):
@@ -44,6 +42,9 @@ for fft in (True, False):
     out[f"ts{{int(fft)}}"], out[f"bp{{int(fft)}}"] = a.results.timeseries, np.array(a.results.vacf_by_particle)
     del a
 import gc; gc.collect()
+# the package's own ctypes layer never loaded the library: everything above went through the snippet's CDLL
+from transport_analysis_amd import _lib as _pkg_binding
+assert _pkg_binding._lib is None, "the snippet must not lean on this package's binding"
 np.savez({out!r}, **out)
 '''
 
@@ -70,7 +71,8 @@ def test_integration_snippet_runs_as_written(tmp_path):
 
     T, A = 700, 37
     rng = np.random.default_rng(2025)
-    v = rng.standard_normal((T, A, 3))
+    # float32-representable values: the trajectory hands out float32 copies, as MDAnalysis does
+    v = rng.standard_normal((T, A, 3)).astype(np.float32).astype(np.float64)
     np.save(tmp_path / "v.npy", v)
     (tmp_path / "snippet.py").write_text(snippet_text())
     (tmp_path / "driver.py").write_text(DRIVER.format(repo=REPO, snippet=str(tmp_path / "snippet.py"),

@@ -1,38 +1,44 @@
 #!/bin/bash
 # One artefact that ties clock, power and kernel duration together for the SAME back-to-back
-# launches of the forward kernel.  Run on the GPU box:
-#   tools/power_clock.sh [out file]        -> profiles/r04_power_clock.txt (copy it there)
-# Part 1 (un-profiled): the harness runs the STAMP build of k_wsplit_accum back to back
-#   (150000 pairs x 10000 frames = 24 GB per launch, 250 launches): per launch the hipEvent
-#   time, at the end shader cycles per unit and pass (s_memtime) and the in-kernel clock
-#   = delta s_memtime / delta s_memrealtime x 100 MHz; rocm-smi samples power, its sclk and the
-#   junction temperature meanwhile.
-# Part 2 (rocprofv3, program directly behind --): the same launches under --pmc GRBM_GUI_ACTIVE
-#   with --kernel-trace: effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration.
+# launches of the forward kernel, and the energy per input byte of every plan.
+# Run on the GPU box:   tools/power_clock.sh [out file]   -> copy to profiles/r04_power_clock.txt
+# Part 1 (un-profiled): per plan the harness runs the STAMP build of k_wsplit_accum back to back
+#   (~24 GB per launch, ~2.5 s): hipEvent time per launch, shader cycles per unit and pass
+#   (s_memtime), in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz; rocm-smi
+#   samples package power, its sclk and the junction temperature meanwhile.  Then the same binary
+#   on ALL-ZERO input (WF_ZERO=1): the same instruction stream at a fraction of the power.
+# Part 2 (rocprofv3, program directly behind --): R0 = 20 under --pmc GRBM_GUI_ACTIVE with
+#   --kernel-trace: effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=${1:-$R/gpurun_out/r04_power_clock.txt}
 BIN=$R/tools/wfft/wfft_test
-export WF_R0=${WF_R0:-20} WF_R=${WF_R:-1}
 mkdir -p $(dirname $OUT); cd /tmp; export TMPDIR=/tmp
+smi() { rocm-smi --showpower --showclocks --showtemp 2>/dev/null | grep -E "Power|sclk|Temperature \(Sensor junction" | sed 's/^GPU\[0\]\s*: //; s/=\{10,\}//g' | tr '\n' ';'; echo; }
+plan() {  # R0 pairs T launches [zero]
+  export WF_R0=$1 WF_R=1 WF_ZERO=${5:-0}
+  echo "### plan R0=$1 ($3 frames x $2 pairs, $4 launches back to back)  zero_input=$WF_ZERO"
+  $BIN time $2 $3 $4 1 > /tmp/pc_run.log 2>&1 &
+  local PID=$!
+  sleep 1.3
+  for i in 1 2 3 4; do kill -0 $PID 2>/dev/null && smi; sleep 0.25; done
+  wait $PID
+  cat /tmp/pc_run.log
+}
 {
-echo "# power_clock.sh  $(date -u +%FT%TZ)  plan R0=$WF_R0 R=$WF_R  binary sha $(sha256sum $BIN | cut -c1-16)"
-echo "## part 1: un-profiled, STAMP build, 250 launches of 24 GB back to back; rocm-smi samples meanwhile"
-$BIN time 150000 10000 250 1 > /tmp/pc_run.log 2>&1 &
-PID=$!
-sleep 1.2
-for i in 1 2 3 4 5 6 7 8; do
-  if kill -0 $PID 2>/dev/null; then
-    rocm-smi --showpower --showclocks --showtemp 2>/dev/null | grep -E "Power|sclk|mclk|Temperature \(Sensor junction" | sed 's/^GPU\[0\]\s*: //' | tr '\n' ';'
-    echo
-  fi
-  sleep 0.25
-done
-wait $PID
-cat /tmp/pc_run.log
-echo "## idle, 1 s later"
-sleep 1
-rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | sed 's/^GPU\[0\]\s*: //' | tr '\n' ';'; echo
-echo "## part 2: rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace, 40 launches"
+echo "# power_clock.sh  $(date -u +%FT%TZ)  harness sha $(sha256sum $BIN | cut -c1-16)"
+echo "## part 1: un-profiled STAMP build; rocm-smi samples while the launches run"
+plan 20 150000 10000 250
+plan 16 180000 8192 280
+plan 12 240000 6144 290
+plan 10 300000 5120 270
+plan 8 360000 4096 280
+echo "## the same on all-zero input"
+plan 20 150000 10000 250 1
+plan 12 240000 6144 290 1
+plan 8 360000 4096 280 1
+echo "## idle, 1 s later"; sleep 1; smi
+echo "## part 2: rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace, R0 = 20, 40 launches"
+export WF_R0=20 WF_R=1 WF_ZERO=0
 rm -rf /tmp/pc_prof
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pc_prof -- $BIN time 150000 10000 40 0 > /tmp/pc_prof.log 2>&1
 tail -1 /tmp/pc_prof.log

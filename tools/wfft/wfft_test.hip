@@ -96,8 +96,11 @@ static int run(int R, int argc, char** argv) {
     CK(hipMalloc(&d_acc, (size_t)n_tuples * L * 8));
     CK(hipMalloc(&d_spec, (size_t)L * 8));
     CK(hipMalloc(&d_lag, (size_t)T * 8));
-    CK(hipMalloc(&d_st, (size_t)nwg * 8 * 8));
-    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, d_pm, n_el, 12345ull);
+    CK(hipMalloc(&d_st, (size_t)nwg * 16 * 8));
+    if (getenv("WF_ZERO") && atoi(getenv("WF_ZERO")))  // all-zero input: the same cycles at a fraction of the power
+        CK(hipMemset(d_pm, 0, n_el * 8));
+    else
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, d_pm, n_el, 12345ull);
     CK(hipDeviceSynchronize());
     auto launch = [&]() {
         auto go = [&](auto kern) {
@@ -187,17 +190,18 @@ static int run(int R, int argc, char** argv) {
     printf("R0=%d R=%d L=%d T=%d pairs=%ld nwg=%d: best %.3f ms  mean %.3f ms  %.1f GB/s  (x150000 pairs: %.2f ms)\n", R0,
            R, L, T, n_pairs, nwg, best, sum / reps, bytes / best * 1e-6, best * 150000.0 / n_pairs);
     if (stamp) {
-        std::vector<unsigned long long> st((size_t)nwg * 8);
+        std::vector<unsigned long long> st((size_t)nwg * 16);
         CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
         for (int h = 0; h < 2; ++h) {
-            double s[4] = {0, 0, 0, 0};
+            double s[4] = {0, 0, 0, 0}, tail = 0;
+            for (int w = 0; w < nwg; ++w) tail += (double)st[(size_t)w * 16 + 8 + h];
             for (int w = 0; w < nwg; ++w)
-                for (int i = 0; i < 4; ++i) s[i] += (double)st[(size_t)w * 8 + h * 4 + i];
+                for (int i = 0; i < 4; ++i) s[i] += (double)st[(size_t)w * 16 + h * 4 + i];
             const double per = (double)nwg * ((double)n_pairs / n_tuples);  // unit-passes
             // two stamps per unit: S1 incl. waiting for its rows, S2 incl. the barrier before it
             {  // [2] / [3] = the kernel's span in shader cycles / 100 MHz ticks
-                printf("cycles per unit and pass (wave %d): S1 %.0f  S2 %.0f  total %.0f   in-kernel clock %.0f MHz\n", 4 * h,
-                       s[0] / per, s[1] / per, (s[0] + s[1]) / per, s[2] / s[3] * 100.0);
+                printf("cycles per unit and pass (wave %d): S1 %.0f  S2 %.0f (of which row requests + barrier wait %.0f)  total %.0f   in-kernel clock %.0f MHz\n", 4 * h,
+                       s[0] / per, s[1] / per, tail / per, (s[0] + s[1]) / per, s[2] / s[3] * 100.0);
             }
         }
     }

@@ -327,9 +327,11 @@ struct WPlan {
     static constexpr bool kRegExchangeSingle = (WF_REG_EXCHANGE_SINGLE >> (R0 - 1)) & 1;  // bit mask over R0
 #endif
 #ifndef WF_MINW_R0
-    static constexpr int kMinWavesPerSimd = 1;
+    // R0 = 2 lives on four waves per SIMD -- several workgroups per compute unit -- and sits just
+    // under the 128 registers that takes: hold it there
+    static __host__ __device__ constexpr int min_waves(bool /*byp*/, bool lng) { return R0 == 2 ? 4 : 1; }
 #else  // experiment: plan R0 = WF_MINW_R0 is compiled for WF_MINW_VAL waves per SIMD
-    static constexpr int kMinWavesPerSimd = R0 == WF_MINW_R0 ? WF_MINW_VAL : 1;
+    static __host__ __device__ constexpr int min_waves(bool, bool) { return R0 == WF_MINW_R0 ? WF_MINW_VAL : 1; }
 #endif
     static constexpr bool kTwResident = true;
     static constexpr int M = R0 * N1;
@@ -340,6 +342,51 @@ struct WPlan {
     static __host__ __device__ constexpr int sub_count(int wave) { return NLO + (wave < REM ? 1 : 0); }
     static __host__ __device__ constexpr int sub_base(int wave) { return wave * NLO + (wave < REM ? wave : REM); }
     static constexpr size_t kLds = (size_t)M * sizeof(cd);
+
+    // ---- by-particle mode, a unit that is a single REAL column (z of an even atom, x of an odd one):
+    // its transform is Hermitian, Z[L - k] = conj Z[k], so |Z|^2 of bin (pass c, sub-series q,
+    // position r) equals that of its mirror: pass 0: (0, R0 - q, 511 - r) (q = 0: (0, 0, 512 - r));
+    // pass c > 0: (2R - c, R0 - 1 - q, 511 - r).  The lag values only see the EVEN part of the power
+    // spectrum (lag[n] = sum_k P[k] cos(2 pi k n / L)), so of every mirror pair of sub-series ONE is
+    // transformed, with weight 2, and the other not at all (a sub-series that is its own mirror:
+    // weight 1): half the second-stage work and half the first-stage stores of such a unit.  Which
+    // member of a pair is taken is chosen per plan so that the waves (and the SIMDs: waves w, w + 4)
+    // share the work evenly; every pass c > 0 takes the same set, which is then also the
+    // complement of the mirror image of what pass 2R - c takes.
+    struct RealSel {
+        unsigned qmask[2];  // [pass > 0]: bit q = sub-series q is transformed
+        unsigned q1mask[2];  // ... with weight 1 (its own mirror) instead of 2
+    };
+    static __host__ __device__ constexpr int owner(int q) {
+        for (int w = 0; w < NW; ++w)
+            if (q >= sub_base(w) && q < sub_base(w) + sub_count(w)) return w;
+        return 0;
+    }
+    static __host__ __device__ constexpr RealSel real_selection() {
+        RealSel r{{0u, 0u}, {0u, 0u}};
+        for (int t = 0; t < 2; ++t) {
+            int load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, simd[4] = {0, 0, 0, 0};
+            auto take = [&](int q, bool self) {
+                r.qmask[t] |= 1u << q;
+                if (self) r.q1mask[t] |= 1u << q;
+                ++load[owner(q)];
+                ++simd[owner(q) % 4];
+            };
+            const int span = t == 0 ? R0 : R0 - 1;  // mirror of q: (span - q) mod R0
+            // the sub-series that are their own mirror
+            for (int q = 0; q < R0; ++q)
+                if ((span - q + R0) % R0 == q) take(q, true);
+            for (int q = 0; q < R0; ++q) {
+                const int m = (span - q + R0) % R0;
+                if (m <= q) continue;  // each pair once (q < m)
+                const int wa = owner(q), wb = owner(m);
+                const int ca = 16 * load[wa] + simd[wa % 4], cb = 16 * load[wb] + simd[wb % 4];
+                take(cb < ca ? m : q, false);
+            }
+        }
+        return r;
+    }
+    static constexpr RealSel kRealSel = real_selection();
 };
 
 __device__ __forceinline__ cd wf_load(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned uni_off) {
@@ -624,6 +671,12 @@ struct WfSub {
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = fma(v[c].y, v[c].y, fma(v[c].x, v[c].x, acc[c]));
     }
+    // ... with a weight (1 or 2: the sub-series of a real column that stand for their mirror images too)
+    __device__ __forceinline__ void stage_c_w(cd (&v)[8], const WfTw& tw, double (&acc)[8], double wgt) const {
+        wf_dft8_tw(v, tw.c);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = fma(wgt, fma(v[c].y, v[c].y, v[c].x * v[c].x), acc[c]);
+    }
 };
 
 constexpr unsigned kWfSubBytes = 512 * sizeof(cd);  // one sub-series in LDS
@@ -651,6 +704,16 @@ __device__ __forceinline__ void wf_sub512(const WfSub& w, const WfTw& tw, double
     hook(wf_part<2>{});
     w.stage_c(v, tw, acc);
     hook(wf_part<3>{});
+}
+
+// ... with the weight of WfSub::stage_c_w (by-particle mode, real columns)
+template <int S0, bool XV = false>
+__device__ __forceinline__ void wf_sub512_w(const WfSub& w, const WfTw& tw, double (&acc)[8], double wgt) {
+    cd v[8];
+    w.read_a<S0 * kWfSubBytes>(v);
+    w.template stage_a<S0 * kWfSubBytes, XV>(v);
+    w.stage_b<S0 * kWfSubBytes>(v, tw);
+    w.stage_c_w(v, tw, acc, wgt);
 }
 
 // Two sub-series (S0, S0 + 1) interleaved: while one's butterflies run, the other's exchange
@@ -755,7 +818,7 @@ __device__ __forceinline__ cd wf_cfma(cd acc, cd a, cd b) {  // acc + a b
 }
 
 template <class P, bool BYP = false, bool LONG = false, bool STAMP = false>
-__global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
+__global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
     k_wsplit_accum(const double* __restrict__ pm, long pitch, int T, long n_units,
                    const cd* __restrict__ tw2, double* __restrict__ accg, int D, int R_arg,
                    unsigned long long* __restrict__ stamps) {
@@ -782,7 +845,7 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
     // STAMP (diagnostic builds only): st_acc[0] / [1] = shader cycles in S1 / S2, [2] / [3] = the
     // kernel's whole span in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime): their
     // quotient x 100 MHz is the clock the kernel ran at (MI355X_MICROARCH.md, DVFS item 6)
-    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0, st_t0 = 0, st_r0 = 0;
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0, st_t0 = 0, st_r0 = 0, st_tail = 0, st_s2end = 0;
     if constexpr (STAMP) {
         st_prev = st_t0 = __builtin_amdgcn_s_memtime();
         st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -877,6 +940,11 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
     for (long item = tuple * grp; item < n_units;) {
         // ---- S1: radix-R0 butterflies u = tid + NT k over rows u + 512 j of u_c (jo = 0 requested
         // during the previous S2); g = W_M^u, h = W_L^{c u}
+#ifndef WF_REAL_S1_SKIP
+#define WF_REAL_S1_SKIP 0  // 1: a real column's unwanted sub-series are not stored either (wave-uniform branches
+                           // around the output twiddles and LDS stores; costs registers: spills at R0 = 20)
+#endif
+        const unsigned qsel = (WF_REAL_S1_SKIP && BYP && kind != 2) ? P::kRealSel.qmask[pass ? 1 : 0] : ~0u;
 #pragma unroll
         for (int k1 = 0; k1 < K1; ++k1) {
         const int u = tid + NT * k1;
@@ -953,10 +1021,10 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
             cd te = pass ? h : cd{1.0, 0.0};
             cd to = pass ? cmul(h, g) : g;
             if (pass) x[0] = cmul(x[0], te);
-            lds[u] = x[0];
+            if (!(WF_REAL_S1_SKIP && BYP) || (qsel & 1u)) lds[u] = x[0];
             if constexpr (R0 > 1) {
                 x[1] = cmul(x[1], to);
-                lds[N1 + u] = x[1];
+                if (!(WF_REAL_S1_SKIP && BYP) || (qsel & 2u)) lds[N1 + u] = x[1];
             }
 #pragma unroll
             for (int q = 2; q < R0; ++q) {
@@ -967,7 +1035,8 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                     te = cmul(te, g2);
                     x[q] = cmul(x[q], te);
                 }
-                lds[q * N1 + u] = x[q];
+                // (only the LDS store is skipped: branches around the products as well cost registers)
+                if (!(WF_REAL_S1_SKIP && BYP) || (qsel >> q & 1u)) lds[q * N1 + u] = x[q];
             }
         }
         }
@@ -1000,6 +1069,19 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
             issue_loads_part(part_c, nrs, nkind);
 #endif
         };
+        if (BYP && kind != 2) {
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            // a real column: the wave's share of P::kRealSel, one sub-series at a time
+            // (the next unit's row requests that would ride along S2 go out first)
+            static_for_range<0, 4>([&](auto part_c) { row_hook(part_c); });
+            const unsigned qs = P::kRealSel.qmask[pass ? 1 : 0] >> P::sub_base(wv);
+            const unsigned q1 = P::kRealSel.q1mask[pass ? 1 : 0] >> P::sub_base(wv);
+            static_for_range<0, NS1>([&](auto ss) {
+                constexpr int s = decltype(ss)::value;
+                if ((s < P::NLO || wv < P::REM) && (qs >> s & 1u))
+                    wf_sub512_w<s, P::kRegExchangeSingle>(wsub, stw, acc[s], (q1 >> s & 1u) ? 1.0 : 2.0);
+            });
+        } else
 #if WF_ABL == 1
         if (T < 0)
 #endif
@@ -1027,6 +1109,7 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
                 }
             });
         }
+        if constexpr (STAMP) st_s2end = __builtin_amdgcn_s_memtime();  // behind the wave's own sub-series
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         auto store_acc = [&](long row) {  // accg[row][pass][q][cc / 2][lane][cc & 1]
             const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
@@ -1061,6 +1144,7 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
         issue_loads_tail(nrs, nkind);
 #endif
         kind = nkind, item = nitem, k = nk, crs = nrs;
+        if constexpr (STAMP) st_tail += __builtin_amdgcn_s_memtime() - st_s2end;  // the row requests behind S2
         WF_STAMP(1)
         __syncthreads();
     }
@@ -1085,8 +1169,10 @@ __global__ void __launch_bounds__(P::NT, P::kMinWavesPerSimd)
     if constexpr (STAMP) {
         st_acc[2] = __builtin_amdgcn_s_memtime() - st_t0;
         st_acc[3] = __builtin_amdgcn_s_memrealtime() - st_r0;
-        if (lane == 0 && (wave == 0 || wave == NW / 2))
-            for (int i = 0; i < 4; ++i) stamps[8 * (long)blockIdx.x + (wave ? 4 : 0) + i] = st_acc[i];
+        if (lane == 0 && (wave == 0 || wave == NW / 2)) {  // 16 slots per workgroup: [0..3] wave 0, [4..7] wave NW/2, [8], [9] tails
+            for (int i = 0; i < 4; ++i) stamps[16 * (long)blockIdx.x + (wave ? 4 : 0) + i] = st_acc[i];
+            stamps[16 * (long)blockIdx.x + 8 + (wave ? 1 : 0)] = st_tail;
+        }
     }
 #undef WF_STAMP
 }
