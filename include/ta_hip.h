@@ -176,6 +176,41 @@ int ta_vacf_direct_staged(ta_ctx *ctx, double *d_lagsum, double *d_by_particle, 
 int ta_helfand_msd_staged(ta_ctx *ctx, const double *d_masses, double scale, double *d_lagsum,
                           double *d_by_particle, int64_t ld_bp, void *stream);
 
+/* ---- several GPUs behind one call (one process, one frame loop) ---------------------------
+ * the multi-GPU fan-out and the reduce happen INSIDE the call.  A group owns
+ * one context per entry of device_ids; member i stages and correlates the contiguous atom range
+ * [n_atoms i / n_dev, n_atoms (i + 1) / n_dev) (ta_group_shard; the same split as one process per
+ * GPU under torch.distributed), so the host fills n_dev pinned slabs per frame -- each GPU's column
+ * block of the reference's slab (velocityautocorr.py:150-152,192-194; viscosity.py:128-134,189-199)
+ * -- in ONE pass over the trajectory.  A compute call queues every member's kernels on its own
+ * device, adds the members' (n_frames,) lag sums ONCE and divides by the total atom count
+ * (velocityautocorr.py:214,237; viscosity.py:233); by-particle blocks are copied device->host
+ * straight into the column range [lo_i, hi_i) of the caller's ONE (n_frames, n_atoms) array.
+ * The reduce: n_dev = 1 none (librccl is not loaded); n_dev > 1 on distinct devices ncclReduce in
+ * one RCCL group call (librccl.so dlopen'ed on first use; communicators from ncclCommInitAll);
+ * members that share a device, or no usable RCCL: peer copies to the first member + a sum in
+ * member order.  ta_group_reduce_kind names what the last call used: "none" | "rccl" | "peer-copy".
+ * h_slabs of ta_group_stage_alloc: n_dev * n_slabs pointers, member i's slab s at [i * n_slabs + s]
+ * (NULL for a member without atoms: more devices than atoms), each (n_frames, hi_i - lo_i, dim).
+ * h_masses of ta_group_helfand_msd: all n_atoms.  Options go to every member.                */
+typedef struct ta_group ta_group;
+int ta_group_create(const int *device_ids, int n_dev, ta_group **out);
+int ta_group_destroy(ta_group *g);
+const char *ta_group_last_error(const ta_group *g);
+int ta_group_size(const ta_group *g);
+int ta_group_member(ta_group *g, int i, ta_ctx **ctx, int *device);
+int ta_group_shard(const ta_group *g, int64_t n_atoms, int i, int64_t *atom_lo, int64_t *atom_hi);
+const char *ta_group_reduce_kind(const ta_group *g);
+int ta_group_set_option(ta_group *g, const char *key, int64_t value);
+int ta_group_stage_alloc(ta_group *g, int64_t n_frames, int64_t n_atoms, int dim, int dtype,
+                         int n_slabs, void **h_slabs);
+int ta_group_stage_commit(ta_group *g, int64_t frame_lo, int64_t frame_hi);
+int ta_group_stage_free(ta_group *g);
+int ta_group_vacf_fft(ta_group *g, double *h_timeseries, double *h_by_particle);
+int ta_group_vacf_direct(ta_group *g, double *h_timeseries, double *h_by_particle);
+int ta_group_helfand_msd(ta_group *g, const double *h_masses, double scale, double *h_timeseries,
+                         double *h_by_particle);
+
 /* ---- instrumentation ----------------------------------------------------
  * Device time of the last *_dev / host-facing compute call on this context,
  * measured with hipEvents recorded on the stream the kernels were launched on.
@@ -193,6 +228,17 @@ int ta_timing_history(ta_ctx *ctx, int max_n, float *total_ms, float *main_kerne
  * names[i] (static strings owned by the library), ms[i], *n_out entries (<= max_n).  The sum is
  * the call's total_ms.  Blocks until the call has completed.                              */
 int ta_kernel_timeline(ta_ctx *ctx, int max_n, const char **names, float *ms, int *n_out);
+/* The clock the headline kernel actually runs at (MI355X lowers it under load; board power and
+ * the driver's sclk are not the test).  Launches a DIAGNOSTIC build of the lag-sum forward kernel
+ * (in-kernel s_memtime / s_memrealtime stamps; the product kernels execute no stamp) n_launches
+ * times back to back on the staged float64 slab -- ask for >= 2 s worth -- and reports, from the
+ * last launch: *mhz = delta s_memtime / delta s_memrealtime x 100 MHz (mean over workgroups),
+ * *cycles_per_unit_pass = shader cycles one workgroup spends per column pair and pass, and
+ * *ms_per_launch (events around all launches; the stamped build is a few per cent slower than the
+ * product kernel).  Plans R0 = 8, 10, 12, 16, 20 without an outer radix (n_frames in (3584, 4096],
+ * (4608, 5120], (5120, 6144], (7168, 8192], (9216, 10240]); otherwise TA_E_UNSUPPORTED.        */
+int ta_clock_probe(ta_ctx *ctx, int n_launches, double *mhz, double *cycles_per_unit_pass,
+                   double *ms_per_launch);
 /* FFT length bookkeeping for a given n_frames: *m_out = padded half-length M
  * (the transform computes a 2M-point correlation, 2M >= 2*n_frames-1): M = R * R0 * 512 with
  * R0 in {1,...,10,12,14,16,18,20} and the outer radix R = 1 up to 10240 frames (one on-chip

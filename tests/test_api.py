@@ -14,7 +14,7 @@ import pytest
 from numpy.testing import assert_allclose, assert_almost_equal, assert_approx_equal
 from scipy import integrate
 
-from conftest import GOLDEN
+from conftest import GOLDEN, scale_rel_err
 from transport_analysis_amd import VelocityAutocorr as VACF
 from transport_analysis_amd import ViscosityHelfand as VH
 from transport_analysis_amd import _base, _lib
@@ -32,9 +32,10 @@ def g(name):
 @pytest.fixture(params=["oracle-backed", pytest.param("hip", marks=pytest.mark.gpu)])
 def backend(request, monkeypatch):
     if request.param == "oracle-backed":
-        from fake_backend import OracleContext
+        from fake_backend import OracleContext, OracleGroup
 
         monkeypatch.setattr(_lib, "Context", OracleContext)
+        monkeypatch.setattr(_lib, "Group", OracleGroup)
     else:
         assert _lib.device_count() >= 1
     return request.param
@@ -310,3 +311,75 @@ def test_stage_columns_equals_the_reference_fill(dim_type, src_dtype, dst_dtype)
         stage_columns(dst, src, lo, hi, dim)
         assert np.array_equal(dst[: hi - lo], src[lo:hi][:, dim].astype(dst_dtype))
         assert np.all(dst[hi - lo:] == -7.0)
+
+
+# ---- several GPUs from one process: devices=[...] -------------------------
+def test_group_partition_matches_the_per_process_one():
+    """The C-ABI's split (ta_group_shard: floor(A i / n)) is transport_analysis_amd.dist.atom_shard:
+    contiguous, covering, and the same whether the GPUs sit behind one process or one each."""
+    from fake_backend import OracleGroup
+    from transport_analysis_amd.dist import atom_shard
+
+    for A in (1, 2, 7, 64, 100000):
+        for n in (1, 2, 3, 8):
+            g = OracleGroup(list(range(n)))
+            edges = [g.shard(A, i) for i in range(n)]
+            assert edges == [atom_shard(A, i, n) for i in range(n)]
+            assert edges[0][0] == 0 and edges[-1][1] == A
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("fft", [True, False])
+def test_devices_one_frame_loop_column_ranges(backend, water, devices, fft):
+    """devices=[...]: ONE pass over the trajectory fills every member's column block, the result is
+    the single-context one -- timeseries over ALL atoms, ONE (n_frames, n_particles) by-particle
+    array whose column ranges the members fill.  On the GPU box the members share the one GPU
+    (the copy-and-add reduce); devices=[0] must equal the plain context bit for bit."""
+    ag = water.atoms
+    ref = VACF(ag, fft=fft).run()
+    calls = {"n": 0}
+    orig = type(ag).velocities.fget
+
+    def counting(self):
+        calls["n"] += 1
+        return orig(self)
+
+    type(ag).velocities = property(counting)
+    try:
+        a = VACF(ag, fft=fft, devices=devices).run()
+    finally:
+        type(ag).velocities = property(orig)
+    # one gather per frame (+ the dtype probe of _prepare), however many devices
+    assert calls["n"] <= ag.universe.trajectory.n_frames + 1
+    assert a.results.vacf_by_particle.shape == ref.results.vacf_by_particle.shape
+    n = len(devices)
+    assert a.results.device_ranges == [(30 * i // n, 30 * (i + 1) // n) for i in range(n)]
+    if len(devices) == 1:
+        assert np.array_equal(a.results.timeseries, ref.results.timeseries)
+        assert np.array_equal(a.results.vacf_by_particle, ref.results.vacf_by_particle)
+    else:
+        assert scale_rel_err(a.results.timeseries, ref.results.timeseries) < 1e-12
+        assert scale_rel_err(a.results.vacf_by_particle, ref.results.vacf_by_particle) < 1e-12
+    h_ref = VH(ag, linear_fit_window=(2, 8)).run()
+    h = VH(ag, linear_fit_window=(2, 8), devices=devices).run()
+    assert scale_rel_err(h.results.timeseries, h_ref.results.timeseries) < 1e-12
+    assert scale_rel_err(h.results.visc_by_particle, h_ref.results.visc_by_particle) < 1e-12
+    np.testing.assert_allclose(h.results.viscosity, h_ref.results.viscosity, rtol=1e-9)
+
+
+def test_devices_more_gpus_than_atoms_and_exclusive_with_distributed(backend):
+    rng = np.random.default_rng(11)
+    v = rng.standard_normal((12, 2, 3)).astype(np.float32)
+    u = ArrayUniverse(velocities=v, positions=np.cumsum(v, axis=0), masses=[1.0, 2.0],
+                      dimensions=[5, 5, 5, 90, 90, 90])
+    ref = VACF(u.atoms, fft=True).run()
+    a = VACF(u.atoms, fft=True, devices=[0, 0, 0]).run()  # member 0 holds no atom
+    assert a.results.device_ranges == [(0, 0), (0, 1), (1, 2)]
+    assert scale_rel_err(a.results.timeseries, ref.results.timeseries) < 1e-12
+    assert scale_rel_err(a.results.vacf_by_particle, ref.results.vacf_by_particle) < 1e-12
+    with pytest.raises(ValueError, match="exclusive"):
+        VACF(u.atoms, devices=[0], distributed=True)
+    with pytest.raises(ValueError, match="exclusive"):
+        VH(u.atoms, devices=[0], distributed=True)
+

@@ -205,3 +205,30 @@ def test_pinned_results_opt_out(monkeypatch):
         warnings.simplefilter("error")  # no allocation attempt, so nothing to warn about
         a = _lib.result_empty((2, 3))
     assert a.shape == (2, 3) and a.dtype == np.float64
+
+
+def test_group_entry_points_reject_bad_arguments():
+    """ta_group_* argument checks (no GPU needed); without a GPU a group cannot be created: the
+    members are ordinary contexts and there is no CPU backend behind them."""
+    import ctypes
+
+    from transport_analysis_amd import _lib
+
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    ids = (ctypes.c_int * 2)(0, 0)
+    assert L.ta_group_create(None, 1, ctypes.byref(h)) != 0
+    assert L.ta_group_create(ids, 0, ctypes.byref(h)) != 0
+    assert L.ta_group_create(ids, 2, None) != 0
+    assert L.ta_group_size(None) == 0 and L.ta_group_destroy(None) == 0
+    assert L.ta_group_stage_commit(None, 0, 1) != 0
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    assert L.ta_group_shard(None, 10, 0, ctypes.byref(lo), ctypes.byref(hi)) != 0
+    if _lib.device_count() == 0:
+        assert L.ta_group_create(ids, 2, ctypes.byref(h)) != 0 and not h.value
+        assert b"no usable HIP device" in L.ta_group_last_error(None)
+        with pytest.raises(_lib.TAError, match="no usable HIP device"):
+            _lib.Group([0])
+    with pytest.raises(ValueError):
+        _lib.Group([])
+

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import scale_rel_err
+from conftest import REPO, scale_rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -193,3 +193,61 @@ def test_bench_one_rank_under_rccl():
     d = json.loads(lines[0])
     assert d["config"]["collective"] == "nccl" and len(d["config"]["rank_devices"]) == 1
     assert d["reduce_us"] > 0 and d["check"]["max_scale_rel_err_vs_torch_lags"] < 1e-10
+
+
+GROUP_DRIVER = r"""
+import sys, numpy as np
+sys.path.insert(0, {repo!r})
+from transport_analysis_amd import _lib          # torch is NOT imported in this process
+from oracle import numpy_oracle as orc
+rng = np.random.default_rng(3)
+T, A, D = 300, 41, 3
+v = rng.standard_normal((T, A, D))
+bp_ref, ts_ref = orc.vacf_windowed(v)
+def run(devices):
+    g = _lib.Group(devices)
+    (views,) = g.stage_alloc(T, A, D, n_slabs=1, dtype=np.float64)
+    for view, (lo, hi) in zip(views, g.shards):
+        if hi > lo:
+            view[...] = v[:, lo:hi]
+    g.stage_commit(0, T)
+    ts, bp = g.vacf_fft(by_particle=True)
+    kind = g.reduce_kind
+    ts2, _ = g.vacf_direct(by_particle=False)
+    g.close()
+    return ts, bp, ts2, kind
+ts1, bp1, d1, k1 = run([0])
+maps = open("/proc/self/maps").read()
+assert k1 == "none" and "librccl" not in maps, "one device: no reduce, RCCL must not be loaded"
+c = _lib.Context(0)
+(slab,) = c.stage_alloc(T, A, D, n_slabs=1, dtype=np.float64)
+slab[...] = v
+c.stage_commit(0, T)
+ts0, bp0 = c.vacf_fft(by_particle=True)
+assert np.array_equal(ts0, ts1) and np.array_equal(bp0, bp1), "devices=[0] must equal the plain context bit for bit"
+ts2, bp2, d2, k2 = run([0, 0])
+ts3, bp3, d3, k3 = run([0, 0, 0, 0, 0])
+assert k2 == "peer-copy" and k3 == "peer-copy"
+np.savez({out!r}, ts_ref=ts_ref, bp_ref=bp_ref, ts1=ts1, bp1=bp1, d1=d1, ts2=ts2, bp2=bp2, d2=d2, ts3=ts3, bp3=bp3, d3=d3)
+"""
+
+
+def test_group_c_abi_one_gpu(tmp_path):
+    """The in-library fan-out on what a one-GPU box can run: a group of ONE device adds nothing to
+    the plain context (bit-equal, no reduce, librccl never loaded); groups of 2 and 5 members that
+    share the GPU stage disjoint column blocks, reduce by copy-and-add inside the call and fill
+    the column ranges of one by-particle array.  (Distinct devices take the RCCL branch: not
+    runnable here -- the driver's multi-GPU node is where it first executes.)"""
+    import subprocess
+    import sys
+
+    out = tmp_path / "g.npz"
+    (tmp_path / "drv.py").write_text(GROUP_DRIVER.format(repo=REPO, out=str(out)))
+    r = subprocess.run([sys.executable, str(tmp_path / "drv.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    z = np.load(out)
+    for k in ("1", "2", "3"):
+        assert scale_rel_err(z["ts" + k], z["ts_ref"]) < TOL
+        assert scale_rel_err(z["bp" + k], z["bp_ref"]) < TOL
+        assert scale_rel_err(z["d" + k], z["ts_ref"]) < TOL
+

@@ -25,8 +25,13 @@ EXPORTS = (
     "ta_vacf_fft", "ta_vacf_direct", "ta_helfand_msd",
     "ta_vacf_fft_dev", "ta_vacf_direct_dev", "ta_helfand_msd_dev",
     "ta_vacf_fft_staged", "ta_vacf_direct_staged", "ta_helfand_msd_staged",
-    "ta_last_timing", "ta_timing_history", "ta_kernel_timeline", "ta_fft_plan_info", "ta_set_option",
+    "ta_last_timing", "ta_timing_history", "ta_kernel_timeline", "ta_clock_probe", "ta_fft_plan_info",
+    "ta_set_option",
     "ta_host_alloc", "ta_host_alloc_on", "ta_host_free",
+    "ta_group_create", "ta_group_destroy", "ta_group_last_error", "ta_group_size", "ta_group_member",
+    "ta_group_shard", "ta_group_reduce_kind", "ta_group_set_option", "ta_group_stage_alloc",
+    "ta_group_stage_commit", "ta_group_stage_free", "ta_group_vacf_fft", "ta_group_vacf_direct",
+    "ta_group_helfand_msd",
 )
 
 
@@ -116,13 +121,30 @@ def lib():
                                     ctypes.POINTER(ci)]
     L.ta_kernel_timeline.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
                                      ctypes.POINTER(ci)]
+    L.ta_clock_probe.argtypes = [vp, ci, ctypes.POINTER(dbl), ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
     L.ta_host_alloc.argtypes = [i64, ctypes.POINTER(vp)]
     L.ta_host_alloc_on.argtypes = [ctypes.c_int, i64, ctypes.POINTER(vp)]
     L.ta_host_free.argtypes = [vp]
     L.ta_fft_plan_info.argtypes = [i64, ctypes.POINTER(i64), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.ta_set_option.argtypes = [vp, ctypes.c_char_p, i64]
+    L.ta_group_create.argtypes = [ctypes.POINTER(ci), ci, ctypes.POINTER(vp)]
+    L.ta_group_destroy.argtypes = [vp]
+    L.ta_group_last_error.argtypes = [vp]
+    L.ta_group_last_error.restype = ctypes.c_char_p
+    L.ta_group_size.argtypes = [vp]
+    L.ta_group_member.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(ci)]
+    L.ta_group_shard.argtypes = [vp, i64, ci, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.ta_group_reduce_kind.argtypes = [vp]
+    L.ta_group_reduce_kind.restype = ctypes.c_char_p
+    L.ta_group_set_option.argtypes = [vp, ctypes.c_char_p, i64]
+    L.ta_group_stage_alloc.argtypes = [vp, i64, i64, ci, ci, ci, ctypes.POINTER(vp)]
+    L.ta_group_stage_commit.argtypes = [vp, i64, i64]
+    L.ta_group_stage_free.argtypes = [vp]
+    L.ta_group_vacf_fft.argtypes = [vp, vp, vp]
+    L.ta_group_vacf_direct.argtypes = [vp, vp, vp]
+    L.ta_group_helfand_msd.argtypes = [vp, vp, dbl, vp, vp]
     for name in EXPORTS:
-        if name not in ("ta_last_error",):
+        if name not in ("ta_last_error", "ta_group_last_error", "ta_group_reduce_kind"):
             getattr(L, name).restype = ci
     _lib = L
     return L
@@ -394,7 +416,135 @@ class Context:
         self._check(lib().ta_kernel_timeline(self._h, max_n, names, ms, ctypes.byref(n)))
         return [(names[i].decode(), ms[i]) for i in range(n.value)]
 
+    def clock_probe(self, n_launches):
+        """{"mhz", "cycles_per_unit_pass", "ms_per_launch"} of the stamped lag-sum forward kernel
+        launched n_launches times back to back on the staged slab (ta_clock_probe)."""
+        a, b, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        self._check(lib().ta_clock_probe(self._h, int(n_launches), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"mhz": a.value, "cycles_per_unit_pass": b.value, "ms_per_launch": c.value}
+
     def last_timing(self):
         t, m = ctypes.c_float(), ctypes.c_float()
         self._check(lib().ta_last_timing(self._h, ctypes.byref(t), ctypes.byref(m)))
         return t.value, m.value
+
+
+class Group:
+    """Several GPUs behind one object (ta_group): ONE frame loop fills every GPU's column block of
+    the slab, a compute call fans out, reduces the lag sums once inside the library (RCCL for
+    distinct devices; `reduce_kind` says what ran) and copies by-particle blocks into the column
+    ranges of one host array.  Same methods as `Context` where the analysis classes use them;
+    `stage_alloc` returns, per slab, the list of per-member views, and `shards` the members' atom
+    ranges [(lo, hi), ...] (an empty range: more devices than atoms, its view is None)."""
+
+    def __init__(self, devices):
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise ValueError("devices must name at least one GPU")
+        self._h = ctypes.c_void_p(None)
+        L = lib()
+        ids = (ctypes.c_int * len(devices))(*devices)
+        rc = L.ta_group_create(ids, len(devices), ctypes.byref(self._h))
+        if rc != 0:
+            raise TAError(rc, L.ta_group_last_error(None).decode())
+        self.devices = devices
+        self.device = devices[0]
+        self.shards = []
+        self._slabs = []
+
+    def _check(self, rc):
+        if rc != 0:
+            raise TAError(rc, lib().ta_group_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._drop_views()
+            lib().ta_group_destroy(self._h)
+            self._h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _drop_views(self):
+        for per_member in self._slabs:
+            for a in per_member:
+                if a is not None:
+                    try:
+                        a.setflags(write=False)
+                    except Exception:
+                        pass
+        self._slabs = []
+
+    def set_option(self, key, value):
+        self._check(lib().ta_group_set_option(self._h, key.encode(), int(value)))
+
+    @property
+    def reduce_kind(self):
+        return lib().ta_group_reduce_kind(self._h).decode()
+
+    def shard(self, n_atoms, i):
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        self._check(lib().ta_group_shard(self._h, int(n_atoms), int(i), ctypes.byref(lo), ctypes.byref(hi)))
+        return lo.value, hi.value
+
+    def result_home(self, shape):
+        return PinnedResult(shape, device=self.device)
+
+    def stage_alloc(self, n_frames, n_atoms, dim, n_slabs=1, dtype=np.float64):
+        """-> [slab][member] NumPy views (n_frames, hi_i - lo_i, dim) of the members' pinned slabs."""
+        code = TA_F64 if np.dtype(dtype) == np.float64 else TA_F32
+        n_dev = len(self.devices)
+        ptrs = (ctypes.c_void_p * (n_dev * n_slabs))()
+        self._drop_views()
+        self._check(lib().ta_group_stage_alloc(self._h, n_frames, n_atoms, dim, code, n_slabs, ptrs))
+        ct = ctypes.c_double if code == TA_F64 else ctypes.c_float
+        self.shards = [self.shard(n_atoms, i) for i in range(n_dev)]
+        out = []
+        for s in range(n_slabs):
+            views = []
+            for i, (lo, hi) in enumerate(self.shards):
+                p = ptrs[i * n_slabs + s]
+                if hi == lo or not p:
+                    views.append(None)
+                    continue
+                n = int(n_frames) * (hi - lo) * int(dim)
+                buf = (ct * n).from_address(p)
+                views.append(np.frombuffer(buf, dtype=dtype).reshape(n_frames, hi - lo, dim))
+            out.append(views)
+        self._slabs = out
+        self.shape = (int(n_frames), int(n_atoms), int(dim))
+        return out
+
+    def stage_commit(self, frame_lo, frame_hi):
+        self._check(lib().ta_group_stage_commit(self._h, int(frame_lo), int(frame_hi)))
+
+    def stage_free(self):
+        self._drop_views()
+        self._check(lib().ta_group_stage_free(self._h))
+
+    def _host(self, fn, by_particle, *extra, out=None):
+        T, A, _ = getattr(self, "shape", None) or (1, 1, 1)
+        ts = np.empty(T, dtype=np.float64)
+        bp = None
+        if out is not None:
+            if out.shape != (T, A) or out.dtype != np.float64 or not out.flags.c_contiguous:
+                raise ValueError("out must be a C-contiguous float64 array of shape (n_frames, n_atoms)")
+            bp = out
+        elif by_particle:
+            bp = result_empty((T, A), device=self.device)
+        self._check(fn(self._h, *extra, _ptr(ts), _ptr(bp)))
+        return ts, bp
+
+    def vacf_fft(self, by_particle=False, out=None):
+        return self._host(lib().ta_group_vacf_fft, by_particle, out=out)
+
+    def vacf_direct(self, by_particle=False, out=None):
+        return self._host(lib().ta_group_vacf_direct, by_particle, out=out)
+
+    def helfand_msd(self, masses, scale, by_particle=False, out=None):
+        m = np.ascontiguousarray(masses, dtype=np.float64)
+        return self._host(lib().ta_group_helfand_msd, by_particle, _ptr(m), ctypes.c_double(scale), out=out)
+

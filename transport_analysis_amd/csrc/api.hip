@@ -862,6 +862,58 @@ int ta_timing_history(ta_ctx* ctx, int max_n, float* total_ms, float* main_kerne
     return TA_OK;
 }
 
+int ta_clock_probe(ta_ctx* ctx, int n_launches, double* mhz, double* cycles_per_unit_pass, double* ms_per_launch) {
+    if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    if (ctx->st_nslabs < 1) return fail(ctx, TA_E_STATE, "slabs have not been staged");
+    if (n_launches < 1) return fail(ctx, TA_E_INVALID, "need at least one launch");
+    if (ctx->st_dev_f32) return fail(ctx, TA_E_UNSUPPORTED, "clock probe: float64 device slabs only");
+    TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t T = ctx->st_T, n_pairs = (ctx->st_A * ctx->st_D + 1) / 2;
+    int R0 = 0, R = 1;
+    if (!wfft_choose((long)T, &R0, &R) || R != 1 || !(R0 == 8 || R0 == 10 || R0 == 12 || R0 == 16 || R0 == 20))
+        return fail(ctx, TA_E_UNSUPPORTED, "clock probe: plans R0 = 8, 10, 12, 16, 20 without an outer radix only");
+    cd* tw = nullptr;
+    int rc = get_wf_table(ctx, R0, R, &tw);
+    if (rc) return rc;
+    const int64_t cap = ctx->opt_fft_nwg > 0 ? ctx->opt_fft_nwg : (int64_t)ctx->n_cu * wfft_max_wg_per_cu(R0);
+    const int64_t nwg = std::max<int64_t>(16, std::min<int64_t>(cap, 2 * n_pairs) / 16 * 16), n_tuples = nwg / 2;
+    const int64_t L = 2L * R0 * 512;
+    if ((rc = ensure(ctx, ctx->partial, sizeof(double) * (size_t)n_tuples * L))) return rc;
+    DevBuf st;
+    if ((rc = ensure(ctx, st, sizeof(unsigned long long) * 16 * (size_t)nwg))) return rc;
+    if (int rc_ = order_after_staging(ctx, ctx->stream)) {
+        hipFree(st.p);
+        return rc_;
+    }
+    hipEvent_t e0 = ctx->ring[0][0], e1 = ctx->ring[0][3];  // borrowed: the probe is not a compute call
+    ctx->timing_valid = false;
+    hipError_t e = hipEventRecord(e0, ctx->stream);
+    for (int i = 0; i < n_launches && e == hipSuccess; ++i)
+        e = launch_wfft_forward_stamp(R0, (int)nwg, ctx->stream, ctx->d_slabs[0], ctx->st_pitch, (int)T, n_pairs, tw,
+                                      (double*)ctx->partial.p, (unsigned long long*)st.p);
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    std::vector<unsigned long long> h(16 * (size_t)nwg);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), st.p, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipFree(st.p);
+    if (e != hipSuccess) return fail(ctx, TA_E_HIP, std::string("clock probe: ") + hipGetErrorString(e));
+    // the last launch's stamps, wave 0 of every workgroup: [0] S1, [1] S2 cycles, [2] the kernel's span
+    // in shader cycles, [3] in 100 MHz ticks
+    double cyc = 0.0, span = 0.0, ticks = 0.0;
+    for (int64_t w = 0; w < nwg; ++w) {
+        cyc += (double)h[16 * w + 0] + (double)h[16 * w + 1];
+        span += (double)h[16 * w + 2];
+        ticks += (double)h[16 * w + 3];
+    }
+    const double unit_passes = 2.0 * (double)n_pairs;  // every pair in both passes, over all workgroups
+    if (mhz) *mhz = ticks > 0 ? span / ticks * 100.0 : 0.0;
+    if (cycles_per_unit_pass) *cycles_per_unit_pass = cyc / unit_passes;
+    if (ms_per_launch) *ms_per_launch = ms / n_launches;
+    return TA_OK;
+}
+
 int ta_kernel_timeline(ta_ctx* ctx, int max_n, const char** names, float* ms, int* n_out) {
     if (!ctx || !n_out) return fail(ctx, TA_E_INVALID, "null argument");
     *n_out = 0;
@@ -886,22 +938,38 @@ int ta_kernel_timeline(ta_ctx* ctx, int max_n, const char** names, float* ms, in
 }
 
 /* ------------------------------------------------- host-facing (blocking) */
-static int host_compute(ta_ctx* ctx, int which, const double* h_masses, double scale,
-                        double* h_ts, double* h_bp) {
+}  // extern "C"
+
+namespace ta {
+// One context's share of a host-facing call, queued but not waited for: compute on the staged
+// slabs, by-particle blocks copied into the caller's host array (row stride ld_host elements: the
+// caller's array may be wider than this context's block of atoms -- the column range of one GPU
+// in a multi-device group), and the lag-indexed SUM over this context's atoms left on the device
+// in *d_total ((n_frames,) float64, valid once host_wait has returned or for work queued behind it
+// on ctx->stream).  h_masses: this context's atoms.
+int host_launch(ta_ctx* ctx, int which, const double* h_masses, double scale, double* h_bp, int64_t ld_host,
+                double** d_total) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
-    if (!h_ts) return fail(ctx, TA_E_INVALID, "h_timeseries is NULL");
     const int need = which == W_HELFAND ? 2 : 1;
     if (ctx->st_nslabs < need) return fail(ctx, TA_E_STATE, "slabs have not been staged");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t T = ctx->st_T, A = ctx->st_A;
-    int rc = ensure(ctx, ctx->out_lagsum, sizeof(double) * T);
+    if (h_bp && ld_host < A) return fail(ctx, TA_E_INVALID, "host row stride smaller than n_atoms");
+    // With a by-particle array the device->host copy (8 GB at 10000 x 100000) is several times
+    // the compute: atoms go in blocks, the copy of block c (a strided 2-D copy into the caller's
+    // (n_frames, ld_host) array, on a second stream) runs under the compute of block c + 1.
+    const int64_t CH = ctx->opt_bp_block > 0 ? (ctx->opt_bp_block + 63) / 64 * 64 : 16384;
+    const bool blocked = h_bp && A >= 2 * CH;
+    const int64_t n_blocks = blocked ? (A + CH - 1) / CH : 1;
+    // rows [0, n_blocks): per-block lag sums; row n_blocks: their sum (one block: row 0 is the sum)
+    int rc = ensure(ctx, ctx->out_lagsum, sizeof(double) * T * (n_blocks + 1));
     if (rc) return rc;
+    double* d_ls = (double*)ctx->out_lagsum.p;
     double* d_bp = nullptr;
     if (h_bp) {
         if ((rc = ensure(ctx, ctx->out_bp, sizeof(double) * (size_t)T * A))) return rc;
         d_bp = (double*)ctx->out_bp.p;
     }
-    double* d_ls = (double*)ctx->out_lagsum.p;
     const double* d_m = nullptr;
     if (which == W_HELFAND) {
         if (!h_masses) return fail(ctx, TA_E_INVALID, "h_masses is NULL");
@@ -910,51 +978,62 @@ static int host_compute(ta_ctx* ctx, int which, const double* h_masses, double s
                                        ctx->stream));
         d_m = (const double*)ctx->masses.p;
     }
-    // With a by-particle array the device->host copy (8 GB at 10000 x 100000) is several times
-    // the compute: atoms go in blocks, the copy of block c (a strided 2-D copy into the caller's
-    // (n_frames, n_atoms) array, on a second stream) runs under the compute of block c + 1.
-    const int64_t CH = ctx->opt_bp_block > 0 ? (ctx->opt_bp_block + 63) / 64 * 64 : 16384;
-    if (h_bp && A >= 2 * CH) {
-        const int64_t n_blocks = (A + CH - 1) / CH;
-        if ((rc = ensure(ctx, ctx->out_lagsum, sizeof(double) * T * n_blocks))) return rc;
-        d_ls = (double*)ctx->out_lagsum.p;
-        if (!ctx->copy_stream) TA_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-        std::vector<double> part((size_t)T * n_blocks);
-        const int D = ctx->st_D;
-        for (int64_t b = 0; b < n_blocks; ++b) {
-            const int64_t lo = b * CH, hi = std::min(A, lo + CH);
-            const int64_t pair_lo = lo * D / 2;  // lo is a multiple of 64: a pair boundary
-            const size_t off = (size_t)pair_lo * ctx->st_pitch * (ctx->st_dev_f32 ? 8 : 16);  // bytes
-            const void* v = (const char*)ctx->d_slabs[0] + off;
-            const void* x = need == 2 ? (const char*)ctx->d_slabs[1] + off : nullptr;
-            if ((rc = compute_pm(ctx, which, v, x, d_m ? d_m + lo : nullptr, ctx->st_pitch, T, hi - lo, D, scale,
-                                 d_ls + b * T, d_bp + lo, A, ctx->stream, true, ctx->st_dev_f32)))
-                return rc;
-            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
-            TA_HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_stage, 0));
-            TA_HIP_TRY(ctx, hipMemcpy2DAsync(h_bp + lo, sizeof(double) * A, d_bp + lo, sizeof(double) * A,
-                                             sizeof(double) * (hi - lo), T, hipMemcpyDeviceToHost,
-                                             ctx->copy_stream));
-        }
-        TA_HIP_TRY(ctx, hipMemcpyAsync(part.data(), d_ls, sizeof(double) * T * n_blocks, hipMemcpyDeviceToHost,
-                                       ctx->stream));
-        TA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        TA_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
-        const double n_at = (double)A;
-        for (int64_t k = 0; k < T; ++k) {
-            double sum = 0.0;
-            for (int64_t b = 0; b < n_blocks; ++b) sum += part[(size_t)b * T + k];
-            h_ts[k] = sum / n_at;
-        }
+    if (!blocked) {
+        if ((rc = staged_entry(ctx, which, d_m, scale, d_ls, d_bp, A, (void*)ctx->stream))) return rc;
+        if (h_bp)
+            TA_HIP_TRY(ctx, hipMemcpy2DAsync(h_bp, sizeof(double) * ld_host, d_bp, sizeof(double) * A,
+                                             sizeof(double) * A, T, hipMemcpyDeviceToHost, ctx->stream));
+        *d_total = d_ls;
         return TA_OK;
     }
-    if ((rc = staged_entry(ctx, which, d_m, scale, d_ls, d_bp, A, (void*)ctx->stream))) return rc;
-    TA_HIP_TRY(ctx, hipMemcpyAsync(h_ts, d_ls, sizeof(double) * T, hipMemcpyDeviceToHost, ctx->stream));
-    if (h_bp)
-        TA_HIP_TRY(ctx, hipMemcpyAsync(h_bp, d_bp, sizeof(double) * (size_t)T * A, hipMemcpyDeviceToHost,
-                                       ctx->stream));
+    if (!ctx->copy_stream) TA_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    const int D = ctx->st_D;
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        const int64_t lo = b * CH, hi = std::min(A, lo + CH);
+        const int64_t pair_lo = lo * D / 2;  // lo is a multiple of 64: a pair boundary
+        const size_t off = (size_t)pair_lo * ctx->st_pitch * (ctx->st_dev_f32 ? 8 : 16);  // bytes
+        const void* v = (const char*)ctx->d_slabs[0] + off;
+        const void* x = need == 2 ? (const char*)ctx->d_slabs[1] + off : nullptr;
+        if ((rc = compute_pm(ctx, which, v, x, d_m ? d_m + lo : nullptr, ctx->st_pitch, T, hi - lo, D, scale,
+                             d_ls + b * T, d_bp + lo, A, ctx->stream, true, ctx->st_dev_f32)))
+            return rc;
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
+        TA_HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_stage, 0));
+        TA_HIP_TRY(ctx, hipMemcpy2DAsync(h_bp + lo, sizeof(double) * ld_host, d_bp + lo, sizeof(double) * A,
+                                         sizeof(double) * (hi - lo), T, hipMemcpyDeviceToHost,
+                                         ctx->copy_stream));
+    }
+    // the blocks' lag sums, added on the device in a fixed order
+    TA_HIP_TRY(ctx, launch_sum_partials(d_ls, (int)n_blocks, T, d_ls + n_blocks * T, ctx->stream));
+    *d_total = d_ls + n_blocks * T;
+    return TA_OK;
+}
+
+int host_wait(ta_ctx* ctx) {
+    TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     TA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    const double n_at = (double)A;  // mean over atoms (velocityautocorr.py:214,237)
+    if (ctx->copy_stream) TA_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+    return TA_OK;
+}
+hipStream_t ctx_stream(ta_ctx* ctx) { return ctx->stream; }
+int ctx_device(const ta_ctx* ctx) { return ctx->device; }
+int64_t ctx_staged_frames(const ta_ctx* ctx) { return ctx->st_nslabs ? ctx->st_T : 0; }
+int ctx_fail(ta_ctx* ctx, int code, const std::string& msg) { return fail(ctx, code, msg); }
+}  // namespace ta
+
+extern "C" {
+
+static int host_compute(ta_ctx* ctx, int which, const double* h_masses, double scale,
+                        double* h_ts, double* h_bp) {
+    if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    if (!h_ts) return fail(ctx, TA_E_INVALID, "h_timeseries is NULL");
+    double* d_total = nullptr;
+    int rc = host_launch(ctx, which, h_masses, scale, h_bp, ctx->st_A, &d_total);
+    if (rc) return rc;
+    const int64_t T = ctx->st_T;
+    TA_HIP_TRY(ctx, hipMemcpyAsync(h_ts, d_total, sizeof(double) * T, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = host_wait(ctx))) return rc;
+    const double n_at = (double)ctx->st_A;  // mean over atoms (velocityautocorr.py:214,237)
     for (int64_t k = 0; k < T; ++k) h_ts[k] /= n_at;
     return TA_OK;
 }

@@ -15,6 +15,7 @@
 // stands.  The transposition runs on the committed chunk while the next chunk crosses PCIe.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 
 #include "ta_internal.hpp"
@@ -52,6 +53,43 @@ __global__ void __launch_bounds__(256)
             if constexpr (sizeof(DstT) == 8) *reinterpret_cast<double2*>(d) = v;
             else *reinterpret_cast<float2*>(d) = float2{(float)v.x, (float)v.y};
         }
+    }
+}
+
+// float64 -> float64 with 16-byte accesses on BOTH sides (ld_row even, bases 16-byte aligned, so that
+// the two columns of a pair are one aligned 16-byte element of the source row): a tile of 64 rows
+// x 64 pairs of 16-byte elements through LDS (rows padded to 65 elements: the transposed
+// ds_read_b128 is conflict-free), 1 KiB per wave instruction in (64 pairs of one row) and out
+// (64 rows of one pair).  The frame-major *_dev inputs take this path: the 8-byte reads of the
+// generic kernel ran at 4.5 TB/s (read + write).
+constexpr int kWideLds = 64 * 65 * 16;
+__global__ void __launch_bounds__(256)
+    k_relayout_wide(const double* __restrict__ src, long ld_row, long n_cols, long t_count,
+                    double* __restrict__ dst, long pitch, long t_dst0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wide_raw[];
+    double2(*tile)[65] = reinterpret_cast<double2(*)[65]>(wide_raw);
+    const int tid = threadIdx.x, q = tid >> 6, l = tid & 63;
+    const long p0 = (long)blockIdx.x * 64, r0 = (long)blockIdx.y * 64;
+    const long n_pairs = (n_cols + 1) / 2;
+    double2 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {  // row 4 i + q of the tile, pair l
+        const long t = r0 + 4 * i + q, c = 2 * (p0 + l);
+        v[i] = double2{0.0, 0.0};
+        if (t < t_count) {
+            const double* s = src + t * ld_row + c;
+            if (c + 1 < n_cols) v[i] = *reinterpret_cast<const double2*>(s);
+            else if (c < n_cols) v[i].x = s[0];  // an odd last column is paired with zeros
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tile[4 * i + q][l] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {  // pair 4 i + q of the tile, row l
+        const long pair = p0 + 4 * i + q, t = r0 + l;
+        if (pair < n_pairs && t < t_count)
+            *reinterpret_cast<double2*>(dst + (pair * pitch + t_dst0 + t) * 2) = tile[l][4 * i + q];
     }
 }
 
@@ -174,6 +212,22 @@ __global__ void __launch_bounds__(256)
 hipError_t launch_relayout(const void* src, bool src_f32, long ld_row, long n_cols, long t_count,
                            void* dst, bool dst_f32, long pitch, long t_dst0, hipStream_t st) {
     if (t_count <= 0 || n_cols <= 0) return hipSuccess;
+    if (!src_f32 && !dst_f32 && ld_row % 2 == 0 && ((uintptr_t)src & 15) == 0) {
+        static std::atomic<bool> set[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !set[dev].load(std::memory_order_acquire)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_relayout_wide),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) set[dev].store(true, std::memory_order_release);
+        }
+        const long n_pairs = (n_cols + 1) / 2;
+        const dim3 wgrid((unsigned)((n_pairs + 63) / 64), (unsigned)((t_count + 63) / 64));
+        hipLaunchKernelGGL(k_relayout_wide, wgrid, dim3(256), kWideLds, st, (const double*)src, ld_row, n_cols, t_count,
+                           (double*)dst, pitch, t_dst0);
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)((n_cols + 63) / 64), (unsigned)((t_count + 63) / 64));
 #define TA_GO(S, Dt) \
     hipLaunchKernelGGL((k_relayout<S, Dt>), grid, dim3(256), 0, st, (const S*)src, ld_row, n_cols, t_count, (Dt*)dst, pitch, t_dst0)

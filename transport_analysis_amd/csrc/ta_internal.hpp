@@ -8,7 +8,20 @@
 
 #include "fft_engine.hpp"
 
+struct ta_ctx;
+
 namespace ta {
+
+// api.hip, for group.hip (several contexts driven by one host thread): one context's share of a
+// host-facing call queued on its streams (which: 0 FFT VACF, 1 windowed VACF, 2 Helfand), the sum
+// over its atoms left on the device; host_wait blocks until that work and its copies are done
+int host_launch(ta_ctx* ctx, int which, const double* h_masses, double scale, double* h_bp, int64_t ld_host,
+                double** d_total);
+int host_wait(ta_ctx* ctx);
+hipStream_t ctx_stream(ta_ctx* ctx);
+int ctx_device(const ta_ctx* ctx);
+int64_t ctx_staged_frames(const ta_ctx* ctx);
+int ctx_fail(ta_ctx* ctx, int code, const std::string& msg);  // records the message, returns code
 
 // direct.hip
 // vel / pos: pair-major slabs (layout.hip) of `pitch` rows per pair, float64 or (src_f32, with the
@@ -62,6 +75,10 @@ int wfft_threads(int R0);
 // accg [nwg / 2R][L] partial spectra; by-particle mode n_units atoms -> accg [n_units][L]
 hipError_t launch_wfft_forward(int R0, int R, bool by_particle, int nwg, hipStream_t st, const double* pm,
                                long pitch, int T, long n_units, int D, const cd* tw, double* accg);
+// the lag-sum forward kernel built with in-kernel clock stamps (plans R0 = 8, 10, 12, 16, 20 without an
+// outer radix): stamps[16 * workgroup + ...], see wfft.hpp (ta_clock_probe)
+hipError_t launch_wfft_forward_stamp(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
+                                     long n_units, const cd* tw, double* accg, unsigned long long* stamps);
 // inverse kernel (R0 > 1): lag values of n_items spectra, out[item * ld + lag]
 hipError_t launch_wfft_inverse(int R0, int R, int nwg, hipStream_t st, const double* spec, int T, long n_items,
                                const cd* tw, double* out, long ld, int prefetch);

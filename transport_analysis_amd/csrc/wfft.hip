@@ -50,6 +50,20 @@ hipError_t launch_forward_r0(int R, bool byp, int nwg, hipStream_t st, const dou
     return hipGetLastError();
 }
 
+// diagnostic build of the lag-sum forward kernel (R = 1) with in-kernel s_memtime / s_memrealtime
+// stamps (ta_clock_probe): 16 unsigned 64-bit slots per workgroup
+template <int R0>
+hipError_t launch_forward_stamp_r0(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_units,
+                                   const cd* tw, double* accg, unsigned long long* stamps) {
+    using P = WPlan<R0>;
+    auto kern = k_wsplit_accum<P, false, false, true>;
+    static DevFlag done[kMaxDev];
+    hipError_t e = set_lds(kern, P::kLds, done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_units, tw, accg, 1, 1, stamps);
+    return hipGetLastError();
+}
+
 template <int R0>
 hipError_t launch_inverse_r0(int R, int nwg, hipStream_t st, const double* spec, int T, long n_items, const cd* tw,
                              double* out, long ld, int pf) {
@@ -254,6 +268,19 @@ hipError_t launch_wfft_forward(int R0, int R, bool by_particle, int nwg, hipStre
         case 16: return launch_forward_r0<16>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 18: return launch_forward_r0<18>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
         case 20: return launch_forward_r0<20>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_wfft_forward_stamp(int R0, int nwg, hipStream_t st, const double* pm, long pitch, int T,
+                                     long n_units, const cd* tw, double* accg, unsigned long long* stamps) {
+    if (nwg < 16 || nwg % 16) return hipErrorInvalidValue;
+    switch (R0) {
+        case 8: return launch_forward_stamp_r0<8>(nwg, st, pm, pitch, T, n_units, tw, accg, stamps);
+        case 10: return launch_forward_stamp_r0<10>(nwg, st, pm, pitch, T, n_units, tw, accg, stamps);
+        case 12: return launch_forward_stamp_r0<12>(nwg, st, pm, pitch, T, n_units, tw, accg, stamps);
+        case 16: return launch_forward_stamp_r0<16>(nwg, st, pm, pitch, T, n_units, tw, accg, stamps);
+        case 20: return launch_forward_stamp_r0<20>(nwg, st, pm, pitch, T, n_units, tw, accg, stamps);
     }
     return hipErrorInvalidValue;
 }

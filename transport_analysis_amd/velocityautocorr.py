@@ -45,12 +45,20 @@ class VelocityAutocorr(AnalysisBase):
         Element type of the pinned staging slab.  Default: the dtype MDAnalysis hands the
         velocities out in (float32) -- lossless, half the PCIe bytes of the reference's
         float64 slab; the device slab and all arithmetic are float64 either way.
+    devices : sequence of int, keyword-only
+        Several GPUs from ONE process and ONE pass over the trajectory: the
+        atoms are split into contiguous blocks, one per GPU; every frame's columns go straight
+        into each GPU's pinned slab, the kernels run on all GPUs at once, the lag sums are reduced
+        once inside the library (RCCL) and ``results.vacf_by_particle`` is ONE
+        ``(n_frames, n_particles)`` array whose column ranges the GPUs fill.  The script is the
+        reference's, unchanged.  Exclusive with ``distributed``.
     distributed : bool, keyword-only, default False
         One process per GPU under ``torch.distributed`` (e.g. ``torchrun``): every rank runs
         the same script on the same AtomGroup, stages and correlates only its contiguous block
-        of atoms and ONE all-reduce of the lag sums gives ``results.timeseries`` (the mean over
-        ALL atoms) on every rank.  ``results.vacf_by_particle`` then holds this rank's atoms
-        only, ``results.particle_range = (lo, hi)``.
+        of atoms (and asks the trajectory for that block's velocities only) and ONE all-reduce of
+        the lag sums gives ``results.timeseries`` (the mean over ALL atoms) on every rank.
+        ``results.vacf_by_particle`` then holds this rank's atoms only,
+        ``results.particle_range = (lo, hi)``.
 
     Attributes
     ----------
@@ -64,7 +72,14 @@ class VelocityAutocorr(AnalysisBase):
         self._want_by_particle = bool(kwargs.pop("by_particle", True))
         self._distributed = bool(kwargs.pop("distributed", False))
         self._stage_dtype = kwargs.pop("stage_dtype", None)
+        devices = kwargs.pop("devices", None)
+        self._devices = None if devices is None else [int(d) for d in devices]
+        if self._devices is not None and self._distributed:
+            raise ValueError("devices=[...] (one process, several GPUs) and distributed=True "
+                             "(one process per GPU) are exclusive")
         device = kwargs.pop("device", None)
+        if device is None and self._devices:
+            device = self._devices[0]
         if device is None:
             if self._distributed:  # one process per GPU: this rank's own device
                 from .dist import default_device
@@ -113,17 +128,30 @@ class VelocityAutocorr(AnalysisBase):
     def _prepare(self):
         """Pinned host slab + device slab instead of ``np.zeros`` (:142-153)."""
         if self._ctx is None:
-            self._ctx = _lib.Context(self._device)
+            self._ctx = _lib.Group(self._devices) if self._devices is not None else _lib.Context(self._device)
         self._lo, self._hi = 0, self.n_particles
+        self._source = self.atomgroup  # whose velocities a frame is read from
         if self._distributed:
             from .dist import shard_of_this_rank
 
             _, _, self._lo, self._hi = shard_of_this_rank(self.n_particles)
             self.results.particle_range = (self._lo, self._hi)
+            # this rank's block only: the trajectory gathers hi - lo atoms per frame, not all of them
+            self._source = self.atomgroup[self._lo:self._hi]
         self._n_local = self._hi - self._lo
         dtype = self._pick_stage_dtype()
-        (self._velocities,) = self._ctx.stage_alloc(
-            self.n_frames, max(self._n_local, 1), self.dim_fac, n_slabs=1, dtype=dtype)
+        if self._devices is not None:
+            # one pinned slab per GPU, each holding that GPU's column block; filled in ONE frame loop
+            (views,) = self._ctx.stage_alloc(self.n_frames, self.n_particles, self.dim_fac, n_slabs=1, dtype=dtype)
+            self._velocities = views
+            self._targets = [(v, lo, hi) for v, (lo, hi) in zip(views, self._ctx.shards) if hi > lo]
+            self.results.device_ranges = list(self._ctx.shards)
+        else:
+            (self._velocities,) = self._ctx.stage_alloc(
+                self.n_frames, max(self._n_local, 1), self.dim_fac, n_slabs=1, dtype=dtype)
+            # (columns of the source group: the distributed source is the block itself)
+            self._targets = [(self._velocities, 0, self._n_local)] if self._distributed else \
+                [(self._velocities, self._lo, self._hi)]
         frame_bytes = max(1, self._n_local * self.dim_fac * dtype.itemsize)
         self._commit_every = max(1, _COMMIT_BYTES // frame_bytes)
         self._committed = 0
@@ -140,9 +168,10 @@ class VelocityAutocorr(AnalysisBase):
         if not self._ts.has_velocities:
             raise NoDataError("VACF computation requires velocities in the trajectory")
         i = self._frame_index
-        vel = self.atomgroup.velocities
         if self._n_local:
-            stage_columns(self._velocities[i], np.asarray(vel), self._lo, self._hi, self._dim)
+            vel = np.asarray(self._source.velocities)
+            for view, lo, hi in self._targets:
+                stage_columns(view[i], vel, lo, hi, self._dim)
         if i + 1 - self._committed >= self._commit_every:
             self._ctx.stage_commit(self._committed, i + 1)
             self._committed = i + 1

@@ -58,7 +58,14 @@ class ViscosityHelfand(AnalysisBase):
         self._want_by_particle = bool(kwargs.pop("by_particle", True))
         self._distributed = bool(kwargs.pop("distributed", False))
         self._stage_dtype = kwargs.pop("stage_dtype", None)
+        devices = kwargs.pop("devices", None)
+        self._devices = None if devices is None else [int(d) for d in devices]
+        if self._devices is not None and self._distributed:
+            raise ValueError("devices=[...] (one process, several GPUs) and distributed=True "
+                             "(one process per GPU) are exclusive")
         device = kwargs.pop("device", None)
+        if device is None and self._devices:
+            device = self._devices[0]
         if device is None:
             if self._distributed:  # one process per GPU: this rank's own device
                 from .dist import default_device
@@ -109,22 +116,35 @@ class ViscosityHelfand(AnalysisBase):
     def _prepare(self):
         """Two pinned slabs (velocities, positions) + volumes + masses (:111-142)."""
         if self._ctx is None:
-            self._ctx = _lib.Context(self._device)
+            self._ctx = _lib.Group(self._devices) if self._devices is not None else _lib.Context(self._device)
         self._ctx.set_option("direct_f32", int(self._float32))
         self._ctx.set_option("helfand_fft", int(self._fft))
         # float32 path: the device slabs keep float32 staging as float32 (half the footprint; the
         # kernels round the staged value to float32 anyway, so the results do not change)
         self._ctx.set_option("stage_device_f32", int(self._float32))
         self._lo, self._hi = 0, self.n_particles
+        self._source = self.atomgroup  # whose velocities / positions a frame is read from
         if self._distributed:
             from .dist import shard_of_this_rank
 
             _, _, self._lo, self._hi = shard_of_this_rank(self.n_particles)
             self.results.particle_range = (self._lo, self._hi)
+            # this rank's block only: the trajectory gathers hi - lo atoms per frame, not all of them
+            self._source = self.atomgroup[self._lo:self._hi]
         self._n_local = self._hi - self._lo
         dtype = self._pick_stage_dtype()
-        self._velocities, self._positions = self._ctx.stage_alloc(
-            self.n_frames, max(self._n_local, 1), self.dim_fac, n_slabs=2, dtype=dtype)
+        if self._devices is not None:
+            # one pair of pinned slabs per GPU (its column block); filled in ONE frame loop
+            vviews, xviews = self._ctx.stage_alloc(self.n_frames, self.n_particles, self.dim_fac, n_slabs=2,
+                                                   dtype=dtype)
+            self._velocities, self._positions = vviews, xviews
+            self._targets = [(v, x, lo, hi) for v, x, (lo, hi) in zip(vviews, xviews, self._ctx.shards) if hi > lo]
+            self.results.device_ranges = list(self._ctx.shards)
+        else:
+            self._velocities, self._positions = self._ctx.stage_alloc(
+                self.n_frames, max(self._n_local, 1), self.dim_fac, n_slabs=2, dtype=dtype)
+            self._targets = [(self._velocities, self._positions, 0, self._n_local)] if self._distributed else \
+                [(self._velocities, self._positions, self._lo, self._hi)]
         self._volumes = np.zeros(self.n_frames)
         self._masses = np.asarray(self.atomgroup.masses, dtype=np.float64)[self._lo:self._hi]
         if self._n_local == 0:
@@ -156,8 +176,10 @@ class ViscosityHelfand(AnalysisBase):
         i = self._frame_index
         self._volumes[i] = ts.volume
         if self._n_local:
-            stage_columns(self._velocities[i], np.asarray(self.atomgroup.velocities), self._lo, self._hi, self._dim)
-            stage_columns(self._positions[i], np.asarray(self.atomgroup.positions), self._lo, self._hi, self._dim)
+            vel, pos = np.asarray(self._source.velocities), np.asarray(self._source.positions)
+            for vview, xview, lo, hi in self._targets:
+                stage_columns(vview[i], vel, lo, hi, self._dim)
+                stage_columns(xview[i], pos, lo, hi, self._dim)
         if i + 1 - self._committed >= self._commit_every:
             self._ctx.stage_commit(self._committed, i + 1)
             self._committed = i + 1
