@@ -33,6 +33,14 @@ CLASS end to end (frames staged through pinned memory, result array in pinned me
 N > 1 (and N = 1 under torchrun with TA_BENCH_FORCE_DIST=1): `config.rank_devices` lists the GPU
 every rank ran on (the run fails unless they are N distinct devices) and `reduce_us` is the
 all-reduce alone.
+`--single-process` (not under torchrun) runs the N GPUs from THIS process through the library's
+own fan-out (ta_group: one context per device, the reduce inside the call -- RCCL for distinct
+devices); a step is then one host-facing ta_group_vacf_fft call, the (n_frames,) result on the
+host included.  `--devices 0,0` picks the members explicitly (two members on one GPU: what a
+one-GPU box can rehearse).  `device_ms.effective_mhz` is the clock the headline kernel ran at,
+measured inside a stamped build of it (ta_clock_probe) right after the timed region;
+`roofline.model_ceiling` is what this transform structure can reach under the package power
+limit.
 """
 import argparse
 import hashlib
@@ -75,7 +83,74 @@ def parse():
     ap.add_argument("--no-kernel-split", action="store_true",
                     help="skip the extra untimed step that records the per-kernel event timeline")
     ap.add_argument("--cpu-sample-atoms", type=int, default=0)
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs from one process: the library's own fan-out and reduce (ta_group)")
+    ap.add_argument("--devices", default="",
+                    help="--single-process: comma-separated device ids of the members (default 0..N-1)")
+    ap.add_argument("--no-clock-probe", action="store_true")
     return ap.parse_args()
+
+
+# Ceiling of this transform structure under the package power limit (DESIGN.md section 6,
+# profiles/r04_power_clock.txt): every plan of the forward kernel runs AT the 1400 W cap
+# (1352-1390 W measured), so throughput = power / energy per input byte; the most frugal plan
+# measured needs 0.453 nJ/B (R0 = 12: 1389 W at 3064 GB/s), the headline's R0 = 20 0.525 nJ/B.
+POWER_CAP_W = 1400.0
+BEST_PLAN_NJ_PER_BYTE = 0.453
+
+
+def model_ceiling():
+    gbps = POWER_CAP_W / BEST_PLAN_NJ_PER_BYTE
+    return {"frac": gbps / HBM_PEAK_GBPS, "GBps": gbps,
+            "basis": "package power cap / lowest energy per input byte measured over the forward kernel's plans "
+                     "(profiles/r04_power_clock.txt); the kernel is power-bound, not issue- or bandwidth-bound"}
+
+
+def single_process(args):
+    """N GPUs from one process through ta_group: every member's column block of the ONE synthetic
+    tensor resident on its device, a step = ta_group_vacf_fft (fan-out, reduce inside the library,
+    (n_frames,) timeseries on the host)."""
+    import numpy as np
+
+    from transport_analysis_amd import _lib
+    from oracle import synth
+
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        raise SystemExit("--devices must name --gpus devices")
+    T, D = args.frames, args.dim
+    a_total = args.atoms * args.gpus if args.scaling == "weak" else args.atoms
+    g = _lib.Group(devices)
+    g.stage_alloc_device(T, a_total, D, n_slabs=1)
+    g.stage_synth(0, SEED + 3, 0, a_total * D)
+    fn = {"fft": g.vacf_fft, "direct": g.vacf_direct}[args.mode]
+    for _ in range(args.warmup):
+        ts, _ = fn(by_particle=False)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts, _ = fn(by_particle=False)
+    elapsed = time.perf_counter() - t0
+    check = {}
+    if not args.no_check and args.mode == "fft":  # lag 0 of the mean = mean square of the tensor's first columns
+        blk = synth.synthetic_block(SEED + 3, T, a_total * D, 0, min(a_total * D, 96))
+        check["lag0_vs_numpy_block_mean_square"] = float(ts[0] / D), float(np.mean(blk * blk))
+    out = {
+        "metric": "VACF lag-points/sec (n_frames x n_atoms / s)", "value": T * a_total / (elapsed / args.steps),
+        "unit": "lag-points/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"FFT VACF timeseries, {T} frames x {a_total} atoms x {D} float64, atoms sharded over "
+                               f"{args.gpus} member(s) of ONE process (ta_group; host-facing call, result on the host)",
+                   "n_frames": T, "n_atoms_total": a_total, "dim": D, "mode": args.mode,
+                   "sharding": f"atoms x{args.gpus}", "member_devices": devices, "shards": g.shards,
+                   "collective": g.reduce_kind, "library_sha16": so_sha16(), "launcher": "single process"},
+        "check": check,
+        "note": "hardware scaling of this mode is unmeasured until a multi-GPU node runs it; members that share a "
+                "device (e.g. --devices 0,0) serialise on it",
+    }
+    print(json.dumps(out), flush=True)
+    g.close()
+
 
 
 def fft_flops(T, n_cols, M):
@@ -384,10 +459,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_process:
+        if world > 1:
+            raise SystemExit("--single-process drives the GPUs itself: do not launch it under torchrun")
+        return single_process(args)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run (one rank per GPU)")
+        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run (one rank per GPU), "
+                         "or pass --single-process (the library's own fan-out)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # TA_BENCH_ONE_GPU=1: rehearsal of the N > 1 path on a one-GPU box (tests/test_gpu_dist.py):
@@ -467,6 +547,13 @@ def main():
     hist = ctx.timing_history(min(args.steps, 64))
     kernel_ms = statistics.median(m for _, m in hist)
     total_ms = statistics.median(t for t, _ in hist)
+    # the clock the headline kernel holds: >= 2 s of back-to-back launches of its stamped build
+    clock = None
+    if args.mode == "fft" and not args.by_particle and not args.no_clock_probe and world == 1:
+        try:
+            clock = ctx.clock_probe(max(20, int(2500.0 / max(kernel_ms, 0.05))))
+        except Exception as e:  # plans without a stamped build
+            clock = {"error": str(e)[:160]}
 
     # validity of the timed result (N = 1): the staged tensor IS the NumPy generator's (bit for
     # bit, on a block), and a few lags agree with plain torch reductions over the whole tensor
@@ -540,6 +627,11 @@ def main():
         "device_ms": {"whole_call_median": total_ms, "dominant_kernel_median": kernel_ms},
         "check": check,
     }
+    if clock is not None:
+        out["device_ms"]["effective_mhz"] = clock.get("mhz")
+        out["device_ms"]["clock_probe"] = clock
+    if args.mode == "fft" and not composite:
+        out["roofline"]["model_ceiling"] = model_ceiling()
     if reduce_us is not None:
         out["reduce_us"] = reduce_us  # the all-reduce of the (n_frames,) lag sums alone, median per step
     if world == 1 and not args.no_other_configs and args.mode == "fft" and not args.by_particle:

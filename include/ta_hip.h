@@ -205,6 +205,10 @@ int ta_group_set_option(ta_group *g, const char *key, int64_t value);
 int ta_group_stage_alloc(ta_group *g, int64_t n_frames, int64_t n_atoms, int dim, int dtype,
                          int n_slabs, void **h_slabs);
 int ta_group_stage_commit(ta_group *g, int64_t frame_lo, int64_t frame_hi);
+/* device slabs only + the benchmark generator on every member's columns of the one synthetic
+ * tensor (member i: col_offset + lo_i * dim), as ta_stage_alloc_device / ta_stage_synth          */
+int ta_group_stage_alloc_device(ta_group *g, int64_t n_frames, int64_t n_atoms, int dim, int n_slabs);
+int ta_group_stage_synth(ta_group *g, int slab, uint64_t seed, int64_t col_offset, int64_t n_cols_total);
 int ta_group_stage_free(ta_group *g);
 int ta_group_vacf_fft(ta_group *g, double *h_timeseries, double *h_by_particle);
 int ta_group_vacf_direct(ta_group *g, double *h_timeseries, double *h_by_particle);

@@ -30,7 +30,7 @@ EXPORTS = (
     "ta_host_alloc", "ta_host_alloc_on", "ta_host_free",
     "ta_group_create", "ta_group_destroy", "ta_group_last_error", "ta_group_size", "ta_group_member",
     "ta_group_shard", "ta_group_reduce_kind", "ta_group_set_option", "ta_group_stage_alloc",
-    "ta_group_stage_commit", "ta_group_stage_free", "ta_group_vacf_fft", "ta_group_vacf_direct",
+    "ta_group_stage_commit", "ta_group_stage_free", "ta_group_stage_alloc_device", "ta_group_stage_synth", "ta_group_vacf_fft", "ta_group_vacf_direct",
     "ta_group_helfand_msd",
 )
 
@@ -140,6 +140,8 @@ def lib():
     L.ta_group_stage_alloc.argtypes = [vp, i64, i64, ci, ci, ci, ctypes.POINTER(vp)]
     L.ta_group_stage_commit.argtypes = [vp, i64, i64]
     L.ta_group_stage_free.argtypes = [vp]
+    L.ta_group_stage_alloc_device.argtypes = [vp, i64, i64, ci, ci]
+    L.ta_group_stage_synth.argtypes = [vp, ci, ctypes.c_uint64, i64, i64]
     L.ta_group_vacf_fft.argtypes = [vp, vp, vp]
     L.ta_group_vacf_direct.argtypes = [vp, vp, vp]
     L.ta_group_helfand_msd.argtypes = [vp, vp, dbl, vp, vp]
@@ -520,6 +522,15 @@ class Group:
 
     def stage_commit(self, frame_lo, frame_hi):
         self._check(lib().ta_group_stage_commit(self._h, int(frame_lo), int(frame_hi)))
+
+    def stage_alloc_device(self, n_frames, n_atoms, dim, n_slabs=1):
+        self._drop_views()
+        self._check(lib().ta_group_stage_alloc_device(self._h, n_frames, n_atoms, dim, n_slabs))
+        self.shards = [self.shard(n_atoms, i) for i in range(len(self.devices))]
+        self.shape = (int(n_frames), int(n_atoms), int(dim))
+
+    def stage_synth(self, slab, seed, col_offset, n_cols_total):
+        self._check(lib().ta_group_stage_synth(self._h, slab, int(seed), int(col_offset), int(n_cols_total)))
 
     def stage_free(self):
         self._drop_views()

@@ -326,6 +326,37 @@ int ta_group_stage_alloc(ta_group* g, int64_t n_frames, int64_t n_atoms, int dim
     return TA_OK;
 }
 
+int ta_group_stage_alloc_device(ta_group* g, int64_t n_frames, int64_t n_atoms, int dim, int n_slabs) {
+    if (!g) return gfail(nullptr, TA_E_INVALID, "null group");
+    if (n_frames < 1 || n_atoms < 1 || dim < 1 || dim > 3 || n_slabs < 1 || n_slabs > 4)
+        return gfail(g, TA_E_INVALID, "need n_frames >= 1, n_atoms >= 1, 1 <= dim <= 3, 1 <= n_slabs <= 4");
+    const int n = (int)g->ctx.size();
+    g->T = 0;
+    for (int i = 0; i < n; ++i) {
+        shard(n_atoms, i, n, &g->lo[i], &g->hi[i]);
+        if (g->hi[i] == g->lo[i]) {
+            ta_stage_free(g->ctx[i]);
+            continue;
+        }
+        const int rc = ta_stage_alloc_device(g->ctx[i], n_frames, g->hi[i] - g->lo[i], dim, n_slabs);
+        if (rc) return mfail(g, i, rc);
+    }
+    g->T = n_frames, g->A = n_atoms, g->D = dim, g->n_slabs = n_slabs;
+    return TA_OK;
+}
+
+int ta_group_stage_synth(ta_group* g, int slab, uint64_t seed, int64_t col_offset, int64_t n_cols_total) {
+    if (!g) return gfail(nullptr, TA_E_INVALID, "null group");
+    if (g->T == 0) return gfail(g, TA_E_STATE, "slabs have not been staged");
+    for (size_t i = 0; i < g->ctx.size(); ++i) {  // member i: its own columns of the ONE synthetic tensor
+        if (g->hi[i] == g->lo[i]) continue;
+        const int rc = ta_stage_synth(g->ctx[i], slab, seed, col_offset + g->lo[i] * g->D, n_cols_total,
+                                      (void*)ctx_stream(g->ctx[i]));
+        if (rc) return mfail(g, (int)i, rc);
+    }
+    return TA_OK;
+}
+
 int ta_group_stage_commit(ta_group* g, int64_t frame_lo, int64_t frame_hi) {
     if (!g) return gfail(nullptr, TA_E_INVALID, "null group");
     if (g->T == 0) return gfail(g, TA_E_STATE, "ta_group_stage_alloc has not been called");
