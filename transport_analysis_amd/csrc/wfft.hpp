@@ -1279,6 +1279,23 @@ __global__ void __launch_bounds__(P::NT)
             v[s][2 * c2 + 1] = cd{a.y, b.y};
         }
     };
+    // A thread owns the same lags n = u + 512 j for every spectrum: the normalisation 1 / (2M (T - n))
+    // is formed ONCE per launch (an exact product, one division) and applied as a multiplication --
+    // twenty FP64 divisions (~30 instructions each) per thread and spectrum were 15 % of the
+    // kernel's vector instructions.  (Within one ulp of the quotient; the parity bar is 1e-10.)
+    // (plans from R0 = 9 on: one workgroup per compute unit whatever the register count; the smaller
+    // ones keep the division and their two or more workgroups per unit)
+    constexpr bool kHoistNorm = !LONG && R0 >= 9;
+    double rnorm[kHoistNorm ? K1 : 1][kHoistNorm ? R0 : 1];
+    if constexpr (kHoistNorm) {
+#pragma unroll
+        for (int k1 = 0; k1 < K1; ++k1)
+#pragma unroll
+            for (int j = 0; j < R0; ++j) {
+                const int n = tid + NT * k1 + N1 * j;
+                rnorm[k1][j] = n < T ? 1.0 / (2.0 * (double)M * (double)(T - n)) : 0.0;
+            }
+    }
 #pragma unroll
     for (int s = 0; s < PF; ++s) load_spec(blockIdx.x, 0, s);
     for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -1361,7 +1378,11 @@ __global__ void __launch_bounds__(P::NT)
                         const double ar = 0.5 * (x[j].x + qm.x), br = 0.5 * (x[j].y + qm.y),
                                      bi = -0.5 * (x[j].x - qm.x);
                         const double lagv = ar + (w.x * br - w.y * bi);
-                        if (n < T) o[n] = lagv / (2.0 * (double)M * (double)(T - n));  // 2M(T-n) < 2^53: exact product
+                        if constexpr (kHoistNorm) {
+                            if (n < T) o[n] = lagv * rnorm[k1][j];  // 1 / (2M (T - n))
+                        } else {
+                            if (n < T) o[n] = lagv / (2.0 * (double)M * (double)(T - n));  // 2M(T-n) < 2^53: exact product
+                        }
                     }
                 } else {
                     // passes c0 = 2 cp (real parts of the input) and c1 = c0 + 1 (imaginary parts):
