@@ -8,9 +8,9 @@
 # the library's hash.  usage: profile_all.sh TAG [quick]
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 QUICK=${2:-}
-COMMON="--no-cpu-baseline --no-other-configs --no-host-path --no-check --no-kernel-split"
+COMMON="--no-cpu-baseline --no-other-configs --no-host-path --no-check --no-kernel-split --no-clock-probe"
 export TA_TRAFFIC_MERGE=$R/gpurun_out/hbm_traffic_$TAG.json
 rm -f $TA_TRAFFIC_MERGE
 run() {  # name key kernels steps_total args...

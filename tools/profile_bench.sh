@@ -6,7 +6,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r01}
 shift || true
-ARGS=${@:-"--steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --no-host-path --no-check --no-kernel-split"}
+ARGS=${@:-"--steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --no-host-path --no-check --no-kernel-split --no-clock-probe"}
 KEY=${TA_TRAFFIC_KEY:-fft_10000x100000x3}
 KERN=${TA_TRAFFIC_KERNEL:-k_wsplit_accum}
 OUT=$R/gpurun_out/prof_$TAG
