@@ -656,6 +656,41 @@ def test_pair_major_layout_roundtrip(ctx, T, A, D, dtype):
     assert np.array_equal(out.cpu().numpy(), wide.cpu().numpy()[:, 2:2 + A * D])
 
 
+@pytest.mark.parametrize("T,A,D,ld,off", [(130, 7, 3, 26, 2), (64, 64, 2, 128, 0), (257, 33, 3, 100, 0), (1, 1, 2, 2, 0),
+                                           (200, 129, 1, 130, 0)])
+def test_relayout_16_byte_path(ctx, T, A, D, ld, off):
+    """Frame-major float64 rows with an EVEN row stride and a 16-byte aligned base take the
+    transposition with 16-byte accesses on both sides (k_relayout_wide): odd column counts (the last
+    column paired with zeros), partial tiles in both directions, a column block of a wider tensor."""
+    import torch
+
+    rng = np.random.default_rng(T + 7 * A)
+    wide = torch.from_numpy(rng.standard_normal((T, ld))).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.stage_alloc_device(T, A, D, n_slabs=1)
+    assert (wide.data_ptr() + off * 8) % 16 == 0 and ld % 2 == 0
+    ctx.stage_commit_dev(0, wide.data_ptr() + off * 8, ld, 0, T, stream=st)
+    out = torch.empty((T, A * D), dtype=torch.float64, device="cuda")
+    ctx.stage_read_dev(0, out.data_ptr(), A * D, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), wide.cpu().numpy()[:, off:off + A * D])
+
+
+def test_clock_probe(ctx):
+    """ta_clock_probe: the stamped build of the lag-sum forward kernel reports a plausible shader
+    clock and cycle count on the staged slab; plans without a stamped build say so."""
+    from transport_analysis_amd import _lib
+
+    ctx.stage_alloc_device(10000, 600, 3, n_slabs=1)
+    ctx.stage_synth(0, 99, 0, 1800)
+    p = ctx.clock_probe(3)
+    assert 300.0 < p["mhz"] < 2600.0 and p["cycles_per_unit_pass"] > 1000 and p["ms_per_launch"] > 0
+    ctx.stage_alloc_device(700, 50, 3, n_slabs=1)  # R0 = 2: no stamped build
+    ctx.stage_synth(0, 99, 0, 150)
+    with pytest.raises(_lib.TAError, match="clock probe"):
+        ctx.clock_probe(1)
+
+
 @pytest.mark.parametrize("T,A,D,off,tot", [(50, 7, 3, 0, 21), (33, 5, 3, 6, 40), (128, 64, 1, 10, 100)])
 def test_synthetic_generator_bit_exact(ctx, T, A, D, off, tot):
     """ta_stage_synth == oracle.synth (NumPy) bit for bit: the CPU baseline and every GPU shard
