@@ -4,6 +4,10 @@
 //   wfft_test check            : 11 pairs; the summed spectrum of the forward kernel against a
 //                                long-double transform, and the inverse kernel's lag sums against
 //                                the direct sums of products
+//   wfft_test inv <n_items> [T] [reps]
+//                              : inverse kernel on n_items random spectra (by-particle shape: one
+//                                workgroup per spectrum, grid = compute units); built with
+//                                -DWF_INV_STAMP=1 also the cycles per phase
 //   wfft_test time <n_pairs> [T] [reps] [stamp]
 //                              : forward kernel, lag-sum mode; stamp = 1 adds the in-kernel s_memtime
 //                                split (S1 incl. waiting for rows / S2 incl. the barrier)
@@ -64,6 +68,63 @@ template <int R0>
 static int run(int R, int argc, char** argv) {
     using P = WPlan<R0>;
     const int M = P::M, L = 2 * R * M;
+    if (argc > 1 && !strcmp(argv[1], "inv")) {
+        const long n_items = argc > 2 ? atol(argv[2]) : 2048;
+        const int Ti = argc > 3 ? atoi(argv[3]) : (R * M == 10240 ? 10000 : R * M - 37);
+        const int reps_i = argc > 4 ? atoi(argv[4]) : 5;
+        const long ld = (Ti + 7) / 8 * 8;
+        hipDeviceProp_t pr;
+        CK(hipGetDeviceProperties(&pr, 0));
+        std::vector<cd> twv(wf_table_elems(R0, R));
+        wf_fill_table(R0, R, twv.data());
+        cd* dtw;
+        double *dspec, *dout;
+        CK(hipMalloc(&dtw, twv.size() * sizeof(cd)));
+        CK(hipMemcpy(dtw, twv.data(), twv.size() * sizeof(cd), hipMemcpyHostToDevice));
+        CK(hipMalloc(&dspec, (size_t)n_items * L * 8));
+        CK(hipMalloc(&dout, (size_t)n_items * ld * 8));
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, dspec, (size_t)n_items * L, 777ull);
+        CK(hipDeviceSynchronize());
+        auto go = [&](auto kern) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)P::kLds));
+            hipLaunchKernelGGL(kern, dim3(std::min<long>(pr.multiProcessorCount, n_items)), dim3(P::NT), P::kLds, 0, dspec,
+                               Ti, n_items, dtw, dout, ld, R);
+            CK(hipGetLastError());
+        };
+        auto launch_inv = [&]() {
+            if (R > 1) go(k_winverse<P, true, 0>);
+            else go(k_winverse<P, false, (P::NS1 < 2 ? P::NS1 : 2)>);  // the library's default prefetch depth
+        };
+        launch_inv();
+        CK(hipDeviceSynchronize());
+#if WF_INV_STAMP
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(wf_inv_stamps), z, sizeof(z)));
+#endif
+        hipEvent_t a0, a1;
+        CK(hipEventCreate(&a0));
+        CK(hipEventCreate(&a1));
+        float best = 1e30f;
+        for (int r = 0; r < reps_i; ++r) {
+            CK(hipEventRecord(a0, 0));
+            launch_inv();
+            CK(hipEventRecord(a1, 0));
+            CK(hipEventSynchronize(a1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a0, a1));
+            best = std::min(best, ms);
+        }
+        printf("inverse R0=%d R=%d T=%d items=%ld: best %.3f ms = %.2f us per item and CU  (x100000 items: %.2f ms)\n", R0, R, Ti,
+               n_items, best, best * 1e3 * pr.multiProcessorCount / n_items, best * 100000.0 / n_items);
+#if WF_INV_STAMP
+        CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(wf_inv_stamps), sizeof(z)));
+        const double it = (double)z[4];
+        printf("cycles per item (wave 0): sub-series stage incl. spectrum wait %.0f  radix-R0 %.0f  Q to LDS %.0f  untangle + stores %.0f  total %.0f\n",
+               z[0] / it, z[1] / it, z[2] / it, z[3] / it, (z[0] + z[1] + z[2] + z[3]) / it);
+#endif
+        return 0;
+    }
     const bool check = argc < 2 || !strcmp(argv[1], "check");
     const long n_pairs = check ? 11 : atol(argv[2]);
     const int T = argc > 3 ? atoi(argv[3]) : (R * M == 10240 ? 10000 : R * M - 37);

@@ -1245,6 +1245,15 @@ struct WfSubT {
 };
 
 
+#ifndef WF_INV_STAMP
+#define WF_INV_STAMP 0  // diagnostic builds (tools/wfft): shader cycles per phase of k_winverse, summed over
+                        // workgroups (wave 0) into wf_inv_stamps: [0] sub-series stage incl. waiting for the
+                        // spectrum, [1] radix-R0 stage, [2] Q to LDS, [3] untangling + stores, [4] items
+#endif
+#if WF_INV_STAMP
+__device__ unsigned long long wf_inv_stamps[8];
+#endif
+
 template <class P, bool LONG = false, int PF = 0>
 __global__ void __launch_bounds__(P::NT)
     k_winverse(const double* __restrict__ spec, int T, long n_items, const cd* __restrict__ tw2,
@@ -1296,9 +1305,23 @@ __global__ void __launch_bounds__(P::NT)
                 rnorm[k1][j] = n < T ? 1.0 / (2.0 * (double)M * (double)(T - n)) : 0.0;
             }
     }
+#if WF_INV_STAMP
+    unsigned long long ist[5] = {0, 0, 0, 0, 0}, iprev = __builtin_amdgcn_s_memtime();
+#define WF_ISTAMP(i)                                                      \
+    {                                                                     \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
+        ist[i] += now_ - iprev;                                           \
+        iprev = now_;                                                     \
+    }
+#else
+#define WF_ISTAMP(i)
+#endif
 #pragma unroll
     for (int s = 0; s < PF; ++s) load_spec(blockIdx.x, 0, s);
     for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
+#if WF_INV_STAMP
+        ++ist[4];
+#endif
         for (int cp = 0; cp < R; ++cp) {
             // per-thread offsets and LDS addresses are re-formed per transform: hoisted out of the
             // loops they would be spilled
@@ -1319,6 +1342,7 @@ __global__ void __launch_bounds__(P::NT)
                     if (NW * s + NW - 1 < R0 || q < R0) wt.run(lds + q * N1, v[s], twa, twb);
                 }
             }
+            WF_ISTAMP(0)
             __syncthreads();
             if constexpr (PF > 0) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -1349,7 +1373,11 @@ __global__ void __launch_bounds__(P::NT)
                 }
                 Dft<R0>::run(x);  // x[j'] = Q[u + 512 j']
             }
-            __syncthreads();  // every thread has read its G values: LDS free for Q in natural order
+            WF_ISTAMP(1)
+            // No barrier here: thread u has read G_q[u] for every q -- column u of every 8 KiB block --
+            // and writes Q[u + 512 j] into the SAME column of the same blocks; nobody else touches it.
+            // (Round 4: the barrier that stood here cost the waves of a SIMD their skew twice.)
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k1 = 0; k1 < K1; ++k1) {
                 const int u = tid + NT * k1;
@@ -1357,6 +1385,7 @@ __global__ void __launch_bounds__(P::NT)
 #pragma unroll
                 for (int j = 0; j < R0; ++j) lds[u + N1 * j] = xx[k1][j];
             }
+            WF_ISTAMP(2)
             __syncthreads();
             double* o = out + item * ld;
 #pragma unroll
@@ -1374,7 +1403,9 @@ __global__ void __launch_bounds__(P::NT)
                         const int jm = u == 0 ? (R0 - j) % R0 : R0 - 1 - j;
                         const cd qm = lds[mu + N1 * jm];
                         // W_2M^n = W_2M^u * W_{2 R0}^j = cos - i sin (the second factor lane-uniform)
-                        const cd w = j == 0 ? h : cmul(h, tw_uniform(tw2, j * N1));
+                        // (the lane-uniform factor as a literal, wfft_twist.inc: a scalar load here shares its
+                        // counter with the LDS loads of Qm and made every step wait for all of them)
+                        const cd w = j == 0 ? h : cmul(h, cd{WfTwist<R0>::re(j), WfTwist<R0>::im(j)});
                         const double ar = 0.5 * (x[j].x + qm.x), br = 0.5 * (x[j].y + qm.y),
                                      bi = -0.5 * (x[j].x - qm.x);
                         const double lagv = ar + (w.x * br - w.y * bi);
@@ -1416,9 +1447,15 @@ __global__ void __launch_bounds__(P::NT)
                     }
                 }
             }
+            WF_ISTAMP(3)
             __syncthreads();  // Q consumed before the next transform's sub-series overwrite the LDS
         }
     }
+#if WF_INV_STAMP
+    if (tid == 0)
+        for (int i = 0; i < 5; ++i) atomicAdd(&wf_inv_stamps[i], ist[i]);
+#endif
+#undef WF_ISTAMP
 }
 
 // ================================================================================================
