@@ -70,6 +70,56 @@ def host_cases(n_cases, seed):
     return 0
 
 
+def group_cases(n_cases, seed):
+    """Several device members behind one call (ta_group; all on GPU 0): random member counts,
+    shapes (more members than atoms included), kinds, staging dtypes and by-particle columns."""
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for case in range(n_cases):
+        n_dev = int(rng.integers(1, 6))
+        T = int(rng.integers(1, 3000)) if rng.random() < 0.8 else int(rng.integers(9000, 12000))
+        A = int(rng.integers(1, 40 if T < 3000 else 8))
+        D = int(rng.integers(1, 4))
+        dtype = np.float32 if rng.random() < 0.5 else np.float64
+        kind = rng.choice(["fft", "direct", "helfand"]) if T < 3000 else "fft"
+        v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=int(rng.integers(1 << 30)))
+        v, x = v.astype(dtype), x.astype(dtype)
+        g = _lib.Group([0] * n_dev)
+        slabs = g.stage_alloc(T, A, D, n_slabs=2 if kind == "helfand" else 1, dtype=dtype)
+        cut = int(rng.integers(0, T + 1))
+        for lo_t, hi_t in ((0, cut), (cut, T)):
+            for view_v, (lo, hi) in zip(slabs[0], g.shards):
+                if hi > lo:
+                    view_v[lo_t:hi_t] = v[lo_t:hi_t, lo:hi]
+            if kind == "helfand":
+                for view_x, (lo, hi) in zip(slabs[1], g.shards):
+                    if hi > lo:
+                        view_x[lo_t:hi_t] = x[lo_t:hi_t, lo:hi]
+            g.stage_commit(lo_t, hi_t)
+        v64, x64 = v.astype(np.float64), x.astype(np.float64)
+        by_particle = bool(rng.random() < 0.6)
+        if kind == "helfand":
+            scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+            ts, bp = g.helfand_msd(m, scale, by_particle=by_particle)
+            want_bp, want_ts = orc.helfand(v64, x64, m, vol, 300.0)
+        else:
+            ts, bp = (g.vacf_fft if kind == "fft" else g.vacf_direct)(by_particle=by_particle)
+            want_bp, want_ts = orc.vacf_fft_batched(v64)
+        active = sum(1 for lo, hi in g.shards if hi > lo)
+        assert g.reduce_kind == ("none" if active <= 1 else "peer-copy"), (g.reduce_kind, g.shards)
+        sc = max(float(np.max(np.abs(want_bp))), 1e-300)
+        e = float(np.max(np.abs(ts - want_ts))) / sc
+        if by_particle:
+            e = max(e, float(np.max(np.abs(bp - want_bp))) / sc)
+        worst = max(worst, e / 1e-10)
+        if e > 1e-10:
+            print("FAIL group", case, kind, n_dev, T, A, D, dtype, by_particle, e, flush=True)
+            return 1
+        g.close()
+    print("group stress ok:", n_cases, "cases, worst err/tol %.3g" % worst)
+    return 0
+
+
 def main(n_cases, seed=1234):
     rng = np.random.default_rng(seed)
     ctx = _lib.Context(0)
@@ -143,4 +193,4 @@ def main(n_cases, seed=1234):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 1234
-    sys.exit(main(n, sd) or host_cases(max(1, n // 5), sd + 1))
+    sys.exit(main(n, sd) or host_cases(max(1, n // 5), sd + 1) or group_cases(max(1, n // 5), sd + 2))
