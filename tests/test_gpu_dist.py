@@ -251,3 +251,36 @@ def test_group_c_abi_one_gpu(tmp_path):
         assert scale_rel_err(z["bp" + k], z["bp_ref"]) < TOL
         assert scale_rel_err(z["d" + k], z["ts_ref"]) < TOL
 
+
+@pytest.mark.parametrize("kind", ["fft", "direct", "helfand"])
+def test_group_blocked_by_particle_copies_into_column_ranges(kind):
+    """Members that process their atoms in blocks (bp_block: a block's device->host copy under the
+    next block's compute) write every block into the right columns of the caller's ONE array: the
+    host row stride is the full atom count, not the member's."""
+    from oracle import numpy_oracle as orc
+    from transport_analysis_amd import _lib
+
+    T, A, D = 200, 700, 3
+    v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=21)
+    g = _lib.Group([0, 0, 0])
+    g.set_option("bp_block", 64)  # members hold 233-234 atoms: four blocks each
+    slabs = g.stage_alloc(T, A, D, n_slabs=2 if kind == "helfand" else 1, dtype=np.float64)
+    for view, (lo, hi) in zip(slabs[0], g.shards):
+        view[...] = v[:, lo:hi]
+    if kind == "helfand":
+        for view, (lo, hi) in zip(slabs[1], g.shards):
+            view[...] = x[:, lo:hi]
+    g.stage_commit(0, T)
+    out = np.full((T, A), np.nan)
+    if kind == "helfand":
+        scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+        ts, bp = g.helfand_msd(m, scale, by_particle=True, out=out)
+        want_bp, want_ts = orc.helfand(v, x, m, vol, 300.0)
+    else:
+        ts, bp = (g.vacf_fft if kind == "fft" else g.vacf_direct)(by_particle=True, out=out)
+        want_bp, want_ts = orc.vacf_windowed(v)
+    assert bp is out and not np.isnan(out).any() and g.reduce_kind == "peer-copy"
+    assert scale_rel_err(ts, want_ts) < TOL
+    assert scale_rel_err(out, want_bp) < TOL
+    g.close()
+
