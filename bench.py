@@ -99,11 +99,23 @@ POWER_CAP_W = 1400.0
 BEST_PLAN_NJ_PER_BYTE = 0.453
 
 
+# measured unit costs (tools/ubench/energy_bench, profiles/r04_energy_ubench.txt): idle 243 W; an HBM byte
+# 150 pJ, an FP64 lane operation 33.5 pJ; the transform needs 6.06 FP64 operations per input byte
+IDLE_W, HBM_PJ_PER_BYTE, FP64_PJ_PER_OP, FP64_OPS_PER_BYTE = 243.0, 150.0, 33.5, 6.06
+
+
 def model_ceiling():
     gbps = POWER_CAP_W / BEST_PLAN_NJ_PER_BYTE
+    # zero-overhead bound: only the HBM read and the transform's FP64 operations (x 0.8: the lower
+    # operating point of the frugal plans), nothing else
+    floor_nj = (HBM_PJ_PER_BYTE + 0.8 * FP64_OPS_PER_BYTE * FP64_PJ_PER_OP) * 1e-3
+    bound = (POWER_CAP_W - IDLE_W) / floor_nj
     return {"frac": gbps / HBM_PEAK_GBPS, "GBps": gbps,
             "basis": "package power cap / lowest energy per input byte measured over the forward kernel's plans "
-                     "(profiles/r04_power_clock.txt); the kernel is power-bound, not issue- or bandwidth-bound"}
+                     "(profiles/r04_power_clock.txt); the kernel is power-bound, not issue- or bandwidth-bound",
+            "zero_overhead_bound": {"frac": bound / HBM_PEAK_GBPS, "GBps": bound,
+                                    "basis": "(cap - idle) / (HBM byte + FP64 operations of the transform), unit costs "
+                                             "from profiles/r04_energy_ubench.txt"}}
 
 
 def single_process(args):
