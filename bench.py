@@ -99,23 +99,24 @@ POWER_CAP_W = 1400.0
 BEST_PLAN_NJ_PER_BYTE = 0.453
 
 
-# measured unit costs (tools/ubench/energy_bench, profiles/r04_energy_ubench.txt): idle 243 W; an HBM byte
-# 150 pJ, an FP64 lane operation 33.5 pJ; the transform needs 6.06 FP64 operations per input byte
-IDLE_W, HBM_PJ_PER_BYTE, FP64_PJ_PER_OP, FP64_OPS_PER_BYTE = 243.0, 150.0, 33.5, 6.06
+# measured (profiles/r04_energy_ubench.txt, profiles/r04_f32_slabs.txt): idle 243 W; an FP64 lane operation
+# <= 33.5 pJ all-in; the HBM read ~40 pJ per input byte (float32-slab A/B: half the bytes, -4.6 % time);
+# the transform needs 6.06 FP64 operations per input byte
+IDLE_W, HBM_PJ_PER_BYTE, FP64_PJ_PER_OP, FP64_OPS_PER_BYTE = 243.0, 40.0, 33.5, 6.06
 
 
 def model_ceiling():
     gbps = POWER_CAP_W / BEST_PLAN_NJ_PER_BYTE
-    # zero-overhead bound: only the HBM read and the transform's FP64 operations (x 0.8: the lower
-    # operating point of the frugal plans), nothing else
+    # what the transform's FP64 operations (x 0.8: the lower operating point of the frugal plans) and
+    # the HBM read alone would allow: no LDS traffic, no other instruction, no waiting wave
     floor_nj = (HBM_PJ_PER_BYTE + 0.8 * FP64_OPS_PER_BYTE * FP64_PJ_PER_OP) * 1e-3
     bound = (POWER_CAP_W - IDLE_W) / floor_nj
     return {"frac": gbps / HBM_PEAK_GBPS, "GBps": gbps,
             "basis": "package power cap / lowest energy per input byte measured over the forward kernel's plans "
                      "(profiles/r04_power_clock.txt); the kernel is power-bound, not issue- or bandwidth-bound",
-            "zero_overhead_bound": {"frac": bound / HBM_PEAK_GBPS, "GBps": bound,
-                                    "basis": "(cap - idle) / (HBM byte + FP64 operations of the transform), unit costs "
-                                             "from profiles/r04_energy_ubench.txt"}}
+            "arithmetic_and_hbm_only": {"frac": bound / HBM_PEAK_GBPS, "GBps": bound,
+                                        "basis": "(cap - idle) / (HBM read + the transform's FP64 operations), nothing else: "
+                                                 "not a reachable state, the distance DESIGN.md section 6.0 item 4 describes"}}
 
 
 def single_process(args):
@@ -199,11 +200,12 @@ class Case:
     """One workload on one rank: slabs staged on the device, `step()` = one pass of the path."""
 
     def __init__(self, torch, ctx, dev, mode, T, A, D, col_offset, n_cols_total, seed, by_particle=False,
-                 float32=False, helfand_fft=False):
+                 float32=False, helfand_fft=False, slab32=False):
         self.torch, self.ctx, self.mode, self.T, self.A, self.D = torch, ctx, mode, T, A, D
         self.helfand_fft = helfand_fft
+        self.slab32 = slab32  # float32 device slabs under float64 arithmetic (the FFT kernels widen the rows)
         ctx.set_option("direct_f32", 1 if float32 else 0)
-        ctx.set_option("stage_device_f32", 1 if float32 else 0)  # float32 path: float32 device slabs
+        ctx.set_option("stage_device_f32", 1 if (float32 or slab32) else 0)  # float32 path: float32 device slabs
         ctx.set_option("helfand_fft", 1 if helfand_fft else 0)
         self.stream = torch.cuda.current_stream().cuda_stream
         ctx.stage_alloc_device(T, A, D, n_slabs=2 if mode == "helfand" else 1)
@@ -282,7 +284,7 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
     T, A, D = case.T, case.A, case.D
     from transport_analysis_amd import _lib
 
-    bytes_algo = T * A * D * 8 * (2 if case.mode == "helfand" else 1)
+    bytes_algo = T * A * D * (4 if getattr(case, "slab32", False) else 8) * (2 if case.mode == "helfand" else 1)
     if case.bp is not None:
         bytes_algo += T * A * 8  # the by-particle array written once
     gbps = bytes_algo / (kernel_ms * 1e-3) / 1e9
@@ -688,14 +690,21 @@ def other_configs(torch, dist, _lib, ctx, dev):
         ("configs[4] per-GPU share, helfand_fft option (float64): 20000 x 25000 x 3", "helfand", 20000, 25000, False, False, True, 3, 1),
         ("long trajectory: FFT VACF timeseries 20000 x 25000 x 3", "fft", 20000, 25000, False, False, False, 5, 1),
         ("long trajectory with vacf_by_particle: FFT VACF 20000 x 25000 x 3", "fft", 20000, 25000, True, False, False, 3, 1),
+        # MDAnalysis data is float32 at the source: the same tensor rounded once to float32, kept as
+        # float32 in the device slab (12 GB), float64 arithmetic; `frac` is priced with the 12 B per
+        # lag-point this input has
+        ("float32 device slab (MDAnalysis' dtype), float64 arithmetic: FFT VACF timeseries 10000 x 100000 x 3", "fft", 10000, 100000, False, False, False, 10, 3, True),
+        ("float32 device slab with vacf_by_particle: FFT VACF 10000 x 100000 x 3", "fft", 10000, 100000, True, False, False, 3, 1, True),
     ]
-    for name, mode, T, A, byp, f32, hfft, steps, warm in specs:
+    for spec in specs:
+        name, mode, T, A, byp, f32, hfft, steps, warm = spec[:9]
+        slab32 = len(spec) > 9 and spec[9]
         try:
             ctx.stage_free()
             ctx.trim()
             torch.cuda.empty_cache()
             seed = SEED + {"fft": 3, "direct": 4, "helfand": 5}[mode]
-            c = Case(torch, ctx, dev, mode, T, A, 3, 0, A * 3, seed, byp, f32, hfft)
+            c = Case(torch, ctx, dev, mode, T, A, 3, 0, A * 3, seed, byp, f32, hfft, slab32)
             el = timed(torch, dist, 1, steps, warm, c.step)
             hist = ctx.timing_history(steps)
             kms = statistics.median(m for _, m in hist)
@@ -705,7 +714,7 @@ def other_configs(torch, dist, _lib, ctx, dev):
             if composite:
                 r["kernel"] = "whole call"
             r["traffic"] = recorded_traffic(f"{mode}_{T}x{A}x3" + ("_bp" if byp else "") + ("_hfft" if hfft else "")
-                                            + ("_f32" if f32 else ""))
+                                            + ("_f32" if f32 else "") + ("_slab32" if slab32 else ""))
             r["kernels"] = kernel_split(ctx, c, torch)
             res.append({"workload": name, "ms_per_step": el / steps * 1e3, "steps": steps,
                         "value": T * A / (el / steps), "unit": "lag-points/s",

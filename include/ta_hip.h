@@ -272,9 +272,11 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *   "stage_device_f32" 0|1 : device slabs allocated AFTERWARDS hold float32 elements when the host
  *                      slabs are TA_F32 (or there are none: ta_stage_alloc_device): half the
  *                      device footprint (BASELINE configs[4]: 12 GB instead of 24 GB per GPU).
- *                      The float32 direct correlators ("direct_f32" 1) read them as they are;
- *                      every other evaluation first widens them into float64 scratch slabs
- *                      (same results as float64 slabs of the same values).  ta_stage_device
+ *                      The float32 direct correlators ("direct_f32" 1) read them as they are, and
+ *                      so do the FFT kernels for 513 ... 10240 frames (8-byte rows widened exactly
+ *                      in the first stage: 3-14 % faster than from float64 slabs, float64
+ *                      arithmetic, results equal to float64 slabs of the same values to rounding);
+ *                      every other evaluation first widens them into float64 scratch slabs.  ta_stage_device
  *                      then returns a pointer to float rows (8 bytes per pair row).
  *   "bp_spec_atoms" n : FFT path with a by-particle array: atoms per block of power spectra
  *                      (scratch = n * 16 * M bytes; 0 = as many as fit 2.5 GiB);

@@ -245,8 +245,14 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
 // sum -> ONE inverse transform.  By-particle array: per block of atoms, forward kernel -> the
 // atoms' power spectra in scratch -> inverse kernel -> atom-major lags; then the transposition
 // into the caller's (n_frames, ld_bp) array, which also adds up its 64 atoms per lag.
+// pm_f32: the slab holds float32 elements (fft_reads_f32 says for which lengths the kernels take it)
+bool fft_reads_f32(int64_t T) {
+    int R0 = 0, R = 1;
+    return wfft_choose((long)T, &R0, &R) && R == 1 && R0 > 1;
+}
+
 int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A, int D,
-             double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st) {
+             double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st, bool pm_f32 = false) {
     int rc;
     const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2;
     int R0 = 0, R = 1;
@@ -292,7 +298,7 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
         if ((rc = ensure(ctx, ctx->spec, sizeof(double) * (size_t)L))) return rc;
         tl_mark(ctx, "k_wsplit_accum", st);
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-        TA_HIP_TRY(ctx, launch_wfft_forward(R0, R, false, (int)nwg, st, pm, pitch, (int)T, n_pairs, D, tw,
+        TA_HIP_TRY(ctx, launch_wfft_forward(R0, R, false, pm_f32, (int)nwg, st, pm, pitch, (int)T, n_pairs, D, tw,
                                             (double*)ctx->partial.p));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
         // the summed spectrum -> lag sums: ONE inverse transform per launch
@@ -317,9 +323,11 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
             const int64_t ca = std::min(CA, A - a0);
             const int64_t groups = D & 1 ? (ca + 1) / 2 : ca;  // a tuple of workgroups per group of atoms
             tl_mark(ctx, "k_wsplit_accum", st);
-            TA_HIP_TRY(ctx, launch_wfft_forward(R0, R, true, (int)forward_grid(groups), st,
-                                                pm + (a0 * D / 2) * pitch * 2, pitch, (int)T, ca, D, tw,
-                                                (double*)ctx->bp_spec.p));
+            // (a block starts on a column-pair boundary; pairs of a float32 slab are 8-byte rows)
+            const double* pm_blk = pm_f32 ? (const double*)((const float*)pm + (a0 * D / 2) * pitch * 2)
+                                          : pm + (a0 * D / 2) * pitch * 2;
+            TA_HIP_TRY(ctx, launch_wfft_forward(R0, R, true, pm_f32, (int)forward_grid(groups), st, pm_blk, pitch,
+                                                (int)T, ca, D, tw, (double*)ctx->bp_spec.p));
             tl_mark(ctx, "k_winverse", st);
             TA_HIP_TRY(ctx, launch_wfft_inverse(R0, R, (int)std::min<int64_t>(cap, ca), st,
                                                 (const double*)ctx->bp_spec.p, (int)T, ca, tw,
@@ -400,7 +408,9 @@ int compute_pm(ta_ctx* ctx, int which, const void* pm_vel_any, const void* pm_po
     // evaluation works on a float64 copy (same layout) in the context's scratch slabs
     const bool direct_on_f32 = pm_f32 && ctx->opt_direct_f32 &&
                                (which == W_DIRECT || (which == W_HELFAND && !(ctx->opt_helfand_fft && T >= 2)));
-    if (pm_f32 && !direct_on_f32) {
+    // ... and by the FFT kernels of the plans without an outer radix (513 ... 10240 frames)
+    const bool fft_on_f32 = pm_f32 && which == W_FFT && fft_reads_f32(T);
+    if (pm_f32 && !direct_on_f32 && !fft_on_f32) {
         const size_t n_el = (size_t)((A * D + 1) / 2) * (size_t)pitch * 2;
         const void* src[2] = {pm_vel_any, pm_pos_any};
         for (int k = 0; k < 2; ++k) {
@@ -417,7 +427,7 @@ int compute_pm(ta_ctx* ctx, int which, const void* pm_vel_any, const void* pm_po
     // paths without a dominant kernel of their own re-record ev[1]/ev[2] inside
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-    if (which == W_FFT) rc = fft_impl(ctx, pm_vel, pitch, T, A, D, d_lagsum, d_bp, ld_bp, st);
+    if (which == W_FFT) rc = fft_impl(ctx, pm_vel, pitch, T, A, D, d_lagsum, d_bp, ld_bp, st, fft_on_f32);
     else if (which == W_DIRECT)
         rc = direct_impl(ctx, MODE_VACF, pm_vel_any, nullptr, nullptr, T, A, D, pitch, 1.0, d_lagsum, d_bp, ld_bp, st,
                          direct_on_f32);

@@ -73,7 +73,8 @@ int wfft_max_wg_per_cu(int R0);
 int wfft_threads(int R0);
 // forward kernel (R0 > 1), nwg a multiple of 16 R: lag-sum mode n_units column pairs ->
 // accg [nwg / 2R][L] partial spectra; by-particle mode n_units atoms -> accg [n_units][L]
-hipError_t launch_wfft_forward(int R0, int R, bool by_particle, int nwg, hipStream_t st, const double* pm,
+// src_f32: pm points at a float32 slab (8-byte rows); R = 1 only
+hipError_t launch_wfft_forward(int R0, int R, bool by_particle, bool src_f32, int nwg, hipStream_t st, const double* pm,
                                long pitch, int T, long n_units, int D, const cd* tw, double* accg);
 // the lag-sum forward kernel built with in-kernel clock stamps (plans R0 = 8, 10, 12, 16, 20 without an
 // outer radix): stamps[16 * workgroup + ...], see wfft.hpp (ta_clock_probe)

@@ -38,13 +38,15 @@ hipError_t set_lds(K kern, size_t bytes, DevFlag* done /* [kMaxDev], one array p
 }
 
 template <int R0>
-hipError_t launch_forward_r0(int R, bool byp, int nwg, hipStream_t st, const double* pm, long pitch, int T,
+hipError_t launch_forward_r0(int R, bool byp, bool src_f32, int nwg, hipStream_t st, const double* pm, long pitch, int T,
                              long n_units, int D, const cd* tw, double* accg) {
     using P = WPlan<R0>;
-    auto kern = byp ? (R > 1 ? k_wsplit_accum<P, true, true> : k_wsplit_accum<P, true, false>)
-                    : (R > 1 ? k_wsplit_accum<P, false, true> : k_wsplit_accum<P, false, false>);
-    static DevFlag done[4][kMaxDev];
-    hipError_t e = set_lds(kern, P::kLds, done[(byp ? 2 : 0) + (R > 1 ? 1 : 0)]);
+    if (src_f32 && R > 1) return hipErrorInvalidValue;  // float32 slabs: no outer radix (the caller widens)
+    auto kern = src_f32 ? (byp ? k_wsplit_accum<P, true, false, false, true> : k_wsplit_accum<P, false, false, false, true>)
+                : byp   ? (R > 1 ? k_wsplit_accum<P, true, true> : k_wsplit_accum<P, true, false>)
+                        : (R > 1 ? k_wsplit_accum<P, false, true> : k_wsplit_accum<P, false, false>);
+    static DevFlag done[6][kMaxDev];
+    hipError_t e = set_lds(kern, P::kLds, done[src_f32 ? 4 + (byp ? 1 : 0) : (byp ? 2 : 0) + (R > 1 ? 1 : 0)]);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, st, pm, pitch, T, n_units, tw, accg, D, R, nullptr);
     return hipGetLastError();
@@ -106,6 +108,8 @@ int max_wg_r0() {
     ask(k_wsplit_accum<P, false, true>);
     ask(k_wsplit_accum<P, true, false>);
     ask(k_wsplit_accum<P, true, true>);
+    ask(k_wsplit_accum<P, false, false, false, true>);
+    ask(k_wsplit_accum<P, true, false, false, true>);
     if (d >= 0) cached[d].store(best, std::memory_order_release);
     return best;
 }
@@ -247,27 +251,28 @@ hipError_t launch_w1_bp(int nwg, hipStream_t st, const double* pm, long pitch, i
     return hipGetLastError();
 }
 
+// (src_f32: the slab holds float32 elements, 8-byte rows; plans without an outer radix only)
 // Forward kernel (R0 > 1): nwg a multiple of 16 R.  Lag-sum mode (by_particle false): n_units
 // column pairs, accg [nwg / 2R][L] partial spectra; by-particle mode: n_units atoms of D columns,
 // accg [n_units][L].  L = 2 R R0 512 doubles per spectrum.
-hipError_t launch_wfft_forward(int R0, int R, bool by_particle, int nwg, hipStream_t st, const double* pm,
+hipError_t launch_wfft_forward(int R0, int R, bool by_particle, bool src_f32, int nwg, hipStream_t st, const double* pm,
                                long pitch, int T, long n_units, int D, const cd* tw, double* accg) {
     if (R < 1 || nwg < 16 * R || nwg % (16 * R)) return hipErrorInvalidValue;
     switch (R0) {
-        case 2: return launch_forward_r0<2>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 3: return launch_forward_r0<3>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 4: return launch_forward_r0<4>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 5: return launch_forward_r0<5>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 6: return launch_forward_r0<6>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 7: return launch_forward_r0<7>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 8: return launch_forward_r0<8>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 9: return launch_forward_r0<9>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 10: return launch_forward_r0<10>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 12: return launch_forward_r0<12>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 14: return launch_forward_r0<14>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 16: return launch_forward_r0<16>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 18: return launch_forward_r0<18>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
-        case 20: return launch_forward_r0<20>(R, by_particle, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 2: return launch_forward_r0<2>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 3: return launch_forward_r0<3>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 4: return launch_forward_r0<4>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 5: return launch_forward_r0<5>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 6: return launch_forward_r0<6>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 7: return launch_forward_r0<7>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 8: return launch_forward_r0<8>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 9: return launch_forward_r0<9>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 10: return launch_forward_r0<10>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 12: return launch_forward_r0<12>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 14: return launch_forward_r0<14>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 16: return launch_forward_r0<16>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 18: return launch_forward_r0<18>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
+        case 20: return launch_forward_r0<20>(R, by_particle, src_f32, nwg, st, pm, pitch, T, n_units, D, tw, accg);
     }
     return hipErrorInvalidValue;
 }

@@ -821,7 +821,20 @@ __device__ __forceinline__ cd wf_cfma(cd acc, cd a, cd b) {  // acc + a b
     return {acc.x + (a.x * b.x - a.y * b.y), acc.y + (a.x * b.y + a.y * b.x)};
 }
 
-template <class P, bool BYP = false, bool LONG = false, bool STAMP = false>
+template <bool S, class A, class B>
+__device__ __forceinline__ auto& wf_pick(A& a, B& b) {
+    if constexpr (S) return a;
+    else return b;
+}
+
+// SRC32: the pair-major slab holds float32 elements (8-byte rows (x[t], y[t]): "stage_device_f32",
+// what MDAnalysis data is at the source): half the HBM bytes -- a third of this kernel's energy is
+// the HBM read -- and half the registers for the next unit's rows, which
+// is what lets R0 = 18, 20 spread their row requests over S2 like the smaller plans.  The rows are
+// widened to float64 (exactly) when the first stage picks them up; everything after is the same
+// arithmetic on the same values.  (Without an outer radix; longer trajectories are widened into a
+// float64 scratch slab first.)
+template <class P, bool BYP = false, bool LONG = false, bool STAMP = false, bool SRC32 = false>
 __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
     k_wsplit_accum(const double* __restrict__ pm, long pitch, int T, long n_units,
                    const cd* __restrict__ tw2, double* __restrict__ accg, int D, int R_arg,
@@ -829,6 +842,7 @@ __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
     constexpr int R0 = P::R0, N1 = P::N1, NW = P::NW, NS1 = P::NS1, M = P::M;
+    static_assert(!(SRC32 && LONG), "float32 slabs: plans without an outer radix only");
     const int R = LONG ? R_arg : 1, npass = 2 * R, L = npass * M;
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63;
@@ -870,19 +884,37 @@ __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
         const bool live = item < n_units;
         *kind = 2;
         if constexpr (BYP) wf_unit_of(live ? item : 0, k, D, &pair, kind);
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + (live ? pair : 0) * pitch * 2), 0,
-                                                 live ? T * 16 : 0, 0x00020000);
+        if constexpr (SRC32)
+            return __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(reinterpret_cast<const float*>(pm) + (live ? pair : 0) * pitch * 2), 0,
+                live ? T * 8 : 0, 0x00020000);
+        else
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + (live ? pair : 0) * pitch * 2), 0,
+                                                     live ? T * 16 : 0, 0x00020000);
     };
-    // row u + 512 j + M jo of the unit (a single real column: that half of the row, imaginary part 0)
-    auto load_row = [&](__amdgpu_buffer_rsrc_t rs, int kd, int u, unsigned row_off) {
-        if (!BYP || kd == 2) return wf_load(rs, (unsigned)u * 16u, row_off * 16u);
-        return cd{__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                                 rs, (unsigned)u * 16u + (unsigned)kd * 8u, row_off * 16u, 0)),
-                  0.0};
+    // row u + 512 j + M jo of the unit (a single real column: that half of the row, imaginary part 0);
+    // SRC32: the raw 8 bytes (one column: its 4 bytes in .x), widened by wf_widen when S1 starts
+    using RowT = std::conditional_t<SRC32, wf_u32x2, cd>;
+    auto load_row = [&](__amdgpu_buffer_rsrc_t rs, int kd, int u, unsigned row_off) -> RowT {
+        if constexpr (SRC32) {
+            // the whole 8-byte row also for a single column (wf_widen picks its half): 4-byte requests
+            // fetch the same lines at half the rate
+            return __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)u * 8u, row_off * 8u, 0);
+        } else {
+            if (!BYP || kd == 2) return wf_load(rs, (unsigned)u * 16u, row_off * 16u);
+            return cd{__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                                     rs, (unsigned)u * 16u + (unsigned)kd * 8u, row_off * 16u, 0)),
+                      0.0};
+        }
+    };
+    [[maybe_unused]] auto wf_widen = [&](wf_u32x2 r, int kd) {
+        if (!BYP || kd == 2)
+            return cd{(double)__builtin_bit_cast(float, (unsigned)r[0]), (double)__builtin_bit_cast(float, (unsigned)r[1])};
+        return cd{(double)__builtin_bit_cast(float, (unsigned)(kd ? r[1] : r[0])), 0.0};
     };
     // thread tid runs the first-stage butterflies u = tid + NT k, k < K1 (u < 512)
     constexpr int K1 = P::K1, NT = P::NT;
-    cd xx[K1][R0];
+    RowT xx[K1][R0];
     auto issue_loads = [&](__amdgpu_buffer_rsrc_t rs, int kd) {
 #pragma unroll
         for (int k1 = 0; k1 < K1; ++k1) {
@@ -903,7 +935,11 @@ __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
     // Rows with linear index i = k1 R0 + j.  Plans with kSpreadRows request them along S2, a quarter
     // at each hook point of the wave's first call; the others in one burst behind S2.
     constexpr int NR = K1 * R0;
-    constexpr int NSPREAD = WF_LOAD_PARTS != 4 ? 0 : (P::kSpreadRows ? NR : 0);
+    constexpr bool kSpread = P::kSpreadRows || (SRC32 && R0 >= 18);  // float32 rows: 2 registers each
+#ifndef WF_SPREAD32_TAIL
+#define WF_SPREAD32_TAIL 8  // float32 rows, R0 = 18, 20: this many of the rows stay behind S2 (all of them along S2 spills)
+#endif
+    constexpr int NSPREAD = WF_LOAD_PARTS != 4 ? 0 : (kSpread ? (SRC32 && R0 >= 18 ? NR - WF_SPREAD32_TAIL : NR) : 0);
     auto issue_row = [&](auto ii, __amdgpu_buffer_rsrc_t rs, int kd) {
         constexpr int i = decltype(ii)::value, k1 = i / R0, j = i % R0;
         const int u = tid + NT * k1;
@@ -953,7 +989,12 @@ __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
         for (int k1 = 0; k1 < K1; ++k1) {
         const int u = tid + NT * k1;
         if (K1 * NT != N1 && u >= N1) continue;
-        cd(&x)[R0] = xx[k1];
+        [[maybe_unused]] cd xwide[SRC32 ? R0 : 1];
+        if constexpr (SRC32) {
+#pragma unroll
+            for (int j = 0; j < R0; ++j) xwide[j] = wf_widen(xx[k1][j], kind);
+        }
+        cd(&x)[R0] = wf_pick<SRC32>(xwide, xx[k1]);
         cd g, g2, h;
         auto load_seeds = [&]() {
             g = wf_load(twr, (unsigned)(u * R) * 32u, 0u);
@@ -1096,8 +1137,13 @@ __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
             // three at a time, the others two at a time (no row requests along S2 in these plans:
             // NSPREAD = 0.  Measured instead, R0 = 20, same box: every wave two at a time with 8 of
             // the 20 requests spread, the third alone afterwards -- correct, 2.12 against 2.11 ms.)
-            if (wave < P::REM) wf_sub512_x3<P::kRegExchange>(wsub, stw, acc[0], acc[1], acc[2]);
-            else wf_sub512_x2<0, P::kRegExchange>(wsub, stw, acc[0], acc[1]);
+            if constexpr (SRC32) {  // room for the next unit's (float32) rows: requested along S2
+                if (wave < P::REM) wf_sub512_x3<P::kRegExchange>(wsub, stw, acc[0], acc[1], acc[2], row_hook);
+                else wf_sub512_x2<0, P::kRegExchange>(wsub, stw, acc[0], acc[1], row_hook);
+            } else {
+                if (wave < P::REM) wf_sub512_x3<P::kRegExchange>(wsub, stw, acc[0], acc[1], acc[2]);
+                else wf_sub512_x2<0, P::kRegExchange>(wsub, stw, acc[0], acc[1]);
+            }
         } else {
             static_for_range<0, NS1>([&](auto ss) {
                 constexpr int s = decltype(ss)::value;

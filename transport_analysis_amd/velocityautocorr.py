@@ -45,6 +45,13 @@ class VelocityAutocorr(AnalysisBase):
         Element type of the pinned staging slab.  Default: the dtype MDAnalysis hands the
         velocities out in (float32) -- lossless, half the PCIe bytes of the reference's
         float64 slab; the device slab and all arithmetic are float64 either way.
+    device_float32 : bool or None, keyword-only, default None
+        Keep float32-staged frames as float32 in the DEVICE slab as well (half the device memory:
+        12 GB instead of 24 GB at 10000 frames x 100000 atoms; the FFT kernels read the 8-byte rows
+        and widen them exactly, 3-14 % faster than from float64 slabs; same values in, results
+        equal to float64 slabs within 1e-15 of the scale).  ``None``: on when the staging slab is
+        float32, ``fft=True`` and the trajectory has 513 ... 10240 frames (the plans that read
+        float32 rows; any other evaluation of float32 device slabs first widens them).
     devices : sequence of int, keyword-only
         Several GPUs from ONE process and ONE pass over the trajectory: the
         atoms are split into contiguous blocks, one per GPU; every frame's columns go straight
@@ -72,6 +79,7 @@ class VelocityAutocorr(AnalysisBase):
         self._want_by_particle = bool(kwargs.pop("by_particle", True))
         self._distributed = bool(kwargs.pop("distributed", False))
         self._stage_dtype = kwargs.pop("stage_dtype", None)
+        self._device_f32 = kwargs.pop("device_float32", None)
         devices = kwargs.pop("devices", None)
         self._devices = None if devices is None else [int(d) for d in devices]
         if self._devices is not None and self._distributed:
@@ -140,6 +148,10 @@ class VelocityAutocorr(AnalysisBase):
             self._source = self.atomgroup[self._lo:self._hi]
         self._n_local = self._hi - self._lo
         dtype = self._pick_stage_dtype()
+        dev32 = self._device_f32
+        if dev32 is None:  # float32 staging stays float32 on the device where the FFT kernels read it as it is
+            dev32 = dtype == np.float32 and bool(self.fft) and 512 < self.n_frames <= 10240
+        self._ctx.set_option("stage_device_f32", int(bool(dev32) and dtype == np.float32))
         if self._devices is not None:
             # one pinned slab per GPU, each holding that GPU's column block; filled in ONE frame loop
             (views,) = self._ctx.stage_alloc(self.n_frames, self.n_particles, self.dim_fac, n_slabs=1, dtype=dtype)
