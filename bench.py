@@ -100,9 +100,9 @@ BEST_PLAN_NJ_PER_BYTE = 0.453
 
 
 # measured (profiles/r04_energy_ubench.txt, profiles/r04_f32_slabs.txt): idle 243 W; an FP64 lane operation
-# <= 33.5 pJ all-in; the HBM read ~40 pJ per input byte (float32-slab A/B: half the bytes, -4.6 % time);
+# <= 33.5 pJ all-in; the HBM read not measurable (float32-slab A/B: half the bytes, same time);
 # the transform needs 6.06 FP64 operations per input byte
-IDLE_W, HBM_PJ_PER_BYTE, FP64_PJ_PER_OP, FP64_OPS_PER_BYTE = 243.0, 40.0, 33.5, 6.06
+IDLE_W, HBM_PJ_PER_BYTE, FP64_PJ_PER_OP, FP64_OPS_PER_BYTE = 243.0, 0.0, 33.5, 6.06
 
 
 def model_ceiling():
@@ -114,9 +114,9 @@ def model_ceiling():
     return {"frac": gbps / HBM_PEAK_GBPS, "GBps": gbps,
             "basis": "package power cap / lowest energy per input byte measured over the forward kernel's plans "
                      "(profiles/r04_power_clock.txt); the kernel is power-bound, not issue- or bandwidth-bound",
-            "arithmetic_and_hbm_only": {"frac": bound / HBM_PEAK_GBPS, "GBps": bound,
-                                        "basis": "(cap - idle) / (HBM read + the transform's FP64 operations), nothing else: "
-                                                 "not a reachable state, the distance DESIGN.md section 6.0 item 4 describes"}}
+            "arithmetic_only": {"frac": bound / HBM_PEAK_GBPS, "GBps": bound,
+                                "basis": "(cap - idle) / (the transform's FP64 operations at 0.8 x 33.5 pJ), nothing else: "
+                                         "not a reachable state, the distance DESIGN.md section 6.0 item 4 describes"}}
 
 
 def single_process(args):

@@ -937,7 +937,9 @@ __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
     constexpr int NR = K1 * R0;
     constexpr bool kSpread = P::kSpreadRows || (SRC32 && R0 >= 18);  // float32 rows: 2 registers each
 #ifndef WF_SPREAD32_TAIL
-#define WF_SPREAD32_TAIL 8  // float32 rows, R0 = 18, 20: this many of the rows stay behind S2 (all of them along S2 spills)
+#define WF_SPREAD32_TAIL 0  // float32 rows, R0 = 18, 20: this many of the rows stay behind S2.  Same-box A/B at
+                            // 10000 x 100000 x 3 (float64 slab 8.69 ms): 20 (none along S2) 8.78 ms, 8: 8.30, 4: 8.24, 0: 7.85 ms
+                            // (28 bytes of scratch and still the fastest)
 #endif
     constexpr int NSPREAD = WF_LOAD_PARTS != 4 ? 0 : (kSpread ? (SRC32 && R0 >= 18 ? NR - WF_SPREAD32_TAIL : NR) : 0);
     auto issue_row = [&](auto ii, __amdgpu_buffer_rsrc_t rs, int kd) {
