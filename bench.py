@@ -74,6 +74,9 @@ def parse():
                     help="also materialise vacf_by_particle (the reference's default output)")
     ap.add_argument("--float32", action="store_true",
                     help="direct / helfand modes: float32 products and block sums (configs[4])")
+    ap.add_argument("--slab32", action="store_true",
+                    help="--mode fft: float32 device slabs (the tensor rounded once to float32; MDAnalysis' dtype), "
+                         "float64 arithmetic")
     ap.add_argument("--helfand-fft", action="store_true",
                     help="--mode helfand: the O(T log T) option (lag sums as S1 - 2 S2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -530,8 +533,10 @@ def main():
     A = hi - lo
     seed = SEED + {"fft": 3, "direct": 4, "helfand": 5}[args.mode]
     ctx = _lib.Context(local_rank)
+    if args.slab32 and args.mode != "fft":
+        raise SystemExit("--slab32 applies to --mode fft")
     case = Case(torch, ctx, dev, args.mode, T, A, D, lo * D, a_total * D, seed, args.by_particle,
-                args.float32, args.helfand_fft)
+                args.float32, args.helfand_fft, args.slab32)
 
     result = {}
     red_events, red_host = [], []
@@ -579,6 +584,8 @@ def main():
         ctx.stage_read_dev(0, fm.data_ptr(), A * D, case.stream)
         torch.cuda.synchronize()
         blk = synth.synthetic_block(seed, min(T, 64), a_total * D, lo * D, lo * D + min(A * D, 96))
+        if args.slab32:  # the slab holds the tensor rounded once to float32
+            blk = blk.astype(np.float32).astype(np.float64)
         check["generator_bit_exact_vs_numpy"] = bool(
             np.array_equal(fm[: blk.shape[0], : blk.shape[1]].cpu().numpy(), blk))
         scale = float((fm * fm).sum().item()) / T
@@ -599,7 +606,7 @@ def main():
     if composite:
         roof["kernel"] = "whole call"
     key = (f"{args.mode}_{T}x{A}x{D}" + ("_bp" if args.by_particle else "") + ("_hfft" if args.helfand_fft else "")
-           + ("_f32" if args.float32 else ""))
+           + ("_f32" if args.float32 else "") + ("_slab32" if args.slab32 else ""))
     roof["traffic"] = recorded_traffic(key)
     if not args.no_kernel_split:
         try:
@@ -625,7 +632,8 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32 (f64 inputs and accumulators)" if args.float32 else "f64",
+        "dtype": "f32 (f64 inputs and accumulators)" if args.float32 else
+                 "f64 (float32 device slab, widened exactly)" if args.slab32 else "f64",
         "data": "synthetic",
         "config": {
             "workload": workload, "n_frames": T, "n_atoms_total": a_total, "n_atoms_this_rank": A, "dim": D,

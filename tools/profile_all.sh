@@ -27,4 +27,6 @@ run helf32 helfand_20000x25000x3_f32 k_direct 2 --steps 1 --warmup 1 --mode helf
 run hfft helfand_20000x25000x3_hfft k_helfand_product+k_wsplit_accum+k_sum_partials+k_winverse+k_helfand_combine 3 --steps 2 --warmup 1 --mode helfand --helfand-fft --frames 20000 --atoms 25000
 run long fft_20000x25000x3 k_wsplit_accum 4 --steps 3 --warmup 1 --frames 20000 --atoms 25000
 run longbp fft_20000x25000x3_bp k_wsplit_accum+k_winverse+k_bp_transpose+k_sum_partials 3 --steps 2 --warmup 1 --frames 20000 --atoms 25000 --by-particle
+run slab32 fft_10000x100000x3_slab32 k_wsplit_accum 13 --steps 10 --warmup 3 --slab32
+run slab32bp fft_10000x100000x3_bp_slab32 k_wsplit_accum+k_winverse+k_bp_transpose+k_sum_partials 3 --steps 2 --warmup 1 --slab32 --by-particle
 cat $TA_TRAFFIC_MERGE
