@@ -114,9 +114,16 @@ def model_ceiling():
     # the HBM read alone would allow: no LDS traffic, no other instruction, no waiting wave
     floor_nj = (HBM_PJ_PER_BYTE + 0.8 * FP64_OPS_PER_BYTE * FP64_PJ_PER_OP) * 1e-3
     bound = (POWER_CAP_W - IDLE_W) / floor_nj
+    # cycle floors at the clock the kernel holds (profiles/r04_occupancy_counters.txt): per
+    # unit and pass ~9000 cycles of vector issue per SIMD / of the LDS pipe, overlapped perfectly
+    issue_floor_gbps = 163840.0 / (9000.0 / 2.16e9) * 256 / 1e9 / 2  # 160 KB per pair, two passes, 256 CUs
     return {"frac": gbps / HBM_PEAK_GBPS, "GBps": gbps,
             "basis": "package power cap / lowest energy per input byte measured over the forward kernel's plans "
                      "(profiles/r04_power_clock.txt); the kernel is power-bound, not issue- or bandwidth-bound",
+            "issue_and_lds_floor_at_measured_clock": {"frac": issue_floor_gbps / HBM_PEAK_GBPS, "GBps": issue_floor_gbps,
+                                                      "basis": "vector issue (8.1-9.1k cycles per SIMD) and LDS pipe (8.8k cycles) "
+                                                               "per unit and pass, overlapped perfectly at 2.16 GHz: what a cycle "
+                                                               "model allows and the power limit does not (the clock falls)"},
             "arithmetic_only": {"frac": bound / HBM_PEAK_GBPS, "GBps": bound,
                                 "basis": "(cap - idle) / (the transform's FP64 operations at 0.8 x 33.5 pJ), nothing else: "
                                          "not a reachable state, the distance DESIGN.md section 6.0 item 4 describes"}}
