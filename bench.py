@@ -116,7 +116,7 @@ def model_ceiling():
     bound = (POWER_CAP_W - IDLE_W) / floor_nj
     # cycle floors at the clock the kernel holds (profiles/r04_occupancy_counters.txt): per
     # unit and pass ~9000 cycles of vector issue per SIMD / of the LDS pipe, overlapped perfectly
-    issue_floor_gbps = 163840.0 / (9000.0 / 2.16e9) * 256 / 1e9 / 2  # 160 KB per pair, two passes, 256 CUs
+    issue_floor_gbps = 160000.0 / (9000.0 / 2.16e9) * 256 / 1e9 / 2  # 10000 rows x 16 B per pair, two passes, 256 CUs
     return {"frac": gbps / HBM_PEAK_GBPS, "GBps": gbps,
             "basis": "package power cap / lowest energy per input byte measured over the forward kernel's plans "
                      "(profiles/r04_power_clock.txt); the kernel is power-bound, not issue- or bandwidth-bound",
