@@ -895,9 +895,10 @@ int ta_clock_probe(ta_ctx* ctx, int n_launches, double* mhz, double* cycles_per_
         hipFree(st.p);
         return rc_;
     }
-    hipEvent_t e0 = ctx->ring[0][0], e1 = ctx->ring[0][3];  // borrowed: the probe is not a compute call
-    ctx->timing_valid = false;
-    hipError_t e = hipEventRecord(e0, ctx->stream);
+    hipEvent_t e0 = nullptr, e1 = nullptr;  // its own events: the probe is not a compute call and leaves the timing ring alone
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
     for (int i = 0; i < n_launches && e == hipSuccess; ++i)
         e = launch_wfft_forward_stamp(R0, (int)nwg, ctx->stream, ctx->d_slabs[0], ctx->st_pitch, (int)T, n_pairs, tw,
                                       (double*)ctx->partial.p, (unsigned long long*)st.p);
@@ -907,6 +908,8 @@ int ta_clock_probe(ta_ctx* ctx, int n_launches, double* mhz, double* cycles_per_
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     hipFree(st.p);
     if (e != hipSuccess) return fail(ctx, TA_E_HIP, std::string("clock probe: ") + hipGetErrorString(e));
     // the last launch's stamps, wave 0 of every workgroup: [0] S1, [1] S2 cycles, [2] the kernel's span
