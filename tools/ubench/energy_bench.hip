@@ -4,6 +4,8 @@
 //   fma   : independent v_fma_f64 (8 accumulators x 8 multiplier pairs per lane), 2 waves per SIMD
 //   lds   : each wave exchanges 8 KiB with itself: 8 ds_write_b128 + 8 ds_read_b128 per round (the
 //           forward kernel's exchange), 2 waves per SIMD
+//   mfma  : v_mfma_f64_16x16x4_f64 back to back, 8 independent accumulators, 2 waves per SIMD
+//           (mfma4: 4 accumulators, 1 wave per SIMD) — the matrix pipe's FP64 rate and its power
 //   copy  : 16 bytes per lane streamed from one 12 GB buffer to another (HBM read + write)
 // Prints per kernel: ms per launch, the in-kernel clock (delta s_memtime / delta s_memrealtime), and
 // operations per second; power is in the script's rocm-smi samples.
@@ -37,6 +39,36 @@ __global__ void __launch_bounds__(512) k_fma(const double* __restrict__ in, doub
     double s = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += a[i];
+    out[g] = s;
+    if (tid == 0) clk[2 * blockIdx.x] = t1 - t0, clk[2 * blockIdx.x + 1] = r1 - r0;
+}
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+// v_mfma_f64_16x16x4_f64 back to back: NACC independent 16x16 accumulators per wave, operands from
+// registers (random values scaled so the accumulators stay bounded).  2048 flop per instruction.
+template <int NACC>
+__global__ void __launch_bounds__(512) k_mfma(const double* __restrict__ in, double* __restrict__ out, int n,
+                                              unsigned long long* clk) {
+    const int tid = threadIdx.x;
+    const size_t g = (size_t)blockIdx.x * 512 + tid;
+    double a[4], b[4];
+    d4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = in[g * 24 + i] * 0.01, b[i] = in[g * 24 + 4 + i] * 0.01;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = d4{0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < n; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(i + k) & 3], b[k], acc[i], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
     out[g] = s;
     if (tid == 0) clk[2 * blockIdx.x] = t1 - t0, clk[2 * blockIdx.x + 1] = r1 - r0;
 }
@@ -115,6 +147,8 @@ int main(int argc, char** argv) {
         return 0;
     }
     const bool lds = !strcmp(what, "lds");
+    const bool mfma = !strcmp(what, "mfma"), mfma4 = !strcmp(what, "mfma4");  // 8 / 4 accumulators; 8 or 4 waves per CU
+    const int wgthreads = mfma4 ? 256 : 512;
     double *in, *out;
     unsigned long long* clk;
     const size_t nthr = (size_t)nwg * 512;
@@ -123,7 +157,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&clk, (size_t)nwg * 16));
     hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, 0, in, nthr * 24);
     CK(hipDeviceSynchronize());
-    const int n = lds ? 20000 : 40000;
+    const int n = lds ? 20000 : (mfma || mfma4) ? 4000 : 40000;
     if (lds) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     float total = 0, ms = 0;
     int launches = 0;
@@ -131,6 +165,8 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e0, 0));
         for (int i = 0; i < 4; ++i) {
             if (lds) hipLaunchKernelGGL(k_lds, dim3(nwg), dim3(512), 65536, 0, in, out, n, clk);
+            else if (mfma) hipLaunchKernelGGL(k_mfma<8>, dim3(nwg), dim3(512), 0, 0, in, out, n, clk);
+            else if (mfma4) hipLaunchKernelGGL(k_mfma<4>, dim3(nwg), dim3(wgthreads), 0, 0, in, out, n, clk);
             else hipLaunchKernelGGL(k_fma, dim3(nwg), dim3(512), 0, 0, in, out, n, clk);
         }
         CK(hipEventRecord(e1, 0));
@@ -143,7 +179,12 @@ int main(int argc, char** argv) {
     double c = 0, r = 0;
     for (int w = 0; w < nwg; ++w) c += (double)h[2 * w], r += (double)h[2 * w + 1];
     const double per = total / launches * 1e-3;
-    if (lds)
+    if (mfma || mfma4) {
+        const double nw = (double)nwg * wgthreads / 64, ninst = nw * n * 4 * (mfma ? 8 : 4);
+        printf("%s: %.3f ms per launch, in-kernel clock %.0f MHz, %.3e v_mfma_f64_16x16x4 per second = %.1f TFLOP/s (%.1f cycles per instruction and SIMD)\n",
+               what, per * 1e3, c / r * 100.0, ninst / per, ninst * 2048 / per / 1e12,
+               per * (c / r * 1e8) / (ninst / (nwg * 4.0)));
+    } else if (lds)
         printf("lds: %.3f ms per launch, in-kernel clock %.0f MHz, %.3e bytes stored + as many loaded per second (%.1f TB/s each way)\n",
                per * 1e3, c / r * 100.0, (double)nthr * n * 8 * 16 / per, (double)nthr * n * 8 * 16 / per / 1e12);
     else

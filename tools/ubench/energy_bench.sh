@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; B=$R/tools/ubench/energy_bench
 smi() { rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | sed 's/^GPU\[0\]\s*: //; s/=\{10,\}//g' | tr '\n' ';'; echo; }
 echo "# energy_bench.sh $(date -u +%FT%TZ)"
 echo "## idle"; sleep 1; smi
-for what in fma lds copy; do
+for what in ${EB_KERNELS:-fma lds copy mfma mfma4}; do
   echo "## $what"
   $B $what 4 > /tmp/eb_$what.log 2>&1 &
   PID=$!

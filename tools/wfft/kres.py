@@ -17,7 +17,7 @@ for l in sys.stdin:
         if m and cur is not None:
             cur[key] = m.group(1)
 for r in rows:
-    if not re.search(r"k_w", r["n"]):
+    if not re.search(r"k_w|k_band", r["n"]):
         continue
     short = re.sub(r"_ZN2ta\d+", "", r["n"])
     short = re.sub(r"INS_5WPlanILi(\d+)EEE", r"<R0=\1>", short)[:48]

@@ -1,0 +1,280 @@
+// band_kernels.hpp — windowed VACF lag SUMS on the FP64 matrix cores (gfx950 v_mfma_f64_16x16x4_f64).
+//
+// Quantity: VelocityAutocorr._conclude_simple summed over particles
+// (/root/reference/transport_analysis/velocityautocorr.py:217-238):
+//   S[k] = sum_{columns c} sum_{i < T-k} v[i, c] v[i+k, c],   lagsum[k] = S[k] / (T - k)
+// (the per-particle array of that method needs every particle's own sums: k_direct, direct_kernels.hpp).
+//
+// With G[t, s] = sum_c v[t, c] v[s, c] (the Gram matrix of the frames), S[k] is the sum of G's k-th
+// diagonal: GEMM-shaped work, 2 T^2/2 K flop.  G is never formed.  Time is cut into blocks of 16
+// frames; C_d = sum_I G[block I, block I+d] (a 16 x 16 matrix per block lag d) is what an MFMA
+// accumulator holds, accumulated over I AND over columns — the contraction runs over (I, c) — and
+// only at the very end the 31 diagonals of every C_d are summed into lags 16 d - 15 ... 16 d + 15.
+//
+// A wave owns 16 consecutive block lags d0 .. d0+15 (16 accumulators, 128 registers) and a range of
+// blocks [I0, I1) (a "piece" of the band).  Per step I it needs the fragment F_I (16 frames x 4 columns,
+// one float64 per lane) as the A operand and F_{I+d0} .. F_{I+d0+15} as B operands: the B window
+// slides by ONE fragment per step, so a step is 2 loads (16 bytes per lane: two columns of a
+// pair-major row, i.e. fragments of two k-sets) for 32 MFMAs, straight from the slab through L2
+// — no LDS, no barrier in the loop.  Columns go in octets (4 column pairs = one 16-byte load per
+// lane); the workgroups with the same blockIdx % n_labels (one XCD, as the hardware deals them)
+// sweep the same octets in the same order, their waves covering the whole band between them, so
+// an octet (T x 64 bytes) is read from HBM once and from that XCD's L2 by everybody else.
+//
+// Output: partial[label][piece][272] (lags 16 d0 - 15 ... 16 d0 + 255 of that piece), every element
+// written; k_band_gather adds them up in a fixed order: results do not depend on scheduling.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace ta {
+
+typedef double band_d2 __attribute__((ext_vector_type(2)));
+typedef double band_d4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBandPartial = 272;  // lags 16 d0 - 15 ... 16 d0 + 255, padded to a multiple of 16
+
+struct BandPiece {
+    int d0;     // first block lag of the 16 accumulators (a multiple of 16)
+    int i0, i1; // blocks [i0, i1) of the A operand
+    int phase;  // takes octets label + n_labels * (phase + n_ph * j)
+};
+
+// ---- host: cut the band into pieces of equal cost ------------------------------------------
+struct BandPlan {
+    int T = 0, nblk = 0, n_groups = 0, n_ph = 1, n_labels = 8, slots = 0, per_phase = 0;
+    std::vector<BandPiece> pieces;  // [phase][piece within the phase], sorted by group, then i0
+    std::vector<int> group_begin;   // [n_groups + 1] into one phase's pieces
+    std::vector<int> slot_begin;    // [slots + 1] into slot_pieces
+    std::vector<int> slot_pieces;   // piece indices of every wave slot
+    double max_cost = 0, mean_cost = 0;  // steps per octet sweep of the busiest / the average slot
+};
+
+// slots: wave slots per label (workgroups per label x 8).  Group g = block lags 16 g .. 16 g + 15 has
+// nblk - 16 g steps per octet; a visit (one piece on one octet) costs its steps plus kVisit for
+// filling the window.  A label keeps n_ph octets in flight (phases), so that a wave slot's share of
+// the band is long enough (>= 64 steps where the band allows it) to be cut into ~4 pieces: pieces
+// are dealt longest first onto the least loaded slot, which evens out what whole groups cannot.
+inline BandPlan band_plan(int T, int slots, int n_labels) {
+    constexpr double kVisit = 1.5;
+    BandPlan p;
+    p.T = T;
+    p.nblk = (T + 15) / 16;
+    p.n_groups = (p.nblk + 15) / 16;
+    p.n_labels = n_labels;
+    p.slots = slots;
+    auto steps = [&](int g) { return p.nblk - 16 * g; };
+    long total = 0;
+    for (int g = 0; g < p.n_groups; ++g) total += steps(g);
+    // octets in flight per label: their rows (T x 64 bytes each) should stay in one L2 (4 MiB)
+    int n_ph = 1;
+    while (2 * n_ph <= slots && n_ph < 64 && (double)total * n_ph / slots < 64.0 &&
+           (double)T * 64.0 * (2 * n_ph) <= 3.0 * 1048576.0)
+        n_ph *= 2;
+    while (slots % n_ph) n_ph /= 2;
+    p.n_ph = n_ph;
+    const int wslots = slots / n_ph;  // wave slots of one phase
+    // the band as one sequence of steps (group after group), cut into wslots equal shares; a share
+    // that crosses a group boundary is two (or more) pieces
+    std::vector<BandPiece> one;
+    std::vector<std::vector<int>> lists(wslots);
+    p.group_begin.assign(p.n_groups + 1, 0);
+    {
+        int g = 0, i = 0;  // next step to hand out
+        for (int w = 0; w < wslots; ++w) {
+            long need = (long)((double)total * (w + 1) / wslots + 0.5) - (long)((double)total * w / wslots + 0.5);
+            while (need > 0 && g < p.n_groups) {
+                const int take = (int)std::min<long>(need, steps(g) - i);
+                lists[w].push_back((int)one.size());
+                one.push_back({16 * g, i, i + take, 0});
+                need -= take, i += take;
+                if (i == steps(g)) {
+                    ++g, i = 0;
+                    if (g <= p.n_groups) p.group_begin[g] = (int)one.size();
+                }
+            }
+        }
+        for (; g < p.n_groups; ++g) p.group_begin[g + 1] = (int)one.size();
+    }
+    p.per_phase = (int)one.size();
+    for (int ph = 0; ph < n_ph; ++ph)
+        for (BandPiece q : one) {
+            q.phase = ph;
+            p.pieces.push_back(q);
+        }
+    // slot = workgroup * 8 + wave of a label: phase ph owns slots [ph wslots, (ph + 1) wslots)
+    p.slot_begin.assign(slots + 1, 0);
+    for (int s = 0; s < slots; ++s) {
+        p.slot_begin[s] = (int)p.slot_pieces.size();
+        const int ph = s / wslots, w = s % wslots;
+        double load = 0;
+        for (int idx : lists[w]) {
+            p.slot_pieces.push_back(ph * p.per_phase + idx);
+            load += one[idx].i1 - one[idx].i0 + kVisit;
+        }
+        p.max_cost = std::max(p.max_cost, load), p.mean_cost += load / slots;
+    }
+    p.slot_begin[slots] = (int)p.slot_pieces.size();
+    return p;
+}
+
+// ---- device ---------------------------------------------------------------------------------
+typedef unsigned band_u4 __attribute__((ext_vector_type(4)));
+
+// One octet of columns = 4 adjacent column pairs of the pair-major float64 slab behind ONE buffer
+// resource (pairs past the end of the slab fall outside it).  A lane reads row t of pair
+// kk = lane >> 4 at byte offset (kk pitch + t) * 16; frames past the end of the series get an offset
+// outside the resource instead, so the bounds check returns zeros.  (A slab's unpaired last
+// column is paired with zeros by everything that writes slabs: layout.hip.)
+//
+// The loads are inline assembly with hand-placed s_waitcnt: as compiler-visible loads they are
+// sunk next to their first use (they are only used several basic blocks later, behind the
+// early exits of the unrolled ring), and every step then waits out a full memory latency.  The
+// compiler does not know these loads are in flight: band_visit drains them (vmcnt(0)) before it
+// returns, and nothing else in the kernel's loop is a vector memory operation.
+struct BandSrc {
+    band_u4 rs;         // buffer resource of the octet
+    unsigned lane_off;  // (kk pitch + i) * 16
+    int T, i;           // frames; this lane's frame inside a block (lane & 15)
+    __device__ __forceinline__ void request(band_d2& dst, int b) const {
+        const int t = 16 * b + i;
+        const unsigned off = t < T ? lane_off + (unsigned)b * 256u : 0xfffffff0u;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(off), "s"(rs));
+    }
+};
+#define TA_BAND_WAIT(N, REG) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(REG))
+
+#define TA_BAND_MFMA(A, B, C) __builtin_amdgcn_mfma_f64_16x16x4f64((A), (B), (C), 0, 0, 0)
+
+// one piece on one octet: acc[d] += sum_{I in [i0, i1)} F_I^T F_{I + d0 + d}
+// In flight, oldest first, when step I starts: A_I, Wn_{I-3}, A_{I+1}, Wn_{I-2}, A_{I+2}, Wn_{I-1}, A_{I+3}
+// (A_x: the A operand of step x, requested three steps ahead into a ring of four; Wn_x: the window's new
+// fragment requested in step x, used last in step x + 1).
+__device__ __forceinline__ void band_visit(const BandSrc& src, int d0, int i0, int i1, band_d4 (&acc)[16]) {
+    band_d2 W[16], a[4];
+    src.request(a[0], i0);
+#pragma unroll
+    for (int d = 0; d < 16; ++d) src.request(W[d], i0 + d0 + d);
+    src.request(a[1], i0 + 1);
+    src.request(a[2], i0 + 2);
+    TA_BAND_WAIT(0, a[2]);
+#pragma unroll
+    for (int d = 0; d < 16; ++d) TA_BAND_WAIT(0, W[d]);
+    TA_BAND_WAIT(0, a[0]);
+    TA_BAND_WAIT(0, a[1]);
+    int I = i0;
+    for (;;) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            // window slot (j + d) & 15 holds F_{I + d0 + d}; the newest one (d = 15) is used last
+            src.request(a[(j + 3) & 3], I + 3);
+            TA_BAND_WAIT(6, a[j & 3]);
+            const band_d2 A = a[j & 3];
+#pragma unroll
+            for (int d = 0; d < 15; ++d) acc[d] = TA_BAND_MFMA(A.x, W[(j + d) & 15].x, acc[d]);
+            acc[0] = TA_BAND_MFMA(A.y, W[j].y, acc[0]);
+            src.request(W[j], I + d0 + 16);  // slot of d = 0 is free: next step's d = 15
+#pragma unroll
+            for (int d = 1; d < 15; ++d) acc[d] = TA_BAND_MFMA(A.y, W[(j + d) & 15].y, acc[d]);
+            __builtin_amdgcn_sched_barrier(0);  // or the wait moves up to the request above
+            TA_BAND_WAIT(2, W[(j + 15) & 15]);
+            acc[15] = TA_BAND_MFMA(A.x, W[(j + 15) & 15].x, acc[15]);
+            acc[15] = TA_BAND_MFMA(A.y, W[(j + 15) & 15].y, acc[15]);
+            if (++I == i1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                return;
+            }
+        }
+    }
+}
+
+// pm: pair-major float64 slab (layout.hip).  grid: n_labels * (slots / 8) workgroups of 512.
+__global__ void __launch_bounds__(512)
+    k_band_lags(const double* __restrict__ pm, long pitch, int T, long n_pairs, int n_labels, int n_ph,
+                const BandPiece* __restrict__ pieces, int n_pieces, const int* __restrict__ slot_begin,
+                const int* __restrict__ slot_pieces, double* __restrict__ partial) {
+    // per wave: one accumulator block as [m][n] with a row stride of 17, and the 16 x 31 diagonal sums
+    // (LDS operations of one wave complete in order: wave_barrier only pins the compiler's order)
+    __shared__ double red[8][272 + 16 * 32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int label = blockIdx.x % n_labels;
+    const int slot = (blockIdx.x / n_labels) * 8 + wave;
+    const long n_oct = (n_pairs + 3) / 4;
+    const int kk = lane >> 4;
+    double* blk = red[wave];
+    double* dsum = blk + 272;
+    const int pb = __builtin_amdgcn_readfirstlane(slot_begin[slot]), pe = __builtin_amdgcn_readfirstlane(slot_begin[slot + 1]);
+    for (int pi = pb; pi < pe; ++pi) {
+        const int idx = __builtin_amdgcn_readfirstlane(slot_pieces[pi]);
+        const BandPiece pc = pieces[idx];
+        const int d0 = __builtin_amdgcn_readfirstlane(pc.d0), i0 = __builtin_amdgcn_readfirstlane(pc.i0),
+                  i1 = __builtin_amdgcn_readfirstlane(pc.i1), phase = __builtin_amdgcn_readfirstlane(pc.phase);
+        band_d4 acc[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc[d] = band_d4{0.0, 0.0, 0.0, 0.0};
+        for (long o = label + (long)n_labels * phase; o < n_oct; o += (long)n_labels * n_ph) {
+            const long left = n_pairs - 4 * o;  // pairs of this octet that exist
+            BandSrc src;
+            const unsigned long long base = reinterpret_cast<unsigned long long>(pm + 4 * o * pitch * 2);
+            // raw buffer resource: base, stride 0, num_records in bytes, the gfx9 data format word
+            src.rs = band_u4{(unsigned)base, (unsigned)(base >> 32) & 0xffffu, (unsigned)((left < 4 ? left : 4) * pitch) * 16u,
+                             0x00020000u};
+            src.lane_off = (unsigned)(kk * pitch + (lane & 15)) * 16u;
+            src.T = T;
+            src.i = lane & 15;
+            band_visit(src, d0, i0, i1, acc);
+        }
+        // diagonals: acc[d] register r of lane l is C_d[m = 4 r + (l >> 4)][n = l & 15], lag 16 (d0 + d) + n - m
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) blk[(4 * r + (lane >> 4)) * 17 + (lane & 15)] = acc[d][r];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 31) {
+                const int e = lane - 15;
+                const int m_lo = e < 0 ? -e : 0, m_hi = e > 0 ? 16 - e : 16;
+                double s = 0.0;
+                for (int m = m_lo; m < m_hi; ++m) s += blk[m * 17 + m + e];
+                dsum[d * 32 + lane] = s;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        double* out = partial + ((long)label * n_pieces + idx) * kBandPartial;
+        for (int q = lane; q < kBandPartial; q += 64) {
+            // slot q is lag offset q - 15 = 16 d + e: (d, e >= 0) and (d + 1, e - 16)
+            const int off = q - 15;
+            const int d = off >= 0 ? off >> 4 : -1, e = off - 16 * d;  // e in [0, 15] (off < 0: 1..15)
+            double s = 0.0;
+            if (off <= 255) {
+                if (d >= 0) s = dsum[d * 32 + e + 15];
+                if (e >= 1 && d + 1 <= 15) s += dsum[(d + 1) * 32 + e - 16 + 15];
+            }
+            out[q] = s;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// lagsum[k] = (sum over labels and over the pieces that hold lag k) / (T - k), fixed order
+__global__ void __launch_bounds__(256)
+    k_band_gather(const double* __restrict__ partial, int n_labels, int n_pieces, int n_ph, int per_phase,
+                  const int* __restrict__ group_begin, int n_groups, int T, double* __restrict__ lagsum) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= T) return;
+    double s = 0.0;
+    for (int h = 0; h < 2; ++h) {
+        // group g holds lag offsets -15 ... 255 from 256 g
+        const int g = (k >> 8) + h;
+        const int off = k - 256 * g;
+        if (g >= n_groups || off < -15) continue;
+        for (int ph = 0; ph < n_ph; ++ph)
+            for (int li = group_begin[g]; li < group_begin[g + 1]; ++li)
+                for (int lab = 0; lab < n_labels; ++lab)
+                    s += partial[((long)lab * n_pieces + ph * per_phase + li) * kBandPartial + off + 15];
+    }
+    lagsum[k] = s / (double)(T - k);
+}
+
+}  // namespace ta
