@@ -56,6 +56,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # vector FP64
 FP32_PEAK_TFLOPS = 157.3
+FP64_MFMA_PEAK_TFLOPS = 78.6  # matrix FP64 (v_mfma_f64_16x16x4_f64: 32 flop / clock / SIMD, as the vector pipe)
 SEED = 20250824
 
 
@@ -213,6 +214,7 @@ class Case:
                  float32=False, helfand_fft=False, slab32=False):
         self.torch, self.ctx, self.mode, self.T, self.A, self.D = torch, ctx, mode, T, A, D
         self.helfand_fft = helfand_fft
+        self.float32 = float32
         self.slab32 = slab32  # float32 device slabs under float64 arithmetic (the FFT kernels widen the rows)
         ctx.set_option("direct_f32", 1 if float32 else 0)
         ctx.set_option("stage_device_f32", 1 if (float32 or slab32) else 0)  # float32 path: float32 device slabs
@@ -244,7 +246,13 @@ class Case:
             self.ctx.helfand_msd_staged(self.masses.data_ptr(), 1.0, self.lagsum.data_ptr(), d_bp, self.A,
                                         self.stream)
 
+    def on_matrix_cores(self):
+        """windowed VACF lag sums alone: the diagonal sums of the frames' Gram matrix (band_kernels.hpp)"""
+        return self.mode == "direct" and self.bp is None and not self.float32
+
     def kernel_name(self):
+        if self.on_matrix_cores():
+            return "k_band_lags"
         if self.mode != "fft" and not (self.mode == "helfand" and self.helfand_fft):
             return "k_direct"
         if self.T > 163840:
@@ -313,6 +321,12 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
     fl = (2.0 * D * A * T * (T + 1) / 2) if case.mode == "direct" else (3.0 * D * A * T * (T - 1) / 2)
     peak = FP32_PEAK_TFLOPS if float32 else FP64_PEAK_TFLOPS
     tf = fl / (kernel_ms * 1e-3) / 1e12
+    if case.on_matrix_cores():
+        # v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s dense at 2.4 GHz (77.3 measured back to back,
+        # profiles/r04_mfma_f64_ubench.txt); the flop counted are the useful ones (T(T+1)/2 lag products per column)
+        return {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "k_band_lags", "kernel_ms": kernel_ms,
+                "algorithmic_flops_per_launch": fl, "hbm_GBps_for_reference": gbps}
     return {"bound": "valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
             "traffic": None, "kernel": "k_direct", "kernel_ms": kernel_ms,
             "algorithmic_flops_per_launch": fl, "hbm_GBps_for_reference": gbps}
@@ -701,6 +715,7 @@ def other_configs(torch, dist, _lib, ctx, dev):
         ("configs[1]: FFT VACF timeseries 1000 x 10000 x 3", "fft", 1000, 10000, False, False, False, 10, 3),
         ("configs[2] shape with vacf_by_particle: FFT VACF 10000 x 100000 x 3", "fft", 10000, 100000, True, False, False, 3, 1),
         ("configs[3]: windowed (direct) VACF 5000 x 50000 x 3", "direct", 5000, 50000, False, False, False, 3, 1),
+        ("configs[3] shape with vacf_by_particle (vector kernel): windowed VACF 5000 x 50000 x 3", "direct", 5000, 50000, True, False, False, 2, 1),
         ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float32 path", "helfand", 20000, 25000, False, True, False, 2, 1),
         ("configs[4] per-GPU share, helfand_fft option (float64): 20000 x 25000 x 3", "helfand", 20000, 25000, False, False, True, 3, 1),
         ("long trajectory: FFT VACF timeseries 20000 x 25000 x 3", "fft", 20000, 25000, False, False, False, 5, 1),

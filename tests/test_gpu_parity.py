@@ -139,6 +139,36 @@ def test_vacf_direct_vs_oracle_shapes(ctx, T, A, D):
     assert scale_rel_err(ts2, want_ts) < TOL
 
 
+@pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 1, 1), (15, 3, 1), (16, 5, 3), (17, 2, 2), (240, 4, 3), (241, 3, 3),
+                                   (255, 7, 3), (256, 3, 3), (257, 9, 1), (271, 4, 3), (272, 4, 3), (273, 5, 2),
+                                   (511, 6, 3), (513, 11, 3), (1000, 37, 3), (2049, 8, 3), (4100, 3, 3),
+                                   (5000, 21, 3), (9000, 3, 1), (300, 2001, 1)])
+def test_vacf_direct_lag_sums_on_the_matrix_cores(ctx, T, A, D):
+    """Windowed VACF without the by-particle array = diagonal sums of the frames' Gram matrix:
+    k_band_lags (v_mfma_f64_16x16x4_f64, band_kernels.hpp) against the oracle and against the
+    vector kernel it replaces ("direct_mfma" 0); frame counts on both sides of the 16-frame blocks
+    and the 256-lag groups, odd column counts (the unpaired column's zero partner), few and many
+    columns."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(T, A, D, seed=2600 + T)
+    want_ts = orc.vacf_windowed(v)[1] if T <= 1000 else orc.vacf_fft_batched(v)[1]
+    ctx.set_option("timeline", 1)
+    try:
+        ts_m, _ = run_vacf(ctx, v, False, False)
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_lags"]
+        ts_again, _ = ctx.vacf_direct(by_particle=False)
+        assert np.array_equal(ts_m, ts_again)  # fixed summation order: the same bits every launch
+        ctx.set_option("direct_mfma", 0)
+        ts_v, _ = ctx.vacf_direct(by_particle=False)
+        assert "k_direct" in [n for n, _ in ctx.kernel_timeline()]
+    finally:
+        ctx.set_option("direct_mfma", 1)
+        ctx.set_option("timeline", 0)
+    assert scale_rel_err(ts_m, want_ts) < TOL
+    assert scale_rel_err(ts_m, ts_v) < 1e-12
+
+
 @pytest.mark.parametrize("T,A,D", [(100, 700, 3), (1000, 300, 2), (2561, 90, 3), (5121, 70, 3),
                                    (10000, 50, 1), (640, 203, 3)])
 def test_fft_many_units_per_workgroup(ctx, T, A, D):
@@ -1101,7 +1131,9 @@ def test_kernel_timeline_sums_to_the_call(ctx):
         # the marks sit inside the call's own start / end events
         assert 0.5 * total < sum(ms for _, ms in tl) <= 1.02 * total
         ts2, _ = ctx.vacf_direct(by_particle=False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["memset", "k_direct", "k_sum_partials"]
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_lags"]  # lag sums alone: matrix cores
+        ctx.vacf_direct(by_particle=True)
+        assert [n for n, _ in ctx.kernel_timeline()] == ["memset", "k_direct", "k_sum_partials", "k_bp_transpose"]
     finally:
         ctx.set_option("timeline", 0)
     want_bp, want_ts = orc.vacf_fft_batched(v)

@@ -74,6 +74,8 @@ struct ta_ctx {
     int64_t opt_direct_f32 = 0;
     int64_t opt_direct_groups = 0;
     int64_t opt_direct_chunk = 0;
+    int64_t opt_direct_mfma = 1;  // windowed VACF lag sums without the by-particle array: matrix-core kernel
+    BandCache* band = nullptr;
     int64_t opt_helfand_fft = 0;
     int64_t opt_bp_block = 0;
     int64_t opt_bp_spec_atoms = 0;
@@ -165,6 +167,17 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
                 const double* d_masses, int64_t T, int64_t A, int D, int64_t pitch, double scale,
                 double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st, bool src_f32 = false) {
     const bool f32 = ctx->opt_direct_f32 != 0;  // src_f32 only comes with it (compute_pm)
+    // Lag sums of the windowed VACF alone are the diagonal sums of the frames' Gram matrix:
+    // GEMM-shaped, so they run on the FP64 matrix cores (band_kernels.hpp).  The by-particle array,
+    // the Helfand differences (formed first, like the reference) and the float32 option stay on
+    // the vector kernels below.
+    if (mode == MODE_VACF && !d_bp && !f32 && !src_f32 && ctx->opt_direct_mfma) {
+        tl_mark(ctx, "k_band_lags", st);
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+        TA_HIP_TRY(ctx, launch_band_lags(&ctx->band, ctx->n_cu, (const double*)d_vel, pitch, (int)T, A * D, d_lagsum, st));
+        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+        return TA_OK;
+    }
     // Shape of the launch.  A thread owns one chunk pair (2L lags); a column group = W waves;
     // a workgroup = G groups working on G atoms at once, so that ONE workgroup fills a CU's
     // 16 wave slots (G*W <= 16) and its waves are dealt evenly to the 4 SIMDs.  The column
@@ -565,6 +578,7 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ta_stage_free(ctx);
     for (auto& kv : ctx->wf_tables) hipFree(kv.second);
+    band_cache_free(ctx->band);
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
                       &ctx->masses, &ctx->bounce, &ctx->stage_buf, &ctx->helf_p,
                       &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1], &ctx->bp_scratch, &ctx->bp_spec,
@@ -590,6 +604,8 @@ int ta_trim(ta_ctx* ctx) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
+    band_cache_free(ctx->band);
+    ctx->band = nullptr;
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_bp, &ctx->bounce, &ctx->bounce2, &ctx->stage_buf,
                       &ctx->helf_p, &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1],
                       &ctx->bp_scratch, &ctx->bp_spec})
@@ -608,6 +624,7 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "direct_f32")) ctx->opt_direct_f32 = value;
     else if (!strcmp(key, "direct_groups")) ctx->opt_direct_groups = value;
     else if (!strcmp(key, "direct_chunk")) ctx->opt_direct_chunk = value;
+    else if (!strcmp(key, "direct_mfma")) ctx->opt_direct_mfma = value;
     else if (!strcmp(key, "helfand_fft")) ctx->opt_helfand_fft = value;
     else if (!strcmp(key, "bp_block")) ctx->opt_bp_block = value;
     else if (!strcmp(key, "bp_spec_atoms")) ctx->opt_bp_spec_atoms = value;
