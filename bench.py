@@ -247,8 +247,9 @@ class Case:
                                         self.stream)
 
     def on_matrix_cores(self):
-        """windowed VACF lag sums alone: the diagonal sums of the frames' Gram matrix (band_kernels.hpp)"""
-        return self.mode == "direct" and self.bp is None and not self.float32
+        """lag sums alone of the O(T^2) correlators (float64): FP64 MFMA band kernel (band_kernels.hpp)"""
+        return (self.mode in ("direct", "helfand") and self.bp is None and not self.float32
+                and not (self.mode == "helfand" and self.helfand_fft))
 
     def kernel_name(self):
         if self.on_matrix_cores():
@@ -324,9 +325,15 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
     if case.on_matrix_cores():
         # v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s dense at 2.4 GHz (77.3 measured back to back,
         # profiles/r04_mfma_f64_ubench.txt); the flop counted are the useful ones (T(T+1)/2 lag products per column)
-        return {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "k_band_lags", "kernel_ms": kernel_ms,
-                "algorithmic_flops_per_launch": fl, "hbm_GBps_for_reference": gbps}
+        out = {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "k_band_lags", "kernel_ms": kernel_ms,
+               "algorithmic_flops_per_launch": fl, "hbm_GBps_for_reference": gbps}
+        if case.mode == "helfand":
+            # `achieved` counts the reference's arithmetic (difference, square, add = 3 flop per term) like the
+            # vector kernel's line; what the matrix pipe issues is 2 flop per term on 6 of its 8 column slots
+            issued = 2.0 * (8.0 / 6.0) * D * A * T * (T - 1) / 2 / (kernel_ms * 1e-3) / 1e12
+            out["matrix_pipe"] = {"issued_tflops": issued, "frac": issued / FP64_MFMA_PEAK_TFLOPS}
+        return out
     return {"bound": "valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
             "traffic": None, "kernel": "k_direct", "kernel_ms": kernel_ms,
             "algorithmic_flops_per_launch": fl, "hbm_GBps_for_reference": gbps}
@@ -716,6 +723,7 @@ def other_configs(torch, dist, _lib, ctx, dev):
         ("configs[2] shape with vacf_by_particle: FFT VACF 10000 x 100000 x 3", "fft", 10000, 100000, True, False, False, 3, 1),
         ("configs[3]: windowed (direct) VACF 5000 x 50000 x 3", "direct", 5000, 50000, False, False, False, 3, 1),
         ("configs[3] shape with vacf_by_particle (vector kernel): windowed VACF 5000 x 50000 x 3", "direct", 5000, 50000, True, False, False, 2, 1),
+        ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float64 (matrix cores)", "helfand", 20000, 25000, False, False, False, 2, 1),
         ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float32 path", "helfand", 20000, 25000, False, True, False, 2, 1),
         ("configs[4] per-GPU share, helfand_fft option (float64): 20000 x 25000 x 3", "helfand", 20000, 25000, False, False, True, 3, 1),
         ("long trajectory: FFT VACF timeseries 20000 x 25000 x 3", "fft", 20000, 25000, False, False, False, 5, 1),

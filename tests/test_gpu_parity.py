@@ -169,6 +169,59 @@ def test_vacf_direct_lag_sums_on_the_matrix_cores(ctx, T, A, D):
     assert scale_rel_err(ts_m, ts_v) < 1e-12
 
 
+@pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 2, 3), (15, 3, 1), (16, 5, 3), (17, 2, 2), (241, 3, 3), (256, 3, 3),
+                                   (257, 9, 1), (272, 4, 3), (273, 5, 2), (513, 11, 3), (1000, 37, 3), (2049, 8, 3),
+                                   (4100, 3, 3), (5000, 7, 3), (300, 2001, 1)])
+def test_helfand_lag_sums_on_the_matrix_cores(ctx, T, A, D):
+    """Einstein-Helfand mean squared differences without the by-particle array: k_band_lags<helfand>
+    on the product slab (rows centred on a nearby frame, norms carried in the fourth lane group)
+    against the oracle (viscosity.py:201-233: difference first) and against the vector kernel
+    ("direct_mfma" 0); positions with a large offset and a drift, so that P is far from zero-mean."""
+    from oracle import numpy_oracle as orc
+
+    v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=2700 + T)
+    x = x + 50.0 + 0.01 * np.arange(T)[:, None, None]
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+    want_ts = orc.helfand(v, x, m, vol, 300.0)[1]
+    ctx.set_option("timeline", 1)
+    try:
+        ts_m, _ = run_helfand(ctx, v, x, m, scale, False)
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_lags"]
+        ts_again, _ = ctx.helfand_msd(m, scale, by_particle=False)
+        assert np.array_equal(ts_m, ts_again)
+        ctx.set_option("direct_mfma", 0)
+        ts_v, _ = ctx.helfand_msd(m, scale, by_particle=False)
+        assert "k_direct" in [n for n, _ in ctx.kernel_timeline()]
+    finally:
+        ctx.set_option("direct_mfma", 1)
+        ctx.set_option("timeline", 0)
+    assert ts_m[0] == 0.0
+    assert scale_rel_err(ts_m, want_ts) < TOL
+    assert scale_rel_err(ts_m, ts_v) < 1e-11
+    if T > 4:  # lag by lag, not only against the largest value: the centring keeps short lags exact
+        rel = np.abs(ts_m[1:] - ts_v[1:]) / np.abs(ts_v[1:])
+        assert rel.max() < 1e-9, (rel.argmax() + 1, rel.max())
+
+
+def test_helfand_matrix_cores_on_a_pure_trend(ctx):
+    """The case the plain expansion S1 - 2 S2 loses (3.6e-9 on the reference's own
+    step trajectory): v = t, x = t^2 / 2, so P = m t^3 / 2 grows by nine orders of magnitude while
+    the lag-1 differences stay small.  Every lag against the vector kernel (difference first)."""
+    T = 3000
+    v, x = step(T)
+    m = np.array([1.0, 2.0])
+    v = np.repeat(v[:, :1], 2, axis=1) * np.array([1.0, 0.5])[None, :, None]
+    x = np.repeat(x[:, :1], 2, axis=1)
+    ts_m, _ = run_helfand(ctx, v, x, m, 1.0, False)
+    ctx.set_option("direct_mfma", 0)
+    try:
+        ts_v, _ = ctx.helfand_msd(m, 1.0, by_particle=False)
+    finally:
+        ctx.set_option("direct_mfma", 1)
+    rel = np.abs(ts_m[1:] - ts_v[1:]) / np.abs(ts_v[1:])
+    assert rel.max() < 1e-10, (rel.argmax() + 1, rel.max())
+
+
 @pytest.mark.parametrize("T,A,D", [(100, 700, 3), (1000, 300, 2), (2561, 90, 3), (5121, 70, 3),
                                    (10000, 50, 1), (640, 203, 3)])
 def test_fft_many_units_per_workgroup(ctx, T, A, D):

@@ -33,12 +33,17 @@ struct DevPlan {
     void free_all() { (void)hipFree(pieces), (void)hipFree(slot_begin), (void)hipFree(slot_pieces), (void)hipFree(group_begin), (void)hipFree(partial); }
 };
 
+static bool g_helf = false;  // "helfand" anywhere on the command line: squared differences of the slab's columns
 static void run(DevPlan& d, const double* pm, long pitch, int T, long n_cols, double* lagsum, int nwg) {
     const long n_pairs = (n_cols + 1) / 2;
-    hipLaunchKernelGGL(k_band_lags, dim3(nwg), dim3(512), 0, 0, pm, pitch, T, n_pairs, d.p.n_labels, d.p.n_ph,
-                       d.pieces, (int)d.p.pieces.size(), d.slot_begin, d.slot_pieces, d.partial);
+    if (g_helf)
+        hipLaunchKernelGGL(k_band_lags<true>, dim3(nwg), dim3(512), 0, 0, pm, pitch, T, n_pairs, d.p.n_labels, d.p.n_ph,
+                           d.pieces, (int)d.p.pieces.size(), d.slot_begin, d.slot_pieces, d.partial);
+    else
+        hipLaunchKernelGGL(k_band_lags<false>, dim3(nwg), dim3(512), 0, 0, pm, pitch, T, n_pairs, d.p.n_labels, d.p.n_ph,
+                           d.pieces, (int)d.p.pieces.size(), d.slot_begin, d.slot_pieces, d.partial);
     hipLaunchKernelGGL(k_band_gather, dim3((T + 255) / 256), dim3(256), 0, 0, d.partial, d.p.n_labels, (int)d.p.pieces.size(),
-                       d.p.n_ph, d.p.per_phase, d.group_begin, d.p.n_groups, T, lagsum);
+                       d.p.n_ph, d.p.per_phase, d.group_begin, d.p.n_groups, T, g_helf ? -2.0 : 1.0, g_helf ? 1 : 0, lagsum);
 }
 
 static double rnd(unsigned long long& s) {
@@ -50,7 +55,7 @@ static int check_one(int T, long n_cols, int nwg) {
     const long n_pairs = (n_cols + 1) / 2, pitch = (T + 7) / 8 * 8;
     std::vector<double> h((size_t)n_pairs * pitch * 2);
     unsigned long long s = 1234567 + T * 31 + n_cols;
-    for (auto& v : h) v = rnd(s);  // pad rows hold garbage on purpose; an unpaired last column is paired with zeros
+    for (auto& v : h) v = rnd(s) + (g_helf ? 1000.0 : 0.0);  // (Helfand: a large common offset the centring must remove) pad rows hold garbage on purpose; an unpaired last column is paired with zeros
     if (n_cols & 1)
         for (long t = 0; t < pitch; ++t) h[((n_pairs - 1) * pitch + t) * 2 + 1] = 0.0;
     std::vector<double> ref(T, 0.0);
@@ -58,7 +63,10 @@ static int check_one(int T, long n_cols, int nwg) {
         const double* col = h.data() + (c >> 1) * pitch * 2 + (c & 1);
         for (int k = 0; k < T; ++k) {
             double a = 0;
-            for (int i = 0; i + k < T; ++i) a += col[2 * i] * col[2 * (i + k)];
+            if (g_helf)
+                for (int i = 0; i + k < T; ++i) a += (col[2 * i] - col[2 * (i + k)]) * (col[2 * i] - col[2 * (i + k)]);
+            else
+                for (int i = 0; i + k < T; ++i) a += col[2 * i] * col[2 * (i + k)];
             ref[k] += a;
         }
     }
@@ -101,6 +109,8 @@ __global__ void k_fill(double* p, size_t n) {
 
 int main(int argc, char** argv) {
     const char* mode = argc > 1 ? argv[1] : "check";
+    for (int k = 1; k < argc; ++k)
+        if (!strcmp(argv[k], "helfand")) g_helf = true, argc = k;  // last argument
     if (!strcmp(mode, "check")) {
         int bad = 0;
         const int shapes[][3] = {{1, 3, 256},    {5, 7, 256},     {16, 8, 256},   {17, 9, 256},  {100, 30, 256}, {255, 64, 256},
@@ -149,7 +159,7 @@ int main(int argc, char** argv) {
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
-        const double flop = 2.0 * (double)T * (T + 1) / 2 * (double)n_cols;
+        const double flop = (g_helf ? 3.0 : 2.0) * (double)T * (T + 1) / 2 * (double)n_cols;
         printf("  %.3f ms  %.1f useful TFLOP/s\n", ms, flop / (ms * 1e-3) / 1e12);
     }
     std::vector<double> h(8);

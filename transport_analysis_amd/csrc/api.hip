@@ -167,16 +167,35 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
                 const double* d_masses, int64_t T, int64_t A, int D, int64_t pitch, double scale,
                 double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st, bool src_f32 = false) {
     const bool f32 = ctx->opt_direct_f32 != 0;  // src_f32 only comes with it (compute_pm)
-    // Lag sums of the windowed VACF alone are the diagonal sums of the frames' Gram matrix:
-    // GEMM-shaped, so they run on the FP64 matrix cores (band_kernels.hpp).  The by-particle array,
-    // the Helfand differences (formed first, like the reference) and the float32 option stay on
-    // the vector kernels below.
-    if (mode == MODE_VACF && !d_bp && !f32 && !src_f32 && ctx->opt_direct_mfma) {
+    // Lag sums alone are GEMM-shaped — the windowed VACF's are the diagonal sums of the frames' Gram
+    // matrix, the Helfand squared differences follow from products of rows centred on a nearby frame —
+    // and run on the FP64 matrix cores (band_kernels.hpp).  The by-particle arrays and the float32
+    // option stay on the vector kernels below.
+    const bool band_ok = !d_bp && !f32 && !src_f32 && ctx->opt_direct_mfma && T < ((int64_t)1 << 24);
+    if (band_ok && mode == MODE_VACF) {
         tl_mark(ctx, "k_band_lags", st);
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-        TA_HIP_TRY(ctx, launch_band_lags(&ctx->band, ctx->n_cu, (const double*)d_vel, pitch, (int)T, A * D, d_lagsum, st));
+        TA_HIP_TRY(ctx, launch_band_lags(&ctx->band, ctx->n_cu, false, (const double*)d_vel, pitch, (int)T, A * D, 1.0, d_lagsum, st));
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
         return TA_OK;
+    }
+    if (band_ok && mode == MODE_HELFAND) {
+        // the product slab P = (m v) x first (T*A*D*8 bytes more; without them: the vector kernel)
+        const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2;
+        const int n_parts = (int)std::min<int64_t>(1024, n_pairs);
+        if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)) == TA_OK &&
+            ensure(ctx, ctx->helf_small, sizeof(double) * (size_t)n_parts * T) == TA_OK) {
+            tl_mark(ctx, "k_helfand_product", st);
+            TA_HIP_TRY(ctx, launch_helfand_product((const double*)d_vel, (const double*)d_pos, d_masses, pitch, T, n_cols, D,
+                                                   (double*)ctx->helf_p.p, (double*)ctx->helf_small.p, n_parts, st));
+            tl_mark(ctx, "k_band_lags", st);
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+            TA_HIP_TRY(ctx, launch_band_lags(&ctx->band, ctx->n_cu, true, (const double*)ctx->helf_p.p, pitch, (int)T, n_cols,
+                                             scale / (double)D, d_lagsum, st));
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+            return TA_OK;
+        }
+        (void)hipGetLastError();  // out of memory for the product slab: not an error of the call
     }
     // Shape of the launch.  A thread owns one chunk pair (2L lags); a column group = W waves;
     // a workgroup = G groups working on G atoms at once, so that ONE workgroup fills a CU's

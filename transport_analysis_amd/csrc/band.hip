@@ -1,6 +1,7 @@
-// band.hip — launcher of the FP64 matrix-core evaluation of the windowed VACF lag sums
-// (band_kernels.hpp; quantity: /root/reference/transport_analysis/velocityautocorr.py:217-238 summed
-// over particles).  The cut of the band depends on n_frames and the grid only; its device copy and
+// band.hip — launcher of the FP64 matrix-core evaluation of the lag SUMS of the O(T^2) correlators
+// (band_kernels.hpp): windowed VACF (/root/reference/transport_analysis/velocityautocorr.py:217-238 summed
+// over particles) and, on the product slab P = (m v) x, the Einstein-Helfand mean squared differences
+// (viscosity.py:201-233 summed over particles).  The cut of the band depends on n_frames and the grid only; its device copy and
 // the partial-sum buffer are cached per context.
 #include "band_kernels.hpp"
 
@@ -36,8 +37,8 @@ static hipError_t band_upload(V** dst, const std::vector<V>& src) {
     return src.empty() ? hipSuccess : hipMemcpy(*dst, src.data(), sizeof(V) * src.size(), hipMemcpyHostToDevice);
 }
 
-hipError_t launch_band_lags(BandCache** cache, int n_cu, const double* pm, long pitch, int T, long n_cols, double* lagsum,
-                            hipStream_t st) {
+hipError_t launch_band_lags(BandCache** cache, int n_cu, bool helfand, const double* pm, long pitch, int T, long n_cols,
+                            double factor, double* lagsum, hipStream_t st) {
     constexpr int kLabels = 8;  // one per XCD, as the hardware deals workgroups round-robin to them
     const int nwg = std::max(kLabels, n_cu / kLabels * kLabels);
     if (!*cache) *cache = new BandCache;
@@ -60,10 +61,15 @@ hipError_t launch_band_lags(BandCache** cache, int n_cu, const double* pm, long 
     }
     const long n_pairs = (n_cols + 1) / 2;
     const int n_pieces = (int)c.plan.pieces.size();
-    hipLaunchKernelGGL(k_band_lags, dim3(nwg), dim3(512), 0, st, pm, pitch, T, n_pairs, kLabels, c.plan.n_ph, c.pieces, n_pieces,
-                       c.slot_begin, c.slot_pieces, c.partial);
+    if (helfand)  // accumulators hold -1/2 the squared differences
+        hipLaunchKernelGGL(k_band_lags<true>, dim3(nwg), dim3(512), 0, st, pm, pitch, T, n_pairs, kLabels, c.plan.n_ph, c.pieces,
+                           n_pieces, c.slot_begin, c.slot_pieces, c.partial);
+    else
+        hipLaunchKernelGGL(k_band_lags<false>, dim3(nwg), dim3(512), 0, st, pm, pitch, T, n_pairs, kLabels, c.plan.n_ph, c.pieces,
+                           n_pieces, c.slot_begin, c.slot_pieces, c.partial);
     hipLaunchKernelGGL(k_band_gather, dim3((T + 255) / 256), dim3(256), 0, st, c.partial, kLabels, n_pieces, c.plan.n_ph,
-                       c.plan.per_phase, c.group_begin, c.plan.n_groups, T, lagsum);
+                       c.plan.per_phase, c.group_begin, c.plan.n_groups, T, helfand ? -2.0 * factor : factor, helfand ? 1 : 0,
+                       lagsum);
     return hipGetLastError();
 }
 

@@ -138,9 +138,11 @@ struct BandSrc {
     band_u4 rs;         // buffer resource of the octet
     unsigned lane_off;  // (kk pitch + i) * 16
     int T, i;           // frames; this lane's frame inside a block (lane & 15)
+    bool slot;          // Helfand form: lane group 3 carries the norms instead of columns (reads zeros)
+    // (lane_off of the Helfand form's fourth lane group is outside the resource: it reads zeros)
     __device__ __forceinline__ void request(band_d2& dst, int b) const {
-        const int t = 16 * b + i;
-        const unsigned off = t < T ? lane_off + (unsigned)b * 256u : 0xfffffff0u;
+        unsigned off = lane_off + (unsigned)b * 256u;
+        if (16 * b + 16 > T) off = 16 * b + i < T ? off : 0xfffffff0u;  // wave-uniform: a block at the end of the series
         asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(off), "s"(rs));
     }
 };
@@ -190,7 +192,156 @@ __device__ __forceinline__ void band_visit(const BandSrc& src, int d0, int i0, i
     }
 }
 
+// ---- Einstein-Helfand form: sum over column c of (P[i,c] - P[j,c])^2 for every pair of frames --------
+// (viscosity.py:201-233 summed over particles; P = (m v) x, the product slab of helfand_fft.hip.)
+// (a - b)^2 = a^2 + b^2 - 2 a b with a = P[i] - r, b = P[j] - r for a reference row r close to
+// frame i: the reference is the first frame of the A block every kBandRef steps, so |a| is the
+// series' variation over < 16 kBandRef frames and |b| that over the lag — the three terms are
+// each of the size of the result for all but the shortest lags of a smooth series (a pure trend at lag
+// 1: 2 (16 kBandRef)^2 times larger, 1e-12 relative), which the plain expansion S1 - 2 S2 of the
+// helfand_fft option cannot promise.  Three of the four 16-lane groups carry column pairs; the fourth
+// carries, as its "columns", (valid_A[m], -nA[m]/2) in the A operand and (-nB[n]/2, valid_B[n]) in the
+// B operand (nA, nB: squared norms of the centred rows over the group's six columns): the same 32
+// MFMAs per step then accumulate  a.b - nB/2 - nA/2 = -(a - b)^2 / 2  for every pair of valid frames
+// and nothing for the others; the accumulators stay of the size of the result.
+#ifndef TA_BAND_REF
+#define TA_BAND_REF 16
+#endif
+#ifndef TA_BAND_ABL  // timing ablations (wrong results): 1 no re-centring, 2 no preparation at all
+#define TA_BAND_ABL 0
+#endif
+constexpr int kBandRef = TA_BAND_REF;
+
+typedef unsigned band_u2 __attribute__((ext_vector_type(2)));
+
+// s0 + s1 + s2 + s3 of the four 16-lane rows, lane by lane, in every row: two register-to-register
+// swaps (lane bit 5, lane bit 4) instead of trips through the LDS crossbar
+__device__ __forceinline__ double band_sum_halves(double s) {  // lane l: s[l] + s[l ^ 32]
+    const band_u2 w = __builtin_bit_cast(band_u2, s);
+    const band_u2 x0 = __builtin_amdgcn_permlane32_swap(w.x, w.x, false, false);
+    const band_u2 x1 = __builtin_amdgcn_permlane32_swap(w.y, w.y, false, false);
+    return __builtin_bit_cast(double, band_u2{x0.x, x1.x}) + __builtin_bit_cast(double, band_u2{x0.y, x1.y});
+}
+__device__ __forceinline__ double band_sum_row_pairs(double u) {  // lane l: u[l] + u[l ^ 16]
+    const band_u2 v = __builtin_bit_cast(band_u2, u);
+    const band_u2 y0 = __builtin_amdgcn_permlane16_swap(v.x, v.x, false, false);
+    const band_u2 y1 = __builtin_amdgcn_permlane16_swap(v.y, v.y, false, false);
+    return __builtin_bit_cast(double, band_u2{y0.x, y1.x}) + __builtin_bit_cast(double, band_u2{y0.y, y1.y});
+}
+__device__ __forceinline__ double band_sum_rows(double s) { return band_sum_row_pairs(band_sum_halves(s)); }
+
+struct BandHelf {
+    int T, i;
+    bool slot;
+    // Every VALU instruction of this kernel costs matrix-pipe time (measured: FP64 MFMAs and vector
+    // instructions do not overlap on gfx950, interleaved or not), so the common case — a block that lies
+    // inside the series — is kept to the fewest instructions; blocks that reach the end take the
+    // branch with the per-lane selects (wave-uniform).
+    // The reference row carries (-1, 0) in the fourth lane group, whose rows read as zeros: "row - r" puts
+    // (1, 0) there, which IS the A operand's (valid, -nA/2 = 0) of a step without invalid pairs.
+    __device__ __forceinline__ band_d2 first_row(band_d2 raw) const {
+        const int src_lane = (int)(threadIdx.x & 48);
+        band_d2 r = band_d2{__shfl(raw.x, src_lane), __shfl(raw.y, src_lane)};
+        if (slot) r = band_d2{-1.0, 0.0};
+        return r;
+    }
+    // B operand of block b from rows that are already centred except for `shift` (rows - r, or old + delta)
+    // `exact_one`: the fourth group holds exactly (1, 0), so its "norm" 1 is taken off the sum instead of masked
+    template <bool exact_one>
+    __device__ __forceinline__ band_d2 finish_b(band_d2 c, int b) const {
+        if (16 * b + 16 <= T) {
+            double n;
+            if constexpr (exact_one) n = __builtin_fma(-0.5, band_sum_rows(c.x * c.x + c.y * c.y), 0.5);
+            else n = -0.5 * band_sum_rows(slot ? 0.0 : c.x * c.x + c.y * c.y);
+            if (slot) c = band_d2{n, 1.0};
+        } else {
+            const bool valid = 16 * b + i < T;
+            if (!valid) c = band_d2{0.0, 0.0};
+            const double n = -0.5 * band_sum_rows(slot ? 0.0 : c.x * c.x + c.y * c.y);
+            if (slot) c = band_d2{n, valid ? 1.0 : 0.0};
+        }
+        return c;
+    }
+    __device__ __forceinline__ band_d2 prep_b(band_d2 raw, band_d2 r, int b) const { return finish_b<true>(raw - r, b); }
+    __device__ __forceinline__ band_d2 recentre_b(band_d2 old, band_d2 delta, int b) const { return finish_b<false>(old + delta, b); }
+    // A operand of a step whose window reaches the end of the series: (valid, -nA/2) through the product
+    __device__ __forceinline__ band_d2 prep_a_edge(band_d2 raw, band_d2 r, int b) const {
+        const bool valid = 16 * b + i < T;
+        band_d2 c = raw - r;
+        if (!valid) c = band_d2{0.0, 0.0};
+        const double n = -0.5 * band_sum_rows(slot ? 0.0 : c.x * c.x + c.y * c.y);
+        if (slot) c = band_d2{valid ? 1.0 : 0.0, n};
+        return c;
+    }
+    // ... and of every other step: all its pairs are valid, the rows' norms would add the same -nA[m]/2 to
+    // all 16 accumulators, so they are summed per lane in `na` (fourth group: a count, dropped in the
+    // epilogue) and subtracted once
+    __device__ __forceinline__ band_d2 prep_a_bulk(band_d2 raw, band_d2 r, double& na) const {
+        const band_d2 c = raw - r;
+        na += c.x * c.x + c.y * c.y;
+        return c;
+    }
+};
+
+// In flight when step I starts (A operand one step ahead, ring of two): A_I, Wn_{I-1}, A_{I+1}.
+// The reference row (frame 16 I of every column, every kBandRef steps) is lane i = 0 of the A fragment itself.
+__device__ __forceinline__ void band_visit_helfand(const BandSrc& src, int d0, int i0, int i1, band_d4 (&acc)[16], double& na) {
+    const BandHelf h{src.T, src.i, src.slot};
+    band_d2 W[16], a[2], r;
+    src.request(a[0], i0);
+#pragma unroll
+    for (int d = 0; d < 16; ++d) src.request(W[d], i0 + d0 + d);
+    TA_BAND_WAIT(0, a[0]);
+#pragma unroll
+    for (int d = 0; d < 16; ++d) TA_BAND_WAIT(0, W[d]);
+    r = h.first_row(a[0]);
+#pragma unroll
+    for (int d = 0; d < 15; ++d) {  // (the 16th is prepared by the first step, like every step's newest)
+        W[d] = h.prep_b(W[d], r, i0 + d0 + d);
+        if (d % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // three chains at a time: registers
+    }
+    int I = i0;
+    for (;;) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            src.request(a[(j + 1) & 1], I + 1);
+            TA_BAND_WAIT(2, a[j & 1]);
+            if (TA_BAND_ABL == 0 && j % kBandRef == 0 && I != i0) {  // new reference: the 15 older window fragments follow it
+                const band_d2 rn = h.first_row(a[j & 1]);
+                const band_d2 delta = r - rn;
+                r = rn;
+#pragma unroll
+                for (int d = 0; d < 15; ++d) {
+                    W[(j + d) & 15] = h.recentre_b(W[(j + d) & 15], delta, I + d0 + d);
+                    if (d % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            band_d2 A;
+            if (TA_BAND_ABL >= 2) A = a[j & 1];
+            else if (16 * (I + d0 + 16) <= src.T) A = h.prep_a_bulk(a[j & 1], r, na);
+            else A = h.prep_a_edge(a[j & 1], r, I);
+#pragma unroll
+            for (int d = 0; d < 15; ++d) acc[d] = TA_BAND_MFMA(A.x, W[(j + d) & 15].x, acc[d]);
+            acc[0] = TA_BAND_MFMA(A.y, W[j].y, acc[0]);
+            src.request(W[j], I + d0 + 16);
+#pragma unroll
+            for (int d = 1; d < 15; ++d) acc[d] = TA_BAND_MFMA(A.y, W[(j + d) & 15].y, acc[d]);
+            __builtin_amdgcn_sched_barrier(0);
+            TA_BAND_WAIT(2, W[(j + 15) & 15]);
+            if (TA_BAND_ABL < 2) W[(j + 15) & 15] = h.prep_b(W[(j + 15) & 15], r, I + d0 + 15);
+            acc[15] = TA_BAND_MFMA(A.x, W[(j + 15) & 15].x, acc[15]);
+            acc[15] = TA_BAND_MFMA(A.y, W[(j + 15) & 15].y, acc[15]);
+            if (++I == i1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                return;
+            }
+        }
+    }
+}
+
 // pm: pair-major float64 slab (layout.hip).  grid: n_labels * (slots / 8) workgroups of 512.
+// HELF: pm is the product slab P; columns go in groups of three pairs, results are -1/2 the squared differences
+template <bool HELF>
 __global__ void __launch_bounds__(512)
     k_band_lags(const double* __restrict__ pm, long pitch, int T, long n_pairs, int n_labels, int n_ph,
                 const BandPiece* __restrict__ pieces, int n_pieces, const int* __restrict__ slot_begin,
@@ -201,7 +352,8 @@ __global__ void __launch_bounds__(512)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int label = blockIdx.x % n_labels;
     const int slot = (blockIdx.x / n_labels) * 8 + wave;
-    const long n_oct = (n_pairs + 3) / 4;
+    constexpr int kPairs = HELF ? 3 : 4;  // column pairs per visit
+    const long n_oct = (n_pairs + kPairs - 1) / kPairs;
     const int kk = lane >> 4;
     double* blk = red[wave];
     double* dsum = blk + 272;
@@ -212,25 +364,37 @@ __global__ void __launch_bounds__(512)
         const int d0 = __builtin_amdgcn_readfirstlane(pc.d0), i0 = __builtin_amdgcn_readfirstlane(pc.i0),
                   i1 = __builtin_amdgcn_readfirstlane(pc.i1), phase = __builtin_amdgcn_readfirstlane(pc.phase);
         band_d4 acc[16];
+        double na = 0.0;  // (HELF) squared norms of the A rows of the steps that did not put them through the product
 #pragma unroll
         for (int d = 0; d < 16; ++d) acc[d] = band_d4{0.0, 0.0, 0.0, 0.0};
         for (long o = label + (long)n_labels * phase; o < n_oct; o += (long)n_labels * n_ph) {
-            const long left = n_pairs - 4 * o;  // pairs of this octet that exist
+            const long left = n_pairs - kPairs * o;  // pairs of this octet that exist
             BandSrc src;
-            const unsigned long long base = reinterpret_cast<unsigned long long>(pm + 4 * o * pitch * 2);
+            const unsigned long long base = reinterpret_cast<unsigned long long>(pm + kPairs * o * pitch * 2);
             // raw buffer resource: base, stride 0, num_records in bytes, the gfx9 data format word
-            src.rs = band_u4{(unsigned)base, (unsigned)(base >> 32) & 0xffffu, (unsigned)((left < 4 ? left : 4) * pitch) * 16u,
-                             0x00020000u};
-            src.lane_off = (unsigned)(kk * pitch + (lane & 15)) * 16u;
+            src.rs = band_u4{(unsigned)base, (unsigned)(base >> 32) & 0xffffu,
+                             (unsigned)((left < kPairs ? left : kPairs) * pitch) * 16u, 0x00020000u};
+            src.lane_off = (HELF && kk == 3) ? 0xf0000000u : (unsigned)(kk * pitch + (lane & 15)) * 16u;
             src.T = T;
             src.i = lane & 15;
-            band_visit(src, d0, i0, i1, acc);
+            src.slot = HELF && kk == 3;
+            if constexpr (HELF) band_visit_helfand(src, d0, i0, i1, acc, na);
+            else band_visit(src, d0, i0, i1, acc);
         }
         // diagonals: acc[d] register r of lane l is C_d[m = 4 r + (l >> 4)][n = l & 15], lag 16 (d0 + d) + n - m
+        double na_m[4] = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (HELF) {  // nA[m] / 2 of the lane's four rows m = 4 r + (l >> 4), through the LDS
+            const double tot = band_sum_rows(kk == 3 ? 0.0 : na);
+            if (lane < 16) dsum[lane] = 0.5 * tot;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) na_m[r] = dsum[4 * r + (lane >> 4)];
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) blk[(4 * r + (lane >> 4)) * 17 + (lane & 15)] = acc[d][r];
+            for (int r = 0; r < 4; ++r) blk[(4 * r + (lane >> 4)) * 17 + (lane & 15)] = acc[d][r] - na_m[r];
             __builtin_amdgcn_wave_barrier();
             if (lane < 31) {
                 const int e = lane - 15;
@@ -257,10 +421,12 @@ __global__ void __launch_bounds__(512)
     }
 }
 
-// lagsum[k] = (sum over labels and over the pieces that hold lag k) / (T - k), fixed order
+// lagsum[k] = factor * (sum over labels and over the pieces that hold lag k) / (T - k), fixed order;
+// zero_lag0: lagsum[0] = 0 exactly (viscosity.py:205-233 leaves row 0 at 0)
 __global__ void __launch_bounds__(256)
     k_band_gather(const double* __restrict__ partial, int n_labels, int n_pieces, int n_ph, int per_phase,
-                  const int* __restrict__ group_begin, int n_groups, int T, double* __restrict__ lagsum) {
+                  const int* __restrict__ group_begin, int n_groups, int T, double factor, int zero_lag0,
+                  double* __restrict__ lagsum) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= T) return;
     double s = 0.0;
@@ -274,7 +440,7 @@ __global__ void __launch_bounds__(256)
                 for (int lab = 0; lab < n_labels; ++lab)
                     s += partial[((long)lab * n_pieces + ph * per_phase + li) * kBandPartial + off + 15];
     }
-    lagsum[k] = s / (double)(T - k);
+    lagsum[k] = (zero_lag0 && k == 0) ? 0.0 : factor * (s / (double)(T - k));
 }
 
 }  // namespace ta

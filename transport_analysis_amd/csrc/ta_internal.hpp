@@ -34,11 +34,12 @@ bool direct_chunk_supported(int L);       // lags per chunk compiled in (8, 10)
 size_t direct_lds_bytes(int T, bool f32, int L);
 int direct_max_wg_per_cu(int mode, bool f32, int L, int nt, size_t lds_bytes, bool global_stage);
 
-// band.hip: the windowed VACF lag SUMS on the FP64 matrix cores (band_kernels.hpp); lagsum[k] =
-// sum over all columns and time origins / (n_frames - k); *cache: the plan's device copy, kept by the caller
+// band.hip: lag SUMS on the FP64 matrix cores (band_kernels.hpp); *cache: the plan's device copy, kept by the caller
+//   windowed VACF: lagsum[k] = factor * sum over columns c and origins i of pm[i, c] pm[i + k, c] / (n_frames - k)
+//   helfand (pm = the product slab P): factor * sum of (P[i, c] - P[i + k, c])^2 / (n_frames - k), lagsum[0] = 0
 struct BandCache;
-hipError_t launch_band_lags(BandCache** cache, int n_cu, const double* pm, long pitch, int T, long n_cols, double* lagsum,
-                            hipStream_t st);
+hipError_t launch_band_lags(BandCache** cache, int n_cu, bool helfand, const double* pm, long pitch, int T, long n_cols,
+                            double factor, double* lagsum, hipStream_t st);
 void band_cache_free(BandCache* c);
 
 hipError_t launch_row_sums(const double* bp, long n_rows, long n_cols, long ld, double* out,
