@@ -256,12 +256,15 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *                      products / squared differences and 32-term block sums in float32
  *                      and add them into float64 accumulators (BASELINE configs[4]'s
  *                      float32 path; ~1e-6 relative accuracy).  Default 0 = float64.
- *   "direct_mfma" 1|0: ta_vacf_direct* without a by-particle array (lag sums only, float64) run on
- *                      the FP64 matrix cores: the lag sums are the diagonal sums of the frames'
- *                      Gram matrix (band_kernels.hpp; same quantity, velocityautocorr.py:217-238
- *                      summed over particles; 1.4x the vector kernel).  0 = the vector kernel.
- *                      With a by-particle array, "direct_f32" or the Helfand correlator the
- *                      vector kernels run whatever this says.
+ *   "direct_mfma" 1|0: ta_vacf_direct* and ta_helfand_msd* WITHOUT a by-particle array (lag sums only,
+ *                      float64) run on the FP64 matrix cores (band_kernels.hpp): the windowed VACF's
+ *                      lag sums are the diagonal sums of the frames' Gram matrix
+ *                      (velocityautocorr.py:217-238 summed over particles; 1.4x the vector kernel); the
+ *                      Helfand squared differences (viscosity.py:201-233) are formed from products of
+ *                      rows centred on a nearby frame (1.5x; every lag within 1e-10 of the
+ *                      difference-first vector kernel even for a pure trend; needs T*A*D*8 bytes for
+ *                      the product slab, else the vector kernel runs).  0 = the vector kernels.  With a
+ *                      by-particle array or "direct_f32" the vector kernels run whatever this says.
  *   "helfand_fft" 0|1: ta_helfand_msd* evaluate the mean squared differences in O(T log T)
  *                      (n_frames <= 163840, else as default): sum (P[i]-P[i+k])^2 = S1(k) - 2 S2(k), S2 by the FFT
  *                      lag sums of the product slab P = (m v) x, S1 by prefix sums.  An
