@@ -143,7 +143,8 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, pm, (size_t)n_pairs * pitch * 2);
     CK(hipMalloc(&out, 8 * T));
     DevPlan d;
-    d.p = band_plan(T, (nwg / 8) * 8, 8);
+    const int labels = getenv("BAND_LABELS") ? atoi(getenv("BAND_LABELS")) : 8;
+    d.p = band_plan(T, (nwg / labels) * 8, labels, getenv("BAND_NPH") ? atoi(getenv("BAND_NPH")) : 0);
     d.upload();
     printf("T=%d A=%ld D=%d: groups %d, n_ph %d, pieces %zu, slot cost max/mean %.1f / %.1f steps per octet\n", T, A, D, d.p.n_groups,
            d.p.n_ph, d.p.pieces.size(), d.p.max_cost, d.p.mean_cost);

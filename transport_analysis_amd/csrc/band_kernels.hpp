@@ -57,7 +57,7 @@ struct BandPlan {
 // filling the window.  A label keeps n_ph octets in flight (phases), so that a wave slot's share of
 // the band is long enough (>= 64 steps where the band allows it) to be cut into ~4 pieces: pieces
 // are dealt longest first onto the least loaded slot, which evens out what whole groups cannot.
-inline BandPlan band_plan(int T, int slots, int n_labels) {
+inline BandPlan band_plan(int T, int slots, int n_labels, int force_ph = 0) {
     constexpr double kVisit = 1.5;
     BandPlan p;
     p.T = T;
@@ -73,6 +73,7 @@ inline BandPlan band_plan(int T, int slots, int n_labels) {
     while (2 * n_ph <= slots && n_ph < 64 && (double)total * n_ph / slots < 64.0 &&
            (double)T * 64.0 * (2 * n_ph) <= 3.0 * 1048576.0)
         n_ph *= 2;
+    if (force_ph > 0) n_ph = force_ph;  // (experiments: tools/band/band_test)
     while (slots % n_ph) n_ph /= 2;
     p.n_ph = n_ph;
     const int wslots = slots / n_ph;  // wave slots of one phase
