@@ -251,6 +251,13 @@ int ta_clock_probe(ta_ctx *ctx, int n_launches, double *mhz, double *cycles_per_
  * Beyond that ta_vacf_fft* compute the same quantity with the direct correlator and this
  * call returns TA_E_UNSUPPORTED.                                              */
 int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_stages);
+/* Host only: how the matrix-core lag-sum kernels ("direct_mfma", band_kernels.hpp) cut their work for
+ * n_frames on a device of n_cu compute units: time in blocks of 16 frames, block lags in groups of 16,
+ * group g a band of ceil(n_frames/16) - 16 g steps per group of columns; the band is cut into equal
+ * shares for 256 wave slots per XCD, *octets_in_flight column groups at a time.  The call verifies
+ * that every step belongs to exactly one piece and every piece to exactly one wave
+ * (TA_E_UNSUPPORTED otherwise: a bug); *max_over_mean: the busiest wave's share over the average.  */
+int ta_band_plan_info(int64_t n_frames, int n_cu, int *n_pieces, int *octets_in_flight, double *max_over_mean);
 /* options (key, value):
  *   "direct_f32" 0|1 : direct correlators (ta_vacf_direct*, ta_helfand_msd*) evaluate
  *                      products / squared differences and 32-term block sums in float32

@@ -5,6 +5,7 @@
 // the partial-sum buffer are cached per context.
 #include "band_kernels.hpp"
 
+#include "../../include/ta_hip.h"
 #include "ta_internal.hpp"
 
 namespace ta {
@@ -74,3 +75,44 @@ hipError_t launch_band_lags(BandCache** cache, int n_cu, bool helfand, const dou
 }
 
 }  // namespace ta
+
+// Host only: the cut of the band for n_frames on a device of n_cu compute units, checked cell by
+// cell (every step of every group belongs to exactly one piece of every phase, every piece to
+// exactly one wave slot of its phase).
+extern "C" int ta_band_plan_info(int64_t n_frames, int n_cu, int* n_pieces, int* octets_in_flight, double* max_over_mean) {
+    using namespace ta;
+    if (n_frames < 1 || n_frames >= ((int64_t)1 << 24) || n_cu < 8) return TA_E_INVALID;
+    constexpr int kLabels = 8;
+    const int nwg = n_cu / kLabels * kLabels;
+    const BandPlan p = band_plan((int)n_frames, nwg / kLabels * 8, kLabels);
+    const int per = p.per_phase;
+    if ((int)p.pieces.size() != per * p.n_ph || (int)p.slot_begin.size() != p.slots + 1) return TA_E_UNSUPPORTED;
+    // coverage of the band by one phase's pieces
+    std::vector<std::vector<int>> seen(p.n_groups);
+    for (int g = 0; g < p.n_groups; ++g) seen[g].assign(p.nblk - 16 * g, 0);
+    for (int g = 0; g < p.n_groups; ++g)
+        for (int li = p.group_begin[g]; li < p.group_begin[g + 1]; ++li) {
+            const BandPiece& q = p.pieces[li];
+            if (q.d0 != 16 * g || q.i0 < 0 || q.i1 > p.nblk - 16 * g || q.i0 >= q.i1) return TA_E_UNSUPPORTED;
+            for (int i = q.i0; i < q.i1; ++i) ++seen[g][i];
+        }
+    for (auto& row : seen)
+        for (int c : row)
+            if (c != 1) return TA_E_UNSUPPORTED;
+    // every piece of every phase in exactly one slot, of its own phase
+    std::vector<int> owner(p.pieces.size(), 0);
+    const int wslots = p.slots / p.n_ph;
+    for (int s = 0; s < p.slots; ++s)
+        for (int k = p.slot_begin[s]; k < p.slot_begin[s + 1]; ++k) {
+            const int idx = p.slot_pieces[k];
+            if (idx < 0 || idx >= (int)p.pieces.size() || p.pieces[idx].phase != s / wslots || idx / per != s / wslots)
+                return TA_E_UNSUPPORTED;
+            ++owner[idx];
+        }
+    for (int c : owner)
+        if (c != 1) return TA_E_UNSUPPORTED;
+    if (n_pieces) *n_pieces = (int)p.pieces.size();
+    if (octets_in_flight) *octets_in_flight = p.n_ph;
+    if (max_over_mean) *max_over_mean = p.mean_cost > 0 ? p.max_cost / p.mean_cost : 1.0;
+    return TA_OK;
+}
