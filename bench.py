@@ -26,7 +26,8 @@ carries the FP64 vector co-roof beside it.  `cpu_baseline` is the NumPy oracle (
 tensor.  `other_configs` (N = 1) are short driver-timed runs of the other BASELINE configs; their
 `roofline.frac` is the WHOLE path's algorithmic bytes (or flops) over the whole call's device
 time, with the per-kernel split (`kernels`, from the library's event timeline of one extra,
-untimed step) beside it.  `staging` prices what the timed region leaves out: the on-device
+untimed step) beside it; the float64 lag sums of the O(T^2) correlators (configs[3], configs[4])
+run on the FP64 matrix cores and are priced against the matrix peak (`bound: "mfma"`).  `staging` prices what the timed region leaves out: the on-device
 transposition of frame-major frames into the pair-major slab (k_relayout) and a complete
 ta_vacf_fft_dev call on a frame-major device tensor.  `host_path_by_particle` runs the drop-in
 CLASS end to end (frames staged through pinned memory, result array in pinned memory).
