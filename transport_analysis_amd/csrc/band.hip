@@ -50,12 +50,14 @@ hipError_t launch_band_lags(BandCache** cache, int n_cu, bool helfand, const dou
         band_release(&c);
         c.plan = band_plan(T, nwg / kLabels * 8, kLabels);
         c.nwg = nwg;
-        if ((e = band_upload(&c.pieces, c.plan.pieces)) != hipSuccess) return e;
-        if ((e = band_upload(&c.slot_begin, c.plan.slot_begin)) != hipSuccess) return e;
-        if ((e = band_upload(&c.slot_pieces, c.plan.slot_pieces)) != hipSuccess) return e;
-        if ((e = band_upload(&c.group_begin, c.plan.group_begin)) != hipSuccess) return e;
-        e = hipMalloc((void**)&c.partial, sizeof(double) * (size_t)kLabels * c.plan.pieces.size() * kBandPartial);
-        if (e != hipSuccess) {
+        e = band_upload(&c.pieces, c.plan.pieces);
+        if (e == hipSuccess) e = band_upload(&c.slot_begin, c.plan.slot_begin);
+        if (e == hipSuccess) e = band_upload(&c.slot_pieces, c.plan.slot_pieces);
+        if (e == hipSuccess) e = band_upload(&c.group_begin, c.plan.group_begin);
+        if (e == hipSuccess)
+            e = hipMalloc((void**)&c.partial, sizeof(double) * (size_t)kLabels * c.plan.pieces.size() * kBandPartial);
+        if (e != hipSuccess) {  // nothing half-built stays behind
+            band_release(&c);
             c.plan.T = 0;
             return e;
         }
