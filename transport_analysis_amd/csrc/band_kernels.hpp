@@ -1,4 +1,6 @@
-// band_kernels.hpp — windowed VACF lag SUMS on the FP64 matrix cores (gfx950 v_mfma_f64_16x16x4_f64).
+// band_kernels.hpp — lag SUMS of the O(T^2) correlators on the FP64 matrix cores (gfx950
+// v_mfma_f64_16x16x4_f64): the windowed VACF (below) and, further down, the Einstein-Helfand squared
+// differences on the product slab.
 //
 // Quantity: VelocityAutocorr._conclude_simple summed over particles
 // (/root/reference/transport_analysis/velocityautocorr.py:217-238):
@@ -19,7 +21,9 @@
 // — no LDS, no barrier in the loop.  Columns go in octets (4 column pairs = one 16-byte load per
 // lane); the workgroups with the same blockIdx % n_labels (one XCD, as the hardware deals them)
 // sweep the same octets in the same order, their waves covering the whole band between them, so
-// an octet (T x 64 bytes) is read from HBM once and from that XCD's L2 by everybody else.
+// an octet (T x 64 bytes) is read by one XCD only.  (Nothing paces the waves, though: measured, 90 % of
+// the L2 requests miss and are served by the Infinity Cache / HBM — 2.2 TB/s, no time lost while
+// the matrix pipe is the limit)
 //
 // Output: partial[label][piece][272] (lags 16 d0 - 15 ... 16 d0 + 255 of that piece), every element
 // written; k_band_gather adds them up in a fixed order: results do not depend on scheduling.
@@ -55,8 +59,9 @@ struct BandPlan {
 // slots: wave slots per label (workgroups per label x 8).  Group g = block lags 16 g .. 16 g + 15 has
 // nblk - 16 g steps per octet; a visit (one piece on one octet) costs its steps plus kVisit for
 // filling the window.  A label keeps n_ph octets in flight (phases), so that a wave slot's share of
-// the band is long enough (>= 64 steps where the band allows it) to be cut into ~4 pieces: pieces
-// are dealt longest first onto the least loaded slot, which evens out what whole groups cannot.
+// the band is long enough (>= 64 steps where the band allows it) for the visits' overhead not to
+// count.  The band, group after group, is one sequence of steps cut into equal shares, one per wave
+// slot; a share that crosses a group boundary is two (or more) pieces with their own accumulators.
 inline BandPlan band_plan(int T, int slots, int n_labels, int force_ph = 0) {
     constexpr double kVisit = 1.5;
     BandPlan p;
