@@ -284,3 +284,32 @@ def test_group_blocked_by_particle_copies_into_column_ranges(kind):
     assert scale_rel_err(out, want_bp) < TOL
     g.close()
 
+
+@pytest.mark.parametrize("kind", ["direct", "helfand"])
+def test_group_lag_sums_on_the_matrix_cores(kind):
+    """Lag sums alone through a device group: every member runs the matrix-core kernel
+    (band_kernels.hpp) on its own column block — shards of different widths, an odd column count in the
+    last one — and the in-library reduce adds the members' lag sums."""
+    from oracle import numpy_oracle as orc
+    from transport_analysis_amd import _lib
+
+    T, A, D = 700, 101, 3
+    v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=23)
+    g = _lib.Group([0, 0, 0])
+    slabs = g.stage_alloc(T, A, D, n_slabs=2 if kind == "helfand" else 1, dtype=np.float64)
+    for view, (lo, hi) in zip(slabs[0], g.shards):
+        view[...] = v[:, lo:hi]
+    if kind == "helfand":
+        for view, (lo, hi) in zip(slabs[1], g.shards):
+            view[...] = x[:, lo:hi]
+    g.stage_commit(0, T)
+    if kind == "helfand":
+        scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+        ts, bp = g.helfand_msd(m, scale, by_particle=False)
+        want_ts = orc.helfand(v, x, m, vol, 300.0)[1]
+    else:
+        ts, bp = g.vacf_direct(by_particle=False)
+        want_ts = orc.vacf_windowed(v)[1]
+    assert bp is None and g.reduce_kind == "peer-copy"
+    assert scale_rel_err(ts, want_ts) < TOL
+    g.close()
