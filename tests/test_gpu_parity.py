@@ -759,6 +759,34 @@ def test_relayout_16_byte_path(ctx, T, A, D, ld, off):
     assert np.array_equal(out.cpu().numpy(), wide.cpu().numpy()[:, off:off + A * D])
 
 
+@pytest.mark.parametrize("T,A,D,ld,off,lo", [(130, 7, 3, 28, 4, 0), (64, 64, 2, 128, 0, 0), (257, 33, 3, 100, 0, 0), (1, 1, 2, 4, 0, 0),
+                                              (200, 129, 1, 132, 0, 0), (131, 10, 3, 32, 0, 64), (90, 9, 3, 28, 0, 33)])
+def test_relayout_float32_16_byte_path(ctx, T, A, D, ld, off, lo):
+    """float32 frame-major rows into a float32 device slab ("stage_device_f32"): row stride a multiple of
+    4 and a 16-byte aligned base take k_relayout_wide32 (16-byte accesses on both sides, two rows of
+    a pair per store): odd column and frame counts, partial tiles, a column block of a wider tensor,
+    frames committed in two pieces (an odd first frame of the second piece falls back to the generic
+    kernel)."""
+    import torch
+
+    rng = np.random.default_rng(T + 11 * A)
+    wide = torch.from_numpy(rng.standard_normal((T, ld)).astype(np.float32)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.set_option("stage_device_f32", 1)
+    try:
+        ctx.stage_alloc_device(T, A, D, n_slabs=1)
+        assert (wide.data_ptr() + off * 4) % 16 == 0 and ld % 4 == 0
+        for a, b in ((0, lo), (lo, T)):
+            if b > a:
+                ctx.stage_commit_dev(0, wide.data_ptr() + off * 4 + a * ld * 4, ld, a, b, dtype="float32", stream=st)
+        out = torch.empty((T, A * D), dtype=torch.float64, device="cuda")
+        ctx.stage_read_dev(0, out.data_ptr(), A * D, st)
+        torch.cuda.synchronize()
+    finally:
+        ctx.set_option("stage_device_f32", 0)
+    assert np.array_equal(out.cpu().numpy(), wide.cpu().numpy()[:, off:off + A * D].astype(np.float64))
+
+
 def test_clock_probe(ctx):
     """ta_clock_probe: the stamped build of the lag-sum forward kernel reports a plausible shader
     clock and cycle count on the staged slab; plans without a stamped build say so."""

@@ -93,6 +93,50 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// float32 -> float32 (MDAnalysis' dtype on both sides: a float32 frame-major device tensor into a float32
+// slab, "stage_device_f32") with 16-byte accesses on both sides: a source element is two pairs of one
+// row, a destination element two rows of one pair.  Tile: 64 rows x 64 pairs of 8 bytes through LDS.
+// Needs ld_row % 4 == 0, a 16-byte aligned source, even t_dst0 (the slab pitch is a multiple of 8).
+__global__ void __launch_bounds__(256)
+    k_relayout_wide32(const float* __restrict__ src, long ld_row, long n_cols, long t_count,
+                      float* __restrict__ dst, long pitch, long t_dst0) {
+    __shared__ __attribute__((aligned(16))) float2 tile[64][65];
+    const int tid = threadIdx.x, q = tid >> 5, l = tid & 31;
+    const long p0 = (long)blockIdx.x * 64, r0 = (long)blockIdx.y * 64;
+    const long n_pairs = (n_cols + 1) / 2;
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // row 8 i + q of the tile, pairs 2 l and 2 l + 1
+        const long t = r0 + 8 * i + q, c = 2 * (p0 + 2 * l);
+        v[i] = float4{0.f, 0.f, 0.f, 0.f};
+        if (t < t_count) {
+            const float* s = src + t * ld_row + c;
+            if (c + 3 < n_cols) v[i] = *reinterpret_cast<const float4*>(s);
+            else {  // the row's last columns: an odd last column is paired with a zero
+                if (c < n_cols) v[i].x = s[0];
+                if (c + 1 < n_cols) v[i].y = s[1];
+                if (c + 2 < n_cols) v[i].z = s[2];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        tile[8 * i + q][2 * l] = float2{v[i].x, v[i].y};
+        tile[8 * i + q][2 * l + 1] = float2{v[i].z, v[i].w};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // pair 8 i + q of the tile, rows 2 l and 2 l + 1
+        const long pair = p0 + 8 * i + q, t = r0 + 2 * l;
+        if (pair < n_pairs && t < t_count) {
+            const float2 a = tile[2 * l][8 * i + q], b = tile[2 * l + 1][8 * i + q];
+            float* d = dst + (pair * pitch + t_dst0 + t) * 2;
+            if (t + 1 < t_count) *reinterpret_cast<float4*>(d) = float4{a.x, a.y, b.x, b.y};
+            else *reinterpret_cast<float2*>(d) = a;
+        }
+    }
+}
+
 // The inverse, for callers that want a frame-major copy back (tests, diagnostics).
 template <typename PmT>
 __global__ void __launch_bounds__(256)
@@ -226,6 +270,13 @@ hipError_t launch_relayout(const void* src, bool src_f32, long ld_row, long n_co
         const dim3 wgrid((unsigned)((n_pairs + 63) / 64), (unsigned)((t_count + 63) / 64));
         hipLaunchKernelGGL(k_relayout_wide, wgrid, dim3(256), kWideLds, st, (const double*)src, ld_row, n_cols, t_count,
                            (double*)dst, pitch, t_dst0);
+        return hipGetLastError();
+    }
+    if (src_f32 && dst_f32 && ld_row % 4 == 0 && ((uintptr_t)src & 15) == 0 && t_dst0 % 2 == 0 && pitch % 2 == 0) {
+        const long n_pairs = (n_cols + 1) / 2;
+        const dim3 wgrid((unsigned)((n_pairs + 63) / 64), (unsigned)((t_count + 63) / 64));
+        hipLaunchKernelGGL(k_relayout_wide32, wgrid, dim3(256), 0, st, (const float*)src, ld_row, n_cols, t_count,
+                           (float*)dst, pitch, t_dst0);
         return hipGetLastError();
     }
     const dim3 grid((unsigned)((n_cols + 63) / 64), (unsigned)((t_count + 63) / 64));
