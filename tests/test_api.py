@@ -205,6 +205,23 @@ def test_helfand_full_kat(backend, step_vtraj):
     assert_allclose(vh.results.timeseries, g("kat_helfand_poly_N5001_D1.npy"))
 
 
+@pytest.mark.parametrize("tdim,tdim_factor", DIMS)
+def test_lag_sums_only_on_the_reference_kats(backend, step_vtraj, tdim, tdim_factor):
+    """by_particle=False (timeseries only) of both O(T^2) analyses on the reference's step
+    trajectory: on the GPU these are the matrix-core kernels (windowed VACF: diagonal sums of the
+    frames' Gram matrix; Helfand: products of rows centred on a nearby frame) — the same tolerances
+    as the reference's own assertions (test_velocityautocorr.py:269-279, test_viscosity.py:180-208),
+    and the Helfand one lag by lag since its short lags are what a careless expansion loses."""
+    v = VACF(step_vtraj.atoms, dim_type=tdim, fft=False, by_particle=False).run()
+    assert v.results.vacf_by_particle is None
+    assert_almost_equal(v.results.timeseries, g(f"kat_vacf_poly_N5001_D{tdim_factor}.npy"), decimal=4)
+    vh = VH(step_vtraj.atoms, dim_type=tdim, by_particle=False).run(start=10, stop=1000, step=10)
+    assert vh.results.visc_by_particle is None and vh.results.timeseries[0] == 0.0
+    assert_allclose(vh.results.timeseries, g(f"kat_helfand_poly_10_1000_10_D{tdim_factor}.npy"))
+    vh = VH(step_vtraj.atoms, dim_type=tdim, by_particle=False).run()
+    assert_allclose(vh.results.timeseries, g(f"kat_helfand_poly_N5001_D{tdim_factor}.npy"))
+
+
 def test_helfand_float32_switch(backend, step_vtraj):
     """float32=True selects the library's float32 squared-difference path (configs[4])."""
     vh = VH(step_vtraj.atoms, dim_type="xy", float32=True).run(start=10, stop=1000, step=10)
