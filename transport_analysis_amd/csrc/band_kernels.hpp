@@ -146,10 +146,16 @@ struct BandSrc {
     int T, i;           // frames; this lane's frame inside a block (lane & 15)
     bool slot;          // Helfand form: lane group 3 carries the norms instead of columns (reads zeros)
     // (lane_off of the Helfand form's fourth lane group is outside the resource: it reads zeros)
+    // "s_nop 4": the resource may have just been restored from a spilled SGPR by v_readlane — a VALU
+    // write of an SGPR that a VMEM instruction reads needs 5 wait states, and the compiler's hazard
+    // recogniser does not look inside inline assembly.  (Found with the block offset in the
+    // instruction's scalar-offset field, which saves the per-request vector add: restored by
+    // v_readlane right in front of the load it read stale, wrong rows; with the nop that form is
+    // correct and no faster — 54.2 / 410.6 / 638.8 ms either way — so the plain form stays.)
     __device__ __forceinline__ void request(band_d2& dst, int b) const {
         unsigned off = lane_off + (unsigned)b * 256u;
         if (16 * b + 16 > T) off = 16 * b + i < T ? off : 0xfffffff0u;  // wave-uniform: a block at the end of the series
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(off), "s"(rs));
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(off), "s"(rs));
     }
 };
 #define TA_BAND_WAIT(N, REG) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(REG))
@@ -380,7 +386,9 @@ __global__ void __launch_bounds__(512)
             // raw buffer resource: base, stride 0, num_records in bytes, the gfx9 data format word
             src.rs = band_u4{(unsigned)base, (unsigned)(base >> 32) & 0xffffu,
                              (unsigned)((left < kPairs ? left : kPairs) * pitch) * 16u, 0x00020000u};
-            src.lane_off = (HELF && kk == 3) ? 0xf0000000u : (unsigned)(kk * pitch + (lane & 15)) * 16u;
+            // (Helfand form: the fourth lane group reads just past the resource's last byte: zeros)
+            src.lane_off = (unsigned)(kk * pitch + (lane & 15)) * 16u;
+            if (HELF && kk == 3) src.lane_off = (unsigned)(3 * pitch) * 16u + (unsigned)(lane & 15) * 16u;
             src.T = T;
             src.i = lane & 15;
             src.slot = HELF && kk == 3;
