@@ -402,6 +402,27 @@ def test_vacf_fft_long_trajectory(ctx, T, A, D):
     assert scale_rel_err(ts, want_ts) < TOL
 
 
+def test_vacf_beyond_the_fft_plans(ctx):
+    """n_frames > 163840: ta_vacf_fft computes the same quantity with the O(T^2) correlators — the lag sums
+    on the matrix cores (10241 block lags, 641 groups: more groups than wave slots, so every wave runs
+    several whole groups), the by-particle array on the vector kernel with the column staged in global
+    memory — against the FFT oracle."""
+    from oracle import numpy_oracle as orc
+
+    T, A, D = 163841, 1, 2
+    v = orc.synthetic_velocities(T, A, D, seed=77)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
+    ctx.set_option("timeline", 1)
+    try:
+        ts, bp = run_vacf(ctx, v, True, False)
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_lags"]
+    finally:
+        ctx.set_option("timeline", 0)
+    assert scale_rel_err(ts, want_ts) < TOL
+    ts, bp = ctx.vacf_fft(by_particle=True)
+    assert scale_rel_err(bp, want_bp) < TOL and scale_rel_err(ts, want_ts) < TOL
+
+
 def test_vacf_fft_long_trajectory_many_pairs_and_step_kat(ctx):
     """More column pairs than workgroups (several pairs per workgroup, accumulator blocks
     carried across pairs), and the reference's closed-form step trajectory at N = 12001."""
