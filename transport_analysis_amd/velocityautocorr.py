@@ -35,9 +35,10 @@ class VelocityAutocorr(AnalysisBase):
     by_particle : bool, keyword-only, default True
         ``True`` materialises ``results.vacf_by_particle`` (n_frames, n_atoms)
         as the reference does.  ``False`` is the fast path: only
-        ``results.timeseries`` is computed (power spectra are summed over atoms
-        on the GPU before the single inverse transform) and
-        ``results.vacf_by_particle`` is ``None``.
+        ``results.timeseries`` is computed (``fft=True``: power spectra are summed
+        over atoms on the GPU before the single inverse transform; ``fft=False``:
+        the lag sums are the diagonal sums of the frames' Gram matrix, on the FP64
+        matrix cores) and ``results.vacf_by_particle`` is ``None``.
     device : int, keyword-only
         GPU index (default: ``$TA_AMD_DEVICE`` or 0; with ``distributed=True``:
         ``$TA_AMD_DEVICE``, else ``$LOCAL_RANK``, else torch's current device).

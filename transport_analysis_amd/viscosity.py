@@ -26,7 +26,8 @@ class ViscosityHelfand(AnalysisBase):
     dim_type : {'xyz', 'xy', 'yz', 'xz', 'x', 'y', 'z'}
     linear_fit_window : (int, int) or None — lag-index window for the slope fit.
     by_particle : bool, keyword-only, default True — materialise
-        ``results.visc_by_particle``; ``False`` computes the timeseries only.
+        ``results.visc_by_particle``; ``False`` computes the timeseries only (float64: on the
+        FP64 matrix cores, 1.5x the vector kernel, every lag to rounding).
     device : int, keyword-only — GPU index (default ``$TA_AMD_DEVICE`` or 0).
     distributed : bool, keyword-only, default False — one process per GPU under
         ``torch.distributed``: each rank handles its contiguous block of atoms, one all-reduce of
