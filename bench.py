@@ -3,9 +3,11 @@
 
     python bench.py [--gpus N --steps K --warmup W] [--scaling weak|strong]
 
-N > 1 is launched by the driver as
+N > 1 runs one rank per GPU (RCCL): either the driver starts the ranks,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-one rank per GPU (RCCL).  Workload: BASELINE.json configs[2]'s tensor, 10 000 frames x
+or a bare `python bench.py --gpus N` starts that very command itself as a CHILD process (before
+this process has imported torch or touched a GPU), lets rank 0's JSON line through and exits
+with the child's status.  Workload: BASELINE.json configs[2]'s tensor, 10 000 frames x
 100 000 atoms x 3 float64 -- per GPU with --scaling weak (the default: the atom axis is the
 sharded unit, per-GPU work fixed), in total with --scaling strong (configs[2] exactly: 100 000
 atoms over the N GPUs).  Every rank materialises ITS column block of ONE synthetic tensor with
@@ -92,6 +94,11 @@ def parse():
                     help="N GPUs from one process: the library's own fan-out and reduce (ta_group)")
     ap.add_argument("--devices", default="",
                     help="--single-process: comma-separated device ids of the members (default 0..N-1)")
+    ap.add_argument("--allow-peer-copy", action="store_true",
+                    help="--single-process on distinct devices: accept the peer-copy reduce when RCCL fails "
+                         "(default: that is an error)")
+    ap.add_argument("--full-json", default="",
+                    help="also write the JSON line, indented, to this file (tools/profile_bench.sh: profiles/rNN_bench_full.json)")
     ap.add_argument("--no-clock-probe", action="store_true")
     return ap.parse_args()
 
@@ -131,6 +138,40 @@ def model_ceiling():
                                          "not a reachable state, the distance DESIGN.md section 6.0 item 4 describes"}}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child
+    `python -m torch.distributed.run` (what the driver's own N > 1 command is) and exit with its
+    status.  Called before torch is imported: this process never creates a GPU context, and the
+    ranks are children, not a re-exec.  stdout is inherited, so rank 0's JSON line is this
+    command's JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TA_BENCH_LAUNCHER="bench.py started torch.distributed.run itself")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def member_rooflines(g, T, D, steps):
+    """per member of a ta_group: median device time of the dominant kernel over the timed calls and the
+    algorithmic HBM rate it stands for (that member's atoms x n_frames x dim x 8 bytes)"""
+    out = []
+    for i, (lo, hi) in enumerate(g.shards):
+        if hi == lo:
+            continue
+        hist = g.member_context(i).timing_history(min(steps, 64))
+        kms = statistics.median(m for _, m in hist)
+        tms = statistics.median(t for t, _ in hist)
+        b = T * (hi - lo) * D * 8
+        out.append({"member": i, "device": g.devices[i], "atoms": hi - lo, "kernel_ms": kms, "whole_call_ms": tms,
+                    "GBps": b / (kms * 1e-3) / 1e9, "bytes": b})
+    return out
+
+
 def single_process(args):
     """N GPUs from one process through ta_group: every member's column block of the ONE synthetic
     tensor resident on its device, a step = ta_group_vacf_fft (fan-out, reduce inside the library,
@@ -146,6 +187,9 @@ def single_process(args):
     T, D = args.frames, args.dim
     a_total = args.atoms * args.gpus if args.scaling == "weak" else args.atoms
     g = _lib.Group(devices)
+    distinct = len(set(devices)) == len(devices)
+    if distinct and len(devices) > 1 and not args.allow_peer_copy:
+        g.set_option("reduce_mode", 2)  # RCCL or an error: a curve of the wrong collective is worse than none
     g.stage_alloc_device(T, a_total, D, n_slabs=1)
     g.stage_synth(0, SEED + 3, 0, a_total * D)
     fn = {"fft": g.vacf_fft, "direct": g.vacf_direct}[args.mode]
@@ -155,6 +199,10 @@ def single_process(args):
     for _ in range(args.steps):
         ts, _ = fn(by_particle=False)
     elapsed = time.perf_counter() - t0
+    members = member_rooflines(g, T, D, args.steps)
+    slowest = min(members, key=lambda m: m["GBps"])
+    # what the call adds to the slowest member's kernels: the reduce, the (n_frames,) copy to the host, the waits
+    overhead_ms = elapsed / args.steps * 1e3 - max(m["whole_call_ms"] for m in members)
     check = {}
     if not args.no_check and args.mode == "fft":  # lag 0 of the mean = mean square of the tensor's first columns
         blk = synth.synthetic_block(SEED + 3, T, a_total * D, 0, min(a_total * D, 96))
@@ -168,13 +216,29 @@ def single_process(args):
                                f"{args.gpus} member(s) of ONE process (ta_group; host-facing call, result on the host)",
                    "n_frames": T, "n_atoms_total": a_total, "dim": D, "mode": args.mode,
                    "sharding": f"atoms x{args.gpus}", "member_devices": devices, "shards": g.shards,
-                   "collective": g.reduce_kind, "library_sha16": so_sha16(), "launcher": "single process"},
+                   "collective": {"kind": g.reduce_kind, "library": "librccl (dlopen) inside ta_group_vacf_*" if g.reduce_kind == "rccl"
+                                  else "hipMemcpyPeerAsync + k_sum_partials" if g.reduce_kind == "peer-copy" else None,
+                                  "ranks_seen_by_rccl": g.rccl_ranks, "members": len(devices),
+                                  "fallback_note": g.reduce_note or None,
+                                  "op": f"reduce(sum) of ({T},) float64 lag sums onto member 0"},
+                   "library_sha16": so_sha16(), "launcher": "single process"},
+        "roofline": {"bound": "hbm", "achieved": slowest["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": slowest["GBps"] / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "k_wsplit_accum" if args.mode == "fft" else "k_band_lags",
+                     "kernel_ms": slowest["kernel_ms"], "algorithmic_bytes_per_launch": slowest["bytes"],
+                     "what": "the slowest member's dominant kernel (hipEvents on its own stream, median over the timed calls); "
+                             "`per_member` has all of them, `reduce_and_host_ms` what the call adds to the slowest member "
+                             "(the reduce, the copy of the timeseries to the host, the waits)",
+                     "per_member": members, "reduce_and_host_ms": overhead_ms},
         "check": check,
-        "note": "hardware scaling of this mode is unmeasured until a multi-GPU node runs it; members that share a "
-                "device (e.g. --devices 0,0) serialise on it",
+        "note": "members that share a device (e.g. --devices 0,0) serialise on it",
     }
-    print(json.dumps(out), flush=True)
+    if distinct and len(devices) > 1 and g.reduce_kind != "rccl" and not args.allow_peer_copy:
+        raise SystemExit(f"the members' lag sums were not reduced by RCCL ({g.reduce_kind}; {g.reduce_note})")
     g.close()
+    if not args.no_cpu_baseline and args.mode == "fft":
+        out["cpu_baseline"] = cpu_baseline(args, T, D, a_total * D)
+    print(json.dumps(out), flush=True)
 
 
 
@@ -330,17 +394,21 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
                "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "k_band_lags", "kernel_ms": kernel_ms,
                "algorithmic_flops_per_launch": fl, "hbm_GBps_for_reference": gbps}
         if case.mode == "helfand":
-            # `achieved` counts the reference's arithmetic (difference, square, add = 3 flop per term) like the
-            # vector kernel's line; what the matrix pipe issues is 2 flop per term on 6 of its 8 column slots
+            # `achieved` / `frac` = what the matrix pipe ISSUES: 2 flop per term on 6 of its 8 column slots (the
+            # fourth lane group carries the norms).  The reference's own arithmetic (difference, square, add =
+            # 3 flop per term; what the vector kernel's line counts) is `reference_flops_*`:
+            # a larger number that says nothing about the pipe
             issued = 2.0 * (8.0 / 6.0) * D * A * T * (T - 1) / 2 / (kernel_ms * 1e-3) / 1e12
-            out["matrix_pipe"] = {"issued_tflops": issued, "frac": issued / FP64_MFMA_PEAK_TFLOPS}
+            out.update({"achieved": issued, "frac": issued / FP64_MFMA_PEAK_TFLOPS,
+                        "issued_flops_per_launch": 2.0 * (8.0 / 6.0) * D * A * T * (T - 1) / 2,
+                        "reference_flops_tflops": tf, "reference_flops_frac": tf / FP64_MFMA_PEAK_TFLOPS})
         return out
     return {"bound": "valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
             "traffic": None, "kernel": "k_direct", "kernel_ms": kernel_ms,
             "algorithmic_flops_per_launch": fl, "hbm_GBps_for_reference": gbps}
 
 
-def cpu_baseline(args, T, D, n_cols_total):
+def cpu_baseline(args, T, D, n_cols_total, seconds=12.0):
     """NumPy oracle (reference control flow: per-atom loop, tidynamics-style FFT) on ONE core
     over the first atoms of the SAME synthetic tensor; linear in the atom count."""
     from oracle import numpy_oracle as orc
@@ -352,7 +420,7 @@ def cpu_baseline(args, T, D, n_cols_total):
         os.sched_setaffinity(0, {sorted(all_cpus)[0]})
     except Exception:
         pass
-    a = args.cpu_sample_atoms or max(8, int(8.0e7 // T))  # ~10-15 s of CPU work
+    a = args.cpu_sample_atoms or max(8, int(8.0e7 * seconds / 12.0 // T))  # ~10-15 s of CPU work at the default
     v = synth.synthetic_block(SEED + 3, T, n_cols_total, 0, a * D).reshape(T, a, D)
     t0 = time.perf_counter()
     orc.vacf_fft(v)
@@ -524,6 +592,9 @@ def host_path_by_particle(dev_index, T, D):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
+        # no launcher around us: be the launcher (a child process; nothing here has touched a GPU)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -538,8 +609,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run (one rank per GPU), "
-                         "or pass --single-process (the library's own fan-out)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # TA_BENCH_ONE_GPU=1: rehearsal of the N > 1 path on a one-GPU box (tests/test_gpu_dist.py):
@@ -651,9 +721,22 @@ def main():
         check["max_scale_rel_err_vs_torch_lags"] = max(errs)
         del fm
 
+    # every rank's dominant-kernel time (its own hipEvents) and bytes, then the group is done: what
+    # follows on rank 0 (CPU baseline, JSON) needs no collective and must not keep the others waiting
+    per_rank = [{"rank": rank, "atoms": A, "kernel_ms": kernel_ms, "whole_call_ms": total_ms, "reduce_us": reduce_us}]
+    collective = None
+    if grouped:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+        collective = {"backend": dist.get_backend(), "library": "RCCL (torch.distributed backend nccl)" if dist.get_backend() == "nccl"
+                      else "gloo (one-GPU rehearsal, lag sums through the host)", "ranks": dist.get_world_size(),
+                      "op": f"all_reduce(sum) of ({T},) float64 lag sums, device tensor in and out" if not one_gpu
+                      else f"all_reduce(sum) of ({T},) float64 lag sums on the host",
+                      "launcher": os.environ.get("TA_BENCH_LAUNCHER", "torch.distributed.run (started by the caller)")}
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
-        if grouped:
-            dist.destroy_process_group()
         return
     ms_per_step = elapsed / args.steps * 1e3
     composite = args.by_particle or args.helfand_fft
@@ -663,6 +746,22 @@ def main():
     key = (f"{args.mode}_{T}x{A}x{D}" + ("_bp" if args.by_particle else "") + ("_hfft" if args.helfand_fft else "")
            + ("_f32" if args.float32 else "") + ("_slab32" if args.slab32 else ""))
     roof["traffic"] = recorded_traffic(key)
+    if world > 1:
+        # N > 1: `achieved` is the SLOWEST rank's rate (its own bytes over its own kernel time); the reduce is apart
+        rates = []
+        for r in per_rank:
+            b = roof["algorithmic_bytes_per_launch"] * r["atoms"] / A if "algorithmic_bytes_per_launch" in roof else None
+            ms_r = r["whole_call_ms"] if composite else r["kernel_ms"]
+            rates.append({"rank": r["rank"], "atoms": r["atoms"], "kernel_ms": ms_r,
+                          "GBps": (b / (ms_r * 1e-3) / 1e9) if b else None, "reduce_us": r["reduce_us"]})
+        roof["per_rank"] = rates
+        if all(x["GBps"] for x in rates):
+            slow = min(rates, key=lambda x: x["GBps"])
+            roof.update({"achieved": slow["GBps"], "frac": slow["GBps"] / HBM_PEAK_GBPS, "kernel_ms": slow["kernel_ms"],
+                         "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"] * slow["atoms"] / A,
+                         "what": "slowest rank's dominant kernel, hipEvents on its launch stream; the all-reduce is `reduce_us`"})
+        roof["reduce_us_median_over_ranks"] = (statistics.median(r["reduce_us"] for r in per_rank)
+                                               if all(r["reduce_us"] is not None for r in per_rank) else None)
     if not args.no_kernel_split:
         try:
             roof["kernels"] = kernel_split(ctx, case, torch)
@@ -698,7 +797,7 @@ def main():
                                                         "NumPy twin oracle/synth.py), not SURVEY 8(d)'s Box-Muller normal",
             "library_sha16": so_sha16(),
             "rank_devices": rank_devices,
-            "collective": (dist.get_backend() if grouped else None),
+            "collective": collective,
         },
         "roofline": roof,
         "device_ms": {"whole_call_median": total_ms, "dominant_kernel_median": kernel_ms},
@@ -733,11 +832,25 @@ def main():
             out["host_path_by_particle"] = host_path_by_particle(local_rank, T, D)
         except Exception as e:
             out["host_path_by_particle"] = {"error": str(e)[:200]}
-    if world == 1 and not args.no_cpu_baseline and args.mode == "fft":
-        out["cpu_baseline"] = cpu_baseline(args, T, D, a_total * D)
-    print(json.dumps(out), flush=True)
-    if grouped:
-        dist.destroy_process_group()
+    if not args.no_cpu_baseline and args.mode == "fft":
+        # N > 1: the other ranks are done; a shorter sample (the run is N times the data already)
+        out["cpu_baseline"] = cpu_baseline(args, T, D, a_total * D, seconds=12.0 if world == 1 else 4.0)
+    if "other_configs" in out:
+        # LAST key of the line (a log that keeps only the tail of stdout still has every config's figures)
+        out["summary"] = [{"workload": "headline: " + workload, "ms": round(ms_per_step, 4), "frac": round(roof["frac"], 4),
+                           "bound": roof["bound"]}] + [
+            {"workload": c["workload"], "ms": round(c["ms_per_step"], 4), "frac": round(c["roofline"]["frac"], 4),
+             "bound": c["roofline"]["bound"]} if "error" not in c else {"workload": c["workload"], "error": c["error"][:80]}
+            for c in out["other_configs"]]
+    line = json.dumps(out)
+    print(line, flush=True)
+    if args.full_json:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.full_json)), exist_ok=True)
+            with open(args.full_json, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:
+            print(f"--full-json: {e}", file=sys.stderr)
 
 
 def other_configs(torch, dist, _lib, ctx, dev):
@@ -747,6 +860,8 @@ def other_configs(torch, dist, _lib, ctx, dev):
     res = []
     specs = [
         ("configs[1]: FFT VACF timeseries 1000 x 10000 x 3", "fft", 1000, 10000, False, False, False, 10, 3),
+        ("configs[2] one-eighth share, 10000 x 12500 x 3 (what each of 8 GPUs computes under --scaling strong; measured on "
+         "ONE GPU: a prediction of the per-GPU term of that curve, the all-reduce not included)", "fft", 10000, 12500, False, False, False, 10, 3),
         ("configs[2] shape with vacf_by_particle: FFT VACF 10000 x 100000 x 3", "fft", 10000, 100000, True, False, False, 3, 1),
         ("configs[3]: windowed (direct) VACF 5000 x 50000 x 3", "direct", 5000, 50000, False, False, False, 3, 1),
         ("configs[3] shape with vacf_by_particle (vector kernel): windowed VACF 5000 x 50000 x 3", "direct", 5000, 50000, True, False, False, 2, 1),

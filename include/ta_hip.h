@@ -188,8 +188,16 @@ int ta_helfand_msd_staged(ta_ctx *ctx, const double *d_masses, double scale, dou
  * straight into the column range [lo_i, hi_i) of the caller's ONE (n_frames, n_atoms) array.
  * The reduce: n_dev = 1 none (librccl is not loaded); n_dev > 1 on distinct devices ncclReduce in
  * one RCCL group call (librccl.so dlopen'ed on first use; communicators from ncclCommInitAll);
- * members that share a device, or no usable RCCL: peer copies to the first member + a sum in
- * member order.  ta_group_reduce_kind names what the last call used: "none" | "rccl" | "peer-copy".
+ * members that share a device, or RCCL failing: peer copies to the first member + a sum in
+ * member order.  ta_group_reduce_kind names what the last call used: "none" | "rccl" | "peer-copy";
+ * ta_group_reduce_note says why an automatic choice fell back from RCCL to peer copies ("" when it
+ * did not), ta_group_rccl_ranks how many ranks the communicator of the last RCCL reduce had
+ * (ncclCommCount).  ta_group_set_option keys of the group itself (every other key goes to the
+ * members' contexts, as ta_set_option):
+ *   "reduce_mode" 0|1|2 : 0 automatic (above; also $TA_AMD_GROUP_REDUCE=auto), 1 peer copies whatever
+ *                      the devices (=peer), 2 RCCL or an error (=rccl) -- with ONE member this runs
+ *                      ncclCommInitAll(1) + ncclReduce onto itself, the form of the RCCL branch a
+ *                      one-GPU box can execute;  "force_rccl" 1 = "reduce_mode" 2.
  * h_slabs of ta_group_stage_alloc: n_dev * n_slabs pointers, member i's slab s at [i * n_slabs + s]
  * (NULL for a member without atoms: more devices than atoms), each (n_frames, hi_i - lo_i, dim).
  * h_masses of ta_group_helfand_msd: all n_atoms.  Options go to every member.                */
@@ -201,6 +209,8 @@ int ta_group_size(const ta_group *g);
 int ta_group_member(ta_group *g, int i, ta_ctx **ctx, int *device);
 int ta_group_shard(const ta_group *g, int64_t n_atoms, int i, int64_t *atom_lo, int64_t *atom_hi);
 const char *ta_group_reduce_kind(const ta_group *g);
+const char *ta_group_reduce_note(const ta_group *g);
+int ta_group_rccl_ranks(const ta_group *g);
 int ta_group_set_option(ta_group *g, const char *key, int64_t value);
 int ta_group_stage_alloc(ta_group *g, int64_t n_frames, int64_t n_atoms, int dim, int dtype,
                          int n_slabs, void **h_slabs);

@@ -250,3 +250,23 @@ def test_group_entry_points_reject_bad_arguments():
     with pytest.raises(ValueError):
         _lib.Group([])
 
+
+
+def test_bench_bare_gpus_n_is_its_own_launcher():
+    """`python bench.py --gpus 2` with no launcher (the shape of the driver's command) starts its ranks
+    itself as a child `torch.distributed.run`; here, without a GPU, both ranks get as far as the GPU
+    check and the command fails with THEIR message and a non-zero status -- not with "launch me under
+    torchrun".  (The run to rc 0 is the -m gpu test test_bench_bare_gpus_2_starts_its_own_ranks.)"""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("the GPU twin of this test covers a box with a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0
+    assert "bench.py needs a GPU" in res.stderr and "torch.distributed.run" not in res.stdout
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

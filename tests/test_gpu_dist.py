@@ -170,6 +170,41 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(scaling):
     assert d["value"] == pytest.approx(2000 * total / (d["ms_per_step"] * 1e-3), rel=1e-9)
     assert d["roofline"]["frac"] > 0 and d["config"]["sharding"] == "atoms x2"
     assert len(d["config"]["rank_devices"]) == 2 and d["reduce_us"] > 0
+    assert d["config"]["collective"]["ranks"] == 2 and d["config"]["collective"]["backend"] == "gloo"
+    assert [r["rank"] for r in d["roofline"]["per_rank"]] == [0, 1] and d["cpu_baseline"]["value"] > 0
+
+
+def test_bench_bare_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the shape of the driver's N = 1 command): the
+    process starts `python -m torch.distributed.run` as a child before it touches a GPU, lets rank 0's
+    ONE JSON line through and exits with the child's status.  Rehearsed with both ranks on this box's
+    one GPU (TA_BENCH_ONE_GPU=1).  The line is complete: `roofline` (slowest rank's kernel, the reduce
+    apart), `cpu_baseline`, and the collective with the rank count it saw."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["TA_BENCH_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--frames", "2000", "--atoms", "3000", "--cpu-sample-atoms", "200"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["n_atoms_total"] == 6000 and d["scaling"] == "weak"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and len(r["per_rank"]) == 2
+    assert r["achieved"] == pytest.approx(min(x["GBps"] for x in r["per_rank"]))
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
+    c = d["config"]["collective"]
+    assert c["ranks"] == 2 and "bench.py started" in c["launcher"]
+    # a failing child is a failing command (here: more ranks asked for than --gpus says)
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "fft", "--float32"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0
 
 
 def test_bench_one_rank_under_rccl():
@@ -191,7 +226,8 @@ def test_bench_one_rank_under_rccl():
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, res.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["config"]["collective"] == "nccl" and len(d["config"]["rank_devices"]) == 1
+    assert d["config"]["collective"]["backend"] == "nccl" and d["config"]["collective"]["ranks"] == 1
+    assert len(d["config"]["rank_devices"]) == 1
     assert d["reduce_us"] > 0 and d["check"]["max_scale_rel_err_vs_torch_lags"] < 1e-10
 
 
@@ -250,6 +286,70 @@ def test_group_c_abi_one_gpu(tmp_path):
         assert scale_rel_err(z["ts" + k], z["ts_ref"]) < TOL
         assert scale_rel_err(z["bp" + k], z["bp_ref"]) < TOL
         assert scale_rel_err(z["d" + k], z["ts_ref"]) < TOL
+
+
+FORCED_RCCL_DRIVER = r"""
+import sys, numpy as np
+sys.path.insert(0, {repo!r})
+from transport_analysis_amd import _lib          # torch is NOT imported in this process
+rng = np.random.default_rng(5)
+T, A, D = 900, 37, 3
+v = rng.standard_normal((T, A, D))
+c = _lib.Context(0)
+(slab,) = c.stage_alloc(T, A, D, n_slabs=1, dtype=np.float64)
+slab[...] = v
+c.stage_commit(0, T)
+ts0, bp0 = c.vacf_fft(by_particle=True)
+d0, _ = c.vacf_direct(by_particle=False)
+f0, _ = c.vacf_fft(by_particle=False)
+g = _lib.Group([0])
+g.set_option("force_rccl", 1)
+(views,) = g.stage_alloc(T, A, D, n_slabs=1, dtype=np.float64)
+views[0][...] = v
+g.stage_commit(0, T)
+ts1, bp1 = g.vacf_fft(by_particle=True)
+kind, ranks = g.reduce_kind, g.rccl_ranks
+d1, _ = g.vacf_direct(by_particle=False)
+assert "librccl" in open("/proc/self/maps").read(), "the reduce must have loaded librccl"
+assert kind == "rccl" and g.reduce_kind == "rccl" and ranks == 1, (kind, ranks, g.reduce_note)
+assert np.array_equal(ts0, ts1) and np.array_equal(bp0, bp1) and np.array_equal(d0, d1), "sum over one member = that member"
+# back to the automatic choice: one member reduces nothing
+g.set_option("reduce_mode", 0)
+ts2, _ = g.vacf_fft(by_particle=False)
+assert g.reduce_kind == "none" and np.array_equal(ts2, f0)
+g.close()
+# members that share a device cannot form a communicator: RCCL-or-error must be the error
+h = _lib.Group([0, 0])
+h.set_option("reduce_mode", 2)
+(views,) = h.stage_alloc(T, A, D, n_slabs=1, dtype=np.float64)
+for view, (lo, hi) in zip(views, h.shards):
+    view[...] = v[:, lo:hi]
+h.stage_commit(0, T)
+try:
+    h.vacf_fft(by_particle=False)
+except _lib.TAError as e:
+    assert "rccl" in str(e)
+else:
+    raise AssertionError("reduce_mode 2 on a shared device must fail")
+h.set_option("reduce_mode", 1)
+ts3, _ = h.vacf_fft(by_particle=False)
+assert h.reduce_kind == "peer-copy" and np.max(np.abs(ts3 - f0)) <= 1e-12 * np.max(np.abs(f0))
+h.close()
+print("ok")
+"""
+
+
+def test_group_forced_rccl_one_member(tmp_path):
+    """The in-library RCCL branch EXECUTES: "force_rccl" on a one-member group runs ncclCommInitAll(1)
+    and ncclReduce through the dlopen'ed, header-typed entry points (group.hip) and leaves the member's
+    sums as they were -- bit-equal to the plain context -- with ta_group_reduce_kind == "rccl" and a
+    communicator of one rank.  (Several distinct devices: only the driver's multi-GPU node can run it.)"""
+    import subprocess
+    import sys
+
+    (tmp_path / "drv.py").write_text(FORCED_RCCL_DRIVER.format(repo=REPO))
+    r = subprocess.run([sys.executable, str(tmp_path / "drv.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("kind", ["fft", "direct", "helfand"])
@@ -313,3 +413,28 @@ def test_group_lag_sums_on_the_matrix_cores(kind):
     assert bp is None and g.reduce_kind == "peer-copy"
     assert scale_rel_err(ts, want_ts) < TOL
     g.close()
+
+
+def test_bench_single_process_line_is_complete():
+    """`bench.py --single-process` (the library's own fan-out and reduce, ta_group) prints the same shape
+    of line as every other mode: `roofline` from the members' own kernel events, `cpu_baseline`, and the
+    collective the library used.  Two members on this box's one GPU: the peer-copy reduce, by construction
+    (distinct devices must reduce by RCCL or the run fails: bench.py single_process)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--single-process", "--gpus", "2", "--devices", "0,0",
+           "--steps", "2", "--warmup", "1", "--frames", "2000", "--atoms", "3000", "--cpu-sample-atoms", "200"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    r = d["roofline"]
+    assert d["n_gpus"] == 2 and r["bound"] == "hbm" and 0 < r["frac"] < 1 and len(r["per_member"]) == 2
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9)
+    assert d["config"]["collective"]["kind"] == "peer-copy" and d["config"]["collective"]["members"] == 2
+    assert d["cpu_baseline"]["value"] > 0 and d["check"]["lag0_vs_numpy_block_mean_square"]

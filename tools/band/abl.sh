@@ -1,6 +1,6 @@
 #!/bin/bash
 # timing ablations of the Helfand form of k_band_lags (wrong results by construction): no re-centring
-# (ABL=1), no preparation at all (ABL=2), a new reference row every 8 / 16 steps (REF).  The variants are
+# (ABL=1), no preparation at all (ABL=2), a new reference row every 8 / 4 steps (REF).  The variants are
 # built here when missing (hipcc: ~1 min each; they travel to the GPU box once built).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R/tools/band

@@ -29,7 +29,7 @@ EXPORTS = (
     "ta_set_option",
     "ta_host_alloc", "ta_host_alloc_on", "ta_host_free",
     "ta_group_create", "ta_group_destroy", "ta_group_last_error", "ta_group_size", "ta_group_member",
-    "ta_group_shard", "ta_group_reduce_kind", "ta_group_set_option", "ta_group_stage_alloc",
+    "ta_group_shard", "ta_group_reduce_kind", "ta_group_reduce_note", "ta_group_rccl_ranks", "ta_group_set_option", "ta_group_stage_alloc",
     "ta_group_stage_commit", "ta_group_stage_free", "ta_group_stage_alloc_device", "ta_group_stage_synth", "ta_group_vacf_fft", "ta_group_vacf_direct",
     "ta_group_helfand_msd",
 )
@@ -137,6 +137,9 @@ def lib():
     L.ta_group_shard.argtypes = [vp, i64, ci, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.ta_group_reduce_kind.argtypes = [vp]
     L.ta_group_reduce_kind.restype = ctypes.c_char_p
+    L.ta_group_reduce_note.argtypes = [vp]
+    L.ta_group_reduce_note.restype = ctypes.c_char_p
+    L.ta_group_rccl_ranks.argtypes = [vp]
     L.ta_group_set_option.argtypes = [vp, ctypes.c_char_p, i64]
     L.ta_group_stage_alloc.argtypes = [vp, i64, i64, ci, ci, ci, ctypes.POINTER(vp)]
     L.ta_group_stage_commit.argtypes = [vp, i64, i64]
@@ -147,7 +150,7 @@ def lib():
     L.ta_group_vacf_direct.argtypes = [vp, vp, vp]
     L.ta_group_helfand_msd.argtypes = [vp, vp, dbl, vp, vp]
     for name in EXPORTS:
-        if name not in ("ta_last_error", "ta_group_last_error", "ta_group_reduce_kind"):
+        if name not in ("ta_last_error", "ta_group_last_error", "ta_group_reduce_kind", "ta_group_reduce_note"):
             getattr(L, name).restype = ci
     _lib = L
     return L
@@ -282,7 +285,8 @@ class Context:
     def close(self):
         if self._h:
             self._drop_views()
-            lib().ta_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):  # a group member's context belongs to its group
+                lib().ta_ctx_destroy(self._h)
             self._h = ctypes.c_void_p(None)
 
     def __del__(self):
@@ -496,6 +500,24 @@ class Group:
     @property
     def reduce_kind(self):
         return lib().ta_group_reduce_kind(self._h).decode()
+
+    @property
+    def reduce_note(self):
+        """why an automatic reduce fell back from RCCL to peer copies ("" when it did not)"""
+        return lib().ta_group_reduce_note(self._h).decode()
+
+    @property
+    def rccl_ranks(self):
+        """ranks of the communicator the last RCCL reduce ran on (ncclCommCount)"""
+        return int(lib().ta_group_rccl_ranks(self._h))
+
+    def member_context(self, i):
+        """Member i's context as a non-owning `Context` (timing history, options of one member)."""
+        h, dev = ctypes.c_void_p(), ctypes.c_int()
+        self._check(lib().ta_group_member(self._h, int(i), ctypes.byref(h), ctypes.byref(dev)))
+        c = Context.__new__(Context)
+        c._h, c.device, c._slabs, c._borrowed = h, dev.value, [], True
+        return c
 
     def shard(self, n_atoms, i):
         lo, hi = ctypes.c_int64(), ctypes.c_int64()

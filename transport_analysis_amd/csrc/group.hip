@@ -7,17 +7,25 @@
 //   n_dev > 1, distinct devices    ncclReduce(sum, float64, n_frames) in one RCCL group call, the
 //                                  communicators from ncclCommInitAll (one process, n devices);
 //                                  librccl.so is dlopen'ed on first use;
-//   otherwise (two members on one GPU -- what a one-GPU box can test -- or RCCL unavailable)
+//   otherwise (two members on one GPU -- what a one-GPU box can test -- or RCCL failing)
 //                                  the members' vectors are copied to member 0's device
 //                                  (hipMemcpyPeerAsync) and added there in member order.
+// "reduce_mode" (ta_group_set_option; $TA_AMD_GROUP_REDUCE = auto | peer | rccl) overrides the choice:
+// 1 = peer copies whatever the devices, 2 = RCCL or an error ("force_rccl" 1 is the same), which also
+// runs the collective for ONE member: the only form of this branch a one-GPU box can execute.
 // Replaces, for several GPUs at once, the same reference code as the single-context calls:
 // velocityautocorr.py:142-153,178-238, viscosity.py:111-142,167-233 (the atom mean at
 // velocityautocorr.py:214,237 / viscosity.py:233 is the reduce + one division).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen'ed (struct Rccl)
+
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ta_hip.h"
@@ -29,27 +37,34 @@ namespace {
 
 thread_local std::string g_group_tls_error;
 
-// the five RCCL entry points of the reduce, resolved from librccl.so when first needed
+// The RCCL entry points of the reduce, resolved from librccl.so when first needed (the library does
+// not link librccl: a one-GPU user never loads it).  <rccl/rccl.h> is included for its TYPES only: every
+// pointer below is declared as decltype(&ncclX), so a call through it is compiled against the
+// header's own prototype, and the static_asserts pin the prototypes this file was written against
+// (a header that reorders or retypes an argument fails the build instead of corrupting a call).
 struct Rccl {
     void* handle = nullptr;
-    int (*CommInitAll)(void**, int, const int*) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool load(std::string* why) {
         if (handle) return true;
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names)
             if ((handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
         if (!handle) {
-            *why = std::string("librccl.so not loadable: ") + (dlerror() ? dlerror() : "?");
+            const char* e = dlerror();
+            *why = std::string("librccl.so not loadable: ") + (e ? e : "?");
             return false;
         }
         auto sym = [&](const char* n) { return dlsym(handle, n); };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommCount = (decltype(CommCount))sym("ncclCommCount");
         Reduce = (decltype(Reduce))sym("ncclReduce");
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
@@ -62,9 +77,21 @@ struct Rccl {
         }
         return true;
     }
+    std::string what(ncclResult_t rc) const { return GetErrorString ? GetErrorString(rc) : "failed"; }
 };
 Rccl g_rccl;
-constexpr int kNcclFloat64 = 8, kNcclSum = 0;  // rccl.h: ncclFloat64 = 8, ncclSum = 0
+static_assert(std::is_same_v<decltype(&ncclCommInitAll), ncclResult_t (*)(ncclComm_t*, int, const int*)>);
+static_assert(std::is_same_v<decltype(&ncclCommDestroy), ncclResult_t (*)(ncclComm_t)>);
+static_assert(std::is_same_v<decltype(&ncclCommCount), ncclResult_t (*)(const ncclComm_t, int*)>);
+static_assert(std::is_same_v<decltype(&ncclReduce), ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t,
+                                                                     int, ncclComm_t, hipStream_t)>);
+static_assert(std::is_same_v<decltype(&ncclGroupStart), ncclResult_t (*)()>);
+static_assert(std::is_same_v<decltype(&ncclGroupEnd), ncclResult_t (*)()>);
+static_assert(std::is_same_v<decltype(&ncclGetErrorString), const char* (*)(ncclResult_t)>);
+static_assert(ncclFloat64 == 8 && ncclSum == 0 && ncclSuccess == 0);
+
+// how the members' lag sums are added: "reduce_mode" option, $TA_AMD_GROUP_REDUCE = auto | peer | rccl
+enum { RED_AUTO = 0, RED_PEER = 1, RED_RCCL = 2 };
 
 }  // namespace
 
@@ -75,9 +102,12 @@ struct ta_group {
     int64_t T = 0, A = 0;
     int D = 0, n_slabs = 0;
     bool distinct = true;          // all members on different devices
-    std::vector<void*> comms;      // RCCL communicators (distinct devices, n > 1), created on first reduce
+    std::vector<ncclComm_t> comms;  // RCCL communicators (distinct devices), created on first reduce
     bool rccl_tried = false;
+    int reduce_mode = RED_AUTO;     // "reduce_mode" option / $TA_AMD_GROUP_REDUCE
+    int rccl_ranks = 0;             // ncclCommCount of the communicator the last RCCL reduce ran on
     std::string reduce_kind = "none";
+    std::string reduce_note;        // why RED_AUTO fell back to peer copies (empty: it did not)
     std::string err;
     // on the reducing member's device: [n + 1][T] rows for the copy-and-add reduce; events to order the devices
     double* d_rows = nullptr;
@@ -112,41 +142,74 @@ void shard(int64_t A, int i, int n, int64_t* lo, int64_t* hi) {  // as transport
 
 // The (n_frames,) sums of the members `who` (d_tot[j] on member who[j]'s device, ready on that member's
 // stream) -> their sum on member who[0]'s device, in d_tot[0], ready on that member's stream.
+// RED_AUTO: RCCL when every member holds atoms on a device of its own (n > 1), peer copies when that
+// fails (reduce_note says why) or does not apply; RED_PEER: peer copies; RED_RCCL: RCCL or an error --
+// also for ONE member (ncclCommInitAll(1) + ncclReduce onto itself: what a one-GPU box can execute of
+// this branch, tests/test_gpu_dist.py::test_group_forced_rccl_one_member).
 int reduce_members(ta_group* g, const std::vector<int>& who, std::vector<double*>& d_tot) {
     const int n = (int)g->ctx.size(), m = (int)who.size();
     const int64_t T = g->T;
-    if (m <= 1) {
+    const int mode = g->reduce_mode;
+    if (m <= 1 && mode != RED_RCCL) {
         g->reduce_kind = "none";
         return TA_OK;
     }
-    // RCCL: every member takes part (communicators are made for all n devices at once)
-    if (m == n && g->distinct && !g->rccl_tried) {
+    const bool rccl_applies = m == n && g->distinct;
+    if (mode == RED_RCCL && !rccl_applies)
+        return gfail(g, TA_E_UNSUPPORTED, "reduce_mode rccl: every member needs atoms and a device of its own");
+    if (mode != RED_PEER && rccl_applies && !g->rccl_tried) {
         g->rccl_tried = true;
         std::string why;
         if (g_rccl.load(&why)) {
             g->comms.assign(n, nullptr);
-            const int rc = g_rccl.CommInitAll(g->comms.data(), n, g->devices.data());
-            if (rc != 0) {
+            const ncclResult_t rc = g_rccl.CommInitAll(g->comms.data(), n, g->devices.data());
+            if (rc != ncclSuccess) {
                 g->comms.clear();
-                g->err = std::string("ncclCommInitAll: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "failed");
+                why = "ncclCommInitAll: " + g_rccl.what(rc);
             }
-        } else {
-            g->err = why;
         }
+        g->reduce_note = why;
     }
-    if (m == n && !g->comms.empty()) {
-        // ONE collective: every member's vector is added into member 0's (in place on the root)
-        int rc = g_rccl.GroupStart();
-        for (int i = 0; i < n && rc == 0; ++i) {
-            TAG_TRY(g, hipSetDevice(g->devices[i]));
-            rc = g_rccl.Reduce(d_tot[i], d_tot[i], (size_t)T, kNcclFloat64, kNcclSum, 0, g->comms[i],
-                               ctx_stream(g->ctx[i]));
+    if (mode != RED_PEER && rccl_applies && !g->comms.empty()) {
+        // ONE collective: every member's vector is added into member 0's (in place on the root).  Nothing
+        // returns between ncclGroupStart and ncclGroupEnd: an open group on this thread would swallow
+        // every later RCCL call made from it (the caller's torch.distributed ones included).
+        ncclResult_t rc = g_rccl.GroupStart();
+        hipError_t he = hipSuccess;
+        if (rc == ncclSuccess) {
+            for (int i = 0; i < n && rc == ncclSuccess && he == hipSuccess; ++i) {
+                he = hipSetDevice(g->devices[i]);
+                if (he == hipSuccess)
+                    rc = g_rccl.Reduce(d_tot[i], d_tot[i], (size_t)T, ncclFloat64, ncclSum, 0, g->comms[i],
+                                       ctx_stream(g->ctx[i]));
+            }
+            const ncclResult_t rc2 = g_rccl.GroupEnd();
+            if (rc == ncclSuccess) rc = rc2;
         }
-        const int rc2 = g_rccl.GroupEnd();
-        if (rc != 0 || rc2 != 0)
-            return gfail(g, TA_E_HIP, std::string("ncclReduce: ") +
-                                          (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "failed"));
-        g->reduce_kind = "rccl";
+        if (rc == ncclSuccess && he == hipSuccess) {
+            int cnt = 0;
+            if (g_rccl.CommCount && g_rccl.CommCount(g->comms[0], &cnt) == ncclSuccess) g->rccl_ranks = cnt;
+            g->reduce_kind = "rccl";
+            return TA_OK;
+        }
+        const std::string why = he != hipSuccess ? std::string("hipSetDevice: ") + hipGetErrorString(he)
+                                                 : "ncclReduce: " + g_rccl.what(rc);
+        if (mode == RED_RCCL) return gfail(g, TA_E_HIP, why);
+        // RED_AUTO: the members' vectors are untouched by a collective that never launched; make sure of
+        // it (drain the streams), drop the communicators and add the vectors by peer copies instead
+        for (int i = 0; i < n; ++i) {
+            (void)hipSetDevice(g->devices[i]);
+            (void)hipStreamSynchronize(ctx_stream(g->ctx[i]));
+        }
+        for (ncclComm_t c : g->comms)
+            if (c) (void)g_rccl.CommDestroy(c);
+        g->comms.clear();
+        g->reduce_note = why;
+    } else if (mode == RED_RCCL) {
+        return gfail(g, TA_E_HIP, "reduce_mode rccl: " + (g->reduce_note.empty() ? std::string("no communicator") : g->reduce_note));
+    }
+    if (m <= 1) {
+        g->reduce_kind = "none";
         return TA_OK;
     }
     // copy-and-add on the first member's device, in member order (bitwise reproducible)
@@ -187,6 +250,12 @@ int reduce_members(ta_group* g, const std::vector<int>& who, std::vector<double*
     return TA_OK;
 }
 
+// everything queued so far on the members `who` has finished (their kernels and their copies into the
+// caller's host arrays): called before an error is returned, so that the caller may free those arrays
+void drain_members(ta_group* g, const std::vector<int>& who) {
+    for (int i : who) (void)host_wait(g->ctx[i]);
+}
+
 int group_compute(ta_group* g, int which, const double* h_masses, double scale, double* h_ts, double* h_bp) {
     if (!g) return gfail(nullptr, TA_E_INVALID, "null group");
     if (!h_ts) return gfail(g, TA_E_INVALID, "h_timeseries is NULL");
@@ -201,16 +270,32 @@ int group_compute(ta_group* g, int which, const double* h_masses, double scale, 
         double* d = nullptr;
         rc = host_launch(g->ctx[i], which, h_masses ? h_masses + g->lo[i] : nullptr, scale,
                          h_bp ? h_bp + g->lo[i] : nullptr, g->A, &d);
-        if (rc) return mfail(g, i, rc);
+        who.push_back(i);  // (a failed launch may have queued work already)
+        if (rc) {
+            rc = mfail(g, i, rc);
+            drain_members(g, who);  // earlier members' copies into h_bp are in flight: not after we return
+            return rc;
+        }
         d_tot.push_back(d);
-        who.push_back(i);
     }
-    if ((rc = reduce_members(g, who, d_tot))) return rc;
+    if ((rc = reduce_members(g, who, d_tot))) {
+        drain_members(g, who);
+        return rc;
+    }
     const int root = who[0];
-    TAG_TRY(g, hipSetDevice(g->devices[root]));
-    TAG_TRY(g, hipMemcpyAsync(h_ts, d_tot[0], sizeof(double) * g->T, hipMemcpyDeviceToHost, ctx_stream(g->ctx[root])));
-    for (int i : who)
-        if ((rc = host_wait(g->ctx[i]))) return mfail(g, i, rc);
+    hipError_t he = hipSetDevice(g->devices[root]);
+    if (he == hipSuccess)
+        he = hipMemcpyAsync(h_ts, d_tot[0], sizeof(double) * g->T, hipMemcpyDeviceToHost, ctx_stream(g->ctx[root]));
+    if (he != hipSuccess) {
+        drain_members(g, who);
+        return gfail(g, TA_E_HIP, std::string("timeseries copy: ") + hipGetErrorString(he));
+    }
+    rc = TA_OK;
+    for (int i : who) {  // every member is waited for, whatever an earlier one reports
+        const int r = host_wait(g->ctx[i]);
+        if (r && !rc) rc = mfail(g, i, r);
+    }
+    if (rc) return rc;
     const double n_at = (double)g->A;  // mean over ALL atoms (velocityautocorr.py:214,237; viscosity.py:233)
     for (int64_t k = 0; k < g->T; ++k) h_ts[k] /= n_at;
     return TA_OK;
@@ -241,6 +326,14 @@ int ta_group_create(const int* device_ids, int n_dev, ta_group** out) {
     }
     g->lo.assign(n_dev, 0);
     g->hi.assign(n_dev, 0);
+    if (const char* e = getenv("TA_AMD_GROUP_REDUCE")) {
+        if (!strcmp(e, "peer")) g->reduce_mode = RED_PEER;
+        else if (!strcmp(e, "rccl")) g->reduce_mode = RED_RCCL;
+        else if (strcmp(e, "auto") && *e) {
+            ta_group_destroy(g);
+            return gfail(nullptr, TA_E_INVALID, "TA_AMD_GROUP_REDUCE must be auto, peer or rccl");
+        }
+    }
     // peer access for the copy-and-add reduce (harmless when RCCL does the reduce; errors ignored:
     // hipMemcpyPeerAsync works without it, through the host)
     for (int i = 1; i < n_dev; ++i)
@@ -294,8 +387,19 @@ int ta_group_shard(const ta_group* g, int64_t n_atoms, int i, int64_t* atom_lo, 
 
 const char* ta_group_reduce_kind(const ta_group* g) { return g ? g->reduce_kind.c_str() : ""; }
 
+const char* ta_group_reduce_note(const ta_group* g) { return g ? g->reduce_note.c_str() : ""; }
+
+int ta_group_rccl_ranks(const ta_group* g) { return g ? g->rccl_ranks : 0; }
+
 int ta_group_set_option(ta_group* g, const char* key, int64_t value) {
-    if (!g) return gfail(nullptr, TA_E_INVALID, "null group");
+    if (!g || !key) return gfail(g, TA_E_INVALID, "null argument");
+    // the group's own options; every other key goes to the members' contexts
+    if (!strcmp(key, "reduce_mode") || !strcmp(key, "force_rccl")) {
+        const int mode = !strcmp(key, "force_rccl") ? (value ? RED_RCCL : RED_AUTO) : (int)value;
+        if (mode < RED_AUTO || mode > RED_RCCL) return gfail(g, TA_E_INVALID, "reduce_mode: 0 auto, 1 peer copies, 2 RCCL");
+        g->reduce_mode = mode;
+        return TA_OK;
+    }
     for (size_t i = 0; i < g->ctx.size(); ++i) {
         const int rc = ta_set_option(g->ctx[i], key, value);
         if (rc) return mfail(g, (int)i, rc);
