@@ -1,0 +1,329 @@
+// band32_kernels.hpp — Einstein-Helfand lag SUMS on the FP32 matrix cores (gfx950 v_mfma_f32_16x16x4_f32):
+// BASELINE configs[4]'s "float32 path" without the by-particle array.
+//
+// Quantity: ViscosityHelfand._conclude summed over particles
+// (/root/reference/transport_analysis/viscosity.py:201-233): for every lag k
+//   S[k] = sum_{columns c} sum_{i < T-k} (P[i, c] - P[i+k, c])^2,  P = (m v) x rounded ONCE to float32
+// (what the float32 vector kernel, direct_kernels.hpp, rounds too: the "direct_f32" contract is float32
+// values and products, float64 accumulation, 2e-6 of the series' scale).
+//
+// Structure: band_kernels.hpp's Helfand form (read that file's comments first) — blocks of 16 frames, a
+// wave owns 16 block lags and a range of blocks, rows centred on a frame close to the A block so that
+// (a - b)^2 = a^2 + b^2 - 2 a b has no cancellation, the squared norms carried by the fourth 16-lane group —
+// with these differences:
+//   * the product slab is float32 (8-byte rows: half the bytes the float64 form pulls through the fabric
+//     at the same number of requests per MFMA), centring, norms and fragments are float32;
+//   * the MFMA is v_mfma_f32_16x16x4_f32: 2048 flop in 32 cycles per SIMD, twice the FP64 form's rate, and
+//     its result rows are m = 4 (lane >> 4) + r (the FP64 form: (lane >> 4) + 4 r);
+//   * float32 accumulators hold at most kFlush steps (128 products each) and are then added into
+//     float64 accumulators in registers: the vector path's own discipline (float32 block sums, float64
+//     accumulation) — sums over 10^6 terms in float32 would lose five digits;
+//   * a step of 1024 MFMA cycles is shorter than a memory round trip, so rows are requested PF steps ahead —
+//     not into registers but into a per-wave LDS ring, by LDS-DMA (buffer_load_dwordx4 ... lds): one request
+//     per step brings the A block and the window's new block (32 lanes x two 8-byte rows each), no register
+//     is the target of a load in flight (the float64 form's inline-assembly loads rely on the compiler not
+//     copying such a register; under this kernel's register pressure it does), and the fragments are read
+//     from the ring one step ahead with ordinary LDS loads the compiler schedules and waits for itself.
+#pragma once
+#include "band_kernels.hpp"
+
+namespace ta {
+
+typedef float band_f2 __attribute__((ext_vector_type(2)));
+typedef float band_f4 __attribute__((ext_vector_type(4)));
+
+// One sextet of columns = 3 adjacent column pairs of the pair-major FLOAT32 slab (8-byte rows) behind one
+// buffer resource.  A request is ONE LDS-DMA instruction: lane L < 32 fetches rows 2 (L & 7), + 1 of block
+// `lo` of pair L >> 3, lane L >= 32 the same rows of block `hi` of pair (L - 32) >> 3, 16 bytes each, landing
+// at ring slot + 16 L: the slot is [2 blocks][4 lane groups][16 frames] of 8-byte rows, i.e. fragment lane
+// l of the A block at [l], of the window's new block at [64 + l].  The fourth lane group (L & 24 == 24: the
+// norm slot) and everything past the resource (pairs that do not exist) fetch out of range: zeros.  Rows
+// past the end of the series inside the resource are NOT zeros (pad rows, the next pair's rows): the
+// consumers mask by frame number wherever a block is not entirely inside the series.
+struct BandSrc32 {
+    band_u4 rs;          // raw buffer resource for the LDS-DMA (inline assembly)
+    __amdgpu_buffer_rsrc_t crs;  // the same for compiler-visible loads (the visit's first 15 fragments)
+    unsigned dma_off;    // this lane's byte offset for block 0 of its half (out of range in the fourth lane group)
+    unsigned dma_hi;     // 128 in lanes >= 32, else 0: block `hi` = `lo` + delta
+    unsigned lane_off;   // (kk pitch + i) * 8 of the fragment lane, out of range in the fourth lane group
+    int T, i;
+    bool slot;
+    // "s_nop 4": an SGPR of the resource restored by v_readlane just before (hazard recogniser does not look
+    // inside inline assembly; tools/check_isa.py verifies the nop is there); s_nop 0: M0 write -> LDS-DMA
+    __device__ __forceinline__ void dma(unsigned lds_addr, unsigned voff) const {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs)
+                     : "memory", "m0");
+    }
+    __device__ __forceinline__ band_f2 load_now(int b) const {  // compiler-visible, waited for at its use
+        return __builtin_bit_cast(band_f2, __builtin_amdgcn_raw_buffer_load_b64(crs, lane_off + (unsigned)b * 128u, 0, 0));
+    }
+};
+#define TA_BAND32_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define TA_BAND32_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+
+// s0 + s1 + s2 + s3 of the four 16-lane rows, in every row: two register swaps (lane bit 5, lane bit 4).
+// Inline assembly because hipcc 7.2 (clang 22) mis-selects the SECOND result of
+// __builtin_amdgcn_permlane{32,16}_swap when it is used as a 32-bit scalar ("x.x + x.y" becomes
+// v_add_f32 v1, v1, v1; tools/band/dma_probe.hip has the three-line reproducer) — the 64-bit use in
+// band_kernels.hpp is compiled correctly.  "s_nop 1": the swap reads VGPRs a VALU instruction may have just
+// written (the compiler pads its own swaps the same way; it does not look inside inline assembly).
+__device__ __forceinline__ float band32_sum_rows(float s) {
+    float a = s, b = s;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a += b;  // s[l] + s[l ^ 32]
+    b = a;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;  // ... + the same of lane l ^ 16
+}
+
+struct BandHelf32 {
+    int T, i;
+    bool slot;
+    float slot_one;  // 1 in the fourth lane group, 0 elsewhere
+    // The reference row carries (-1, 0) in the fourth lane group, whose rows read as zeros: "row - r" puts
+    // (1, 0) there = the A operand's (valid, -nA/2 = 0) of a step without invalid pairs.  The squared norm
+    // starts from -slot_one, so that exact 1 never enters the sum over the lane groups (a norm of 1e-12
+    // beside it would lose its digits: the result must not depend on the unit of P).
+    __device__ __forceinline__ band_f2 first_row(band_f2 raw) const {
+        const int src_lane = (int)(threadIdx.x & 48);
+        band_f2 r = band_f2{__shfl(raw.x, src_lane), __shfl(raw.y, src_lane)};
+        if (slot) r = band_f2{-1.0f, 0.0f};
+        return r;
+    }
+    __device__ __forceinline__ float norm2(band_f2 c) const {  // columns: |c|^2; fourth group with c = (1, 0): exactly 0
+        return __builtin_fmaf(c.y, c.y, __builtin_fmaf(c.x, c.x, -slot_one));
+    }
+    // B operand of block b from rows that are centred already (rows - r, or old + delta).
+    // one_in_slot: the fourth group holds exactly (1, 0) (rows - r); inside: block b lies inside the series
+    template <bool one_in_slot, bool inside>
+    __device__ __forceinline__ band_f2 finish_b(band_f2 c, int b) const {
+        if constexpr (inside) {
+            const float n = -0.5f * band32_sum_rows(one_in_slot ? norm2(c) : (slot ? 0.0f : c.x * c.x + c.y * c.y));
+            if (slot) c = band_f2{n, 1.0f};
+        } else {
+            const bool valid = 16 * b + i < T;
+            if (!valid) c = band_f2{0.0f, 0.0f};
+            const float n = -0.5f * band32_sum_rows(slot ? 0.0f : c.x * c.x + c.y * c.y);
+            if (slot) c = band_f2{n, valid ? 1.0f : 0.0f};
+        }
+        return c;
+    }
+    // A operand of a step whose window reaches the end of the series: (valid, -nA/2) through the product
+    __device__ __forceinline__ band_f2 prep_a_edge(band_f2 raw, band_f2 r, int b) const {
+        const bool valid = 16 * b + i < T;
+        band_f2 c = raw - r;
+        if (!valid) c = band_f2{0.0f, 0.0f};
+        const float n = -0.5f * band32_sum_rows(slot ? 0.0f : c.x * c.x + c.y * c.y);
+        if (slot) c = band_f2{valid ? 1.0f : 0.0f, n};
+        return c;
+    }
+    // ... and of every other step: its rows' norms would add the same -nA[m]/2 to all 16 accumulators, so they
+    // are summed per lane (fourth group: exactly 0) and subtracted once in the epilogue
+    __device__ __forceinline__ band_f2 prep_a_bulk(band_f2 raw, band_f2 r, float& na) const {
+        const band_f2 c = raw - r;
+        na += norm2(c);
+        return c;
+    }
+};
+
+constexpr int kBand32Flush = 16;  // steps a float32 accumulator holds before it is added into float64
+
+// one piece on one sextet.  ring: this wave's LDS ring, NS slots of 128 rows (1 KiB); the request of step x
+// (A block x, window block x + d0 + 15) is issued PF steps ahead into slot (x - i0) % NS and read into
+// registers one step ahead.
+// The float32 accumulators are added into `sum` every 16 steps (a pass of the unrolled ring) and at the end
+// of the visit, and never zeroed: the first MFMAs of every pass take the constant 0 as their C operand.
+template <int PF, int NS>
+__device__ __forceinline__ void band32_visit(const BandSrc32& src, band_f2* ring, int d0, int i0, int i1, band_f4 (&acc)[16],
+                                             band_d4 (&sum)[16], double& na) {
+    static_assert(16 % NS == 0 && NS >= 2 * PF && PF >= 1, "slots are indexed by the unrolled step; a slot is rewritten PF steps after it was read");
+    static_assert(kBand32Flush == 16, "one flush per pass of the ring");
+    const BandHelf32 h{src.T, src.i, src.slot, src.slot ? 1.0f : 0.0f};
+    const int lane = (int)(threadIdx.x & 63);
+    // LDS byte address of the ring (low half of the flat address; the same in every lane of the wave)
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)ring);
+    const unsigned voff0 = src.dma_off + src.dma_hi * (unsigned)(d0 + 15);
+    band_f2 W[16], r;
+    float na32 = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 15; ++d) W[d] = src.load_now(i0 + d0 + d);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) src.dma(ring_addr + 1024u * (s % NS), voff0 + 128u * (unsigned)(i0 + s));
+    TA_BAND32_WAIT(PF - 1);
+    band_f2 anext = ring[lane], wnext = ring[64 + lane];
+    r = h.first_row(anext);
+    if (16 * (i0 + d0 + 15) <= src.T) {  // the 15 blocks lie inside the series
+#pragma unroll
+        for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<true, true>(W[d] - r, 0);
+    } else {
+#pragma unroll
+        for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<true, false>(W[d] - r, i0 + d0 + d);
+    }
+    auto flush = [&]() {  // four values at a time (the accumulators live in AGPRs)
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sum[d][q] += (double)acc[d][q];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        na += (double)na32;
+        na32 = 0.0f;
+    };
+    const band_f4 zero4 = band_f4{0.0f, 0.0f, 0.0f, 0.0f};
+    int I = i0;
+    for (bool more = true; more;) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const band_f2 araw = anext, wraw = wnext;
+            src.dma(ring_addr + 1024u * ((j + PF) % NS), voff0 + 128u * (unsigned)(I + PF));
+            TA_BAND32_WAIT(PF - 1);  // the request of step I + 1 has landed
+            anext = ring[128 * ((j + 1) % NS) + lane];
+            wnext = ring[128 * ((j + 1) % NS) + 64 + lane];
+            if (j == 0 && I != i0) {  // a new pass: flush, and a new reference row that the 15 older window fragments follow
+                flush();
+                const band_f2 rn = h.first_row(araw);
+                const band_f2 delta = r - rn;
+                r = rn;
+                if (16 * (I + d0 + 15) <= src.T) {
+#pragma unroll
+                    for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<false, true>(W[d] + delta, 0);
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<false, false>(W[d] + delta, I + d0 + d);
+                }
+            }
+            band_f2 A;
+            if (16 * (I + d0 + 16) <= src.T) {  // this step's whole window inside the series
+                A = h.prep_a_bulk(araw, r, na32);
+                W[(j + 15) & 15] = h.template finish_b<true, true>(wraw - r, 0);
+            } else {
+                A = h.prep_a_edge(araw, r, I);
+                W[(j + 15) & 15] = h.template finish_b<true, false>(wraw - r, I + d0 + 15);
+            }
+#pragma unroll
+            for (int d = 0; d < 16; ++d) acc[d] = TA_BAND32_MFMA(A.x, W[(j + d) & 15].x, j == 0 ? zero4 : acc[d]);
+#pragma unroll
+            for (int d = 0; d < 16; ++d) acc[d] = TA_BAND32_MFMA(A.y, W[(j + d) & 15].y, acc[d]);
+            if (++I == i1) {  // (one common tail: sixteen copies of the flush would be most of the kernel's code)
+                more = false;
+                break;
+            }
+        }
+    }
+    TA_BAND32_WAIT(0);  // the requests past the piece: the ring is reused by the next visit
+    flush();
+}
+
+// pm: pair-major FLOAT32 product slab (8-byte rows).  grid: n_labels * (slots / NW) workgroups of 64 NW threads.
+// Results: partial[label][piece][272] = -1/2 the squared differences (k_band_gather applies -2 factor).
+template <int NW, int PF, int NS>
+__global__ void __launch_bounds__(64 * NW)
+    k_band32_lags(const float* __restrict__ pm, long pitch, int T, long n_pairs, int n_labels, int n_ph,
+                  const BandPiece* __restrict__ pieces, int n_pieces, const int* __restrict__ slot_begin,
+                  const int* __restrict__ slot_pieces, double* __restrict__ partial) {
+    __shared__ double red[NW][272 + 16 * 32];
+    __shared__ band_f2 rings[NW][NS * 128];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int label = blockIdx.x % n_labels;
+    const int slot = (blockIdx.x / n_labels) * NW + wave;
+    const long n_sext = (n_pairs + 2) / 3;
+    const int kk = lane >> 4;
+    double* blk = red[wave];
+    double* dsum = blk + 272;
+    const int pb = __builtin_amdgcn_readfirstlane(slot_begin[slot]), pe = __builtin_amdgcn_readfirstlane(slot_begin[slot + 1]);
+    for (int pi = pb; pi < pe; ++pi) {
+        const int idx = __builtin_amdgcn_readfirstlane(slot_pieces[pi]);
+        const BandPiece pc = pieces[idx];
+        const int d0 = __builtin_amdgcn_readfirstlane(pc.d0), i0 = __builtin_amdgcn_readfirstlane(pc.i0),
+                  i1 = __builtin_amdgcn_readfirstlane(pc.i1), phase = __builtin_amdgcn_readfirstlane(pc.phase);
+        band_f4 acc[16];
+        band_d4 sum[16];
+        double na = 0.0;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc[d] = band_f4{0.0f, 0.0f, 0.0f, 0.0f}, sum[d] = band_d4{0.0, 0.0, 0.0, 0.0};
+        for (long o = label + (long)n_labels * phase; o < n_sext; o += (long)n_labels * n_ph) {
+            const long left = n_pairs - 3 * o;  // pairs of this sextet that exist
+            BandSrc32 src;
+            const unsigned long long base = reinterpret_cast<unsigned long long>(pm + 3 * o * pitch * 2);
+            const unsigned n_bytes = (unsigned)((left < 3 ? left : 3) * pitch) * 8u;
+            src.rs = band_u4{(unsigned)base, (unsigned)(base >> 32) & 0xffffu, n_bytes, 0x00020000u};
+            src.crs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pm + 3 * o * pitch * 2), 0, (int)n_bytes, 0x00020000);
+            const int dk = (lane >> 3) & 3;  // the DMA lane's pair (3: the norm slot's zeros)
+            src.dma_off = dk == 3 ? 0x80000000u : (unsigned)(dk * pitch + 2 * (lane & 7)) * 8u;
+            src.dma_hi = lane >= 32 ? 128u : 0u;
+            src.lane_off = kk == 3 ? 0x80000000u : (unsigned)(kk * pitch + (lane & 15)) * 8u;
+            src.T = T;
+            src.i = lane & 15;
+            src.slot = kk == 3;
+            band32_visit<PF, NS>(src, rings[wave], d0, i0, i1, acc, sum, na);
+        }
+        // diagonals: sum[d][r] of lane l is C_d[m = 4 (l >> 4) + r][n = l & 15], lag 16 (d0 + d) + n - m
+        double na_m[4];
+        {  // nA[m] / 2 of the lane's four rows, through the LDS
+            const double t0 = band_sum_rows(na);  // (fourth group: exactly 0)
+            if (lane < 16) dsum[lane] = 0.5 * t0;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) na_m[r] = dsum[4 * (lane >> 4) + r];
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) blk[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = sum[d][r] - na_m[r];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 31) {
+                const int e = lane - 15;
+                const int m_lo = e < 0 ? -e : 0, m_hi = e > 0 ? 16 - e : 16;
+                double s = 0.0;
+                for (int m = m_lo; m < m_hi; ++m) s += blk[m * 17 + m + e];
+                dsum[d * 32 + lane] = s;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        double* out = partial + ((long)label * n_pieces + idx) * kBandPartial;
+        for (int q = lane; q < kBandPartial; q += 64) {
+            const int off = q - 15;
+            const int d = off >= 0 ? off >> 4 : -1, e = off - 16 * d;
+            double s = 0.0;
+            if (off <= 255) {
+                if (d >= 0) s = dsum[d * 32 + e + 15];
+                if (e >= 1 && d + 1 <= 15) s += dsum[(d + 1) * 32 + e - 16 + 15];
+            }
+            out[q] = s;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// P = (m v) x per column, the reference's evaluation order (viscosity.py:212-219), formed in float64 and
+// rounded once to float32; pair-major slabs in (float64 16-byte rows or float32 8-byte rows), pair-major
+// float32 out.  A thread takes two consecutive rows of a pair: 16-byte stores.
+template <typename SRC>
+__global__ void __launch_bounds__(256)
+    k_helfand_product32(const SRC* __restrict__ vel, const SRC* __restrict__ pos, const double* __restrict__ masses, long pitch,
+                        long T, long n_cols, int D, float* __restrict__ P) {
+    typedef SRC src4 __attribute__((ext_vector_type(4)));
+    const long n_pairs = (n_cols + 1) / 2, half = pitch / 2;  // pitch is a multiple of 8
+    for (long pair = blockIdx.y; pair < n_pairs; pair += gridDim.y) {
+        const long c = 2 * pair;
+        const double m0 = masses[c / D];
+        const bool two = c + 1 < n_cols;
+        const double m1 = two ? masses[(c + 1) / D] : 0.0;
+        const src4* v = reinterpret_cast<const src4*>(vel) + pair * half;
+        const src4* x = reinterpret_cast<const src4*>(pos) + pair * half;
+        band_f4* p = reinterpret_cast<band_f4*>(P) + pair * half;
+        for (long q = (long)blockIdx.x * 256 + threadIdx.x; 2 * q < T; q += (long)gridDim.x * 256) {
+            const src4 vv = v[q], xx = x[q];
+            band_f4 out;
+            out.x = (float)((m0 * (double)vv.x) * (double)xx.x);
+            out.y = two ? (float)((m1 * (double)vv.y) * (double)xx.y) : 0.0f;
+            out.z = (float)((m0 * (double)vv.z) * (double)xx.z);
+            out.w = two ? (float)((m1 * (double)vv.w) * (double)xx.w) : 0.0f;
+            if (2 * q + 1 >= T) out.z = out.w = 0.0f;
+            p[q] = out;
+        }
+    }
+}
+
+}  // namespace ta
