@@ -60,6 +60,7 @@ HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # vector FP64
 FP32_PEAK_TFLOPS = 157.3
 FP64_MFMA_PEAK_TFLOPS = 78.6  # matrix FP64 (v_mfma_f64_16x16x4_f64: 32 flop / clock / SIMD, as the vector pipe)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # matrix FP32 (v_mfma_f32_16x16x4_f32: 64 flop / clock / SIMD; 155 measured, MI355X guide)
 SEED = 20250824
 
 
@@ -312,13 +313,15 @@ class Case:
                                         self.stream)
 
     def on_matrix_cores(self):
-        """lag sums alone of the O(T^2) correlators (float64): FP64 MFMA band kernel (band_kernels.hpp)"""
-        return (self.mode in ("direct", "helfand") and self.bp is None and not self.float32
-                and not (self.mode == "helfand" and self.helfand_fft))
+        """lag sums alone of the O(T^2) correlators: FP64 MFMA band kernel (band_kernels.hpp); the float32 option's
+        Helfand lag sums: FP32 MFMA (band32_kernels.hpp)"""
+        if self.bp is not None or (self.mode == "helfand" and self.helfand_fft):
+            return False
+        return self.mode == "helfand" or (self.mode == "direct" and not self.float32)
 
     def kernel_name(self):
         if self.on_matrix_cores():
-            return "k_band_lags"
+            return "k_band32_lags" if self.float32 else "k_band_lags"
         if self.mode != "fft" and not (self.mode == "helfand" and self.helfand_fft):
             return "k_direct"
         if self.T > 163840:
@@ -389,9 +392,11 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
     tf = fl / (kernel_ms * 1e-3) / 1e12
     if case.on_matrix_cores():
         # v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s dense at 2.4 GHz (77.3 measured back to back,
-        # profiles/r04_mfma_f64_ubench.txt); the flop counted are the useful ones (T(T+1)/2 lag products per column)
-        out = {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-               "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "k_band_lags", "kernel_ms": kernel_ms,
+        # profiles/r04_mfma_f64_ubench.txt); v_mfma_f32_16x16x4_f32: 157.3.  The flop counted for the windowed
+        # VACF are the useful ones (T(T+1)/2 lag products per column)
+        mpeak = FP32_MFMA_PEAK_TFLOPS if float32 else FP64_MFMA_PEAK_TFLOPS
+        out = {"bound": "mfma", "achieved": tf, "peak": mpeak, "unit": "TFLOP/s",
+               "frac": tf / mpeak, "traffic": None, "kernel": case.kernel_name(), "kernel_ms": kernel_ms,
                "algorithmic_flops_per_launch": fl, "hbm_GBps_for_reference": gbps}
         if case.mode == "helfand":
             # `achieved` / `frac` = what the matrix pipe ISSUES: 2 flop per term on 6 of its 8 column slots (the
@@ -399,9 +404,9 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
             # 3 flop per term; what the vector kernel's line counts) is `reference_flops_*`:
             # a larger number that says nothing about the pipe
             issued = 2.0 * (8.0 / 6.0) * D * A * T * (T - 1) / 2 / (kernel_ms * 1e-3) / 1e12
-            out.update({"achieved": issued, "frac": issued / FP64_MFMA_PEAK_TFLOPS,
+            out.update({"achieved": issued, "frac": issued / mpeak,
                         "issued_flops_per_launch": 2.0 * (8.0 / 6.0) * D * A * T * (T - 1) / 2,
-                        "reference_flops_tflops": tf, "reference_flops_frac": tf / FP64_MFMA_PEAK_TFLOPS})
+                        "reference_flops_tflops": tf, "reference_flops_frac": tf / mpeak})
         return out
     return {"bound": "valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
             "traffic": None, "kernel": "k_direct", "kernel_ms": kernel_ms,
@@ -866,7 +871,7 @@ def other_configs(torch, dist, _lib, ctx, dev):
         ("configs[3]: windowed (direct) VACF 5000 x 50000 x 3", "direct", 5000, 50000, False, False, False, 3, 1),
         ("configs[3] shape with vacf_by_particle (vector kernel): windowed VACF 5000 x 50000 x 3", "direct", 5000, 50000, True, False, False, 2, 1),
         ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float64 (matrix cores)", "helfand", 20000, 25000, False, False, False, 2, 1),
-        ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float32 path", "helfand", 20000, 25000, False, True, False, 2, 1),
+        ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float32 path (FP32 matrix cores)", "helfand", 20000, 25000, False, True, False, 2, 1),
         ("configs[4] per-GPU share, helfand_fft option (float64): 20000 x 25000 x 3", "helfand", 20000, 25000, False, False, True, 3, 1),
         ("long trajectory: FFT VACF timeseries 20000 x 25000 x 3", "fft", 20000, 25000, False, False, False, 5, 1),
         ("long trajectory with vacf_by_particle: FFT VACF 20000 x 25000 x 3", "fft", 20000, 25000, True, False, False, 3, 1),

@@ -222,6 +222,92 @@ def test_helfand_matrix_cores_on_a_pure_trend(ctx):
     assert rel.max() < 1e-10, (rel.argmax() + 1, rel.max())
 
 
+@pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 2, 3), (15, 3, 1), (16, 5, 3), (17, 2, 2), (241, 3, 3), (256, 3, 3),
+                                   (257, 9, 1), (272, 4, 3), (273, 5, 2), (513, 11, 3), (1000, 37, 3), (2049, 8, 3),
+                                   (4100, 3, 3), (5000, 7, 3), (300, 2001, 1)])
+def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D):
+    """BASELINE configs[4]'s float32 path without the by-particle array: k_band32_lags (v_mfma_f32_16x16x4_f32,
+    band32_kernels.hpp) on the float32 product slab — rows fetched by LDS-DMA, float32 accumulators flushed
+    into float64 — against the oracle (viscosity.py:201-233) at the float32 path's bar, 2e-6 of the series'
+    scale, on the shapes of the float64 form's test: both sides of the 16-frame blocks and the 256-lag
+    groups, ragged column counts (sextets with one and two pairs, an unpaired last column), P far from
+    zero-mean.  Same bits every launch; and the float32 vector kernel ("direct_mfma" 0) agrees."""
+    from oracle import numpy_oracle as orc
+
+    v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=2700 + T)
+    x = x + 50.0 + 0.01 * np.arange(T)[:, None, None]
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+    want_ts = orc.helfand(v, x, m, vol, 300.0)[1]
+    ctx.set_option("direct_f32", 1)
+    ctx.set_option("timeline", 1)
+    try:
+        ts_m, _ = run_helfand(ctx, v, x, m, scale, False)
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_lags"]
+        ts_again, _ = ctx.helfand_msd(m, scale, by_particle=False)
+        assert np.array_equal(ts_m, ts_again)  # fixed summation order
+        ctx.set_option("direct_mfma", 0)
+        ts_v, _ = ctx.helfand_msd(m, scale, by_particle=False)
+        assert "k_direct" in [n for n, _ in ctx.kernel_timeline()]
+    finally:
+        ctx.set_option("direct_mfma", 1)
+        ctx.set_option("direct_f32", 0)
+        ctx.set_option("timeline", 0)
+    assert ts_m[0] == 0.0
+    assert scale_rel_err(ts_m, want_ts) < TOL_F32
+    assert scale_rel_err(ts_m, ts_v) < TOL_F32
+    if T > 16:
+        assert scale_rel_err(ts_m, want_ts) > 0.0  # really float32 arithmetic
+
+
+def test_helfand_float32_matrix_cores_trend_units_and_float32_slabs(ctx):
+    """Three properties of the float32 matrix-core Helfand path.  (a) The pure cubic trend (v = t, x = t^2 / 2:
+    P grows by nine orders of magnitude): every lag within 2e-6 of the SCALE of the float64 difference-first
+    result — lag by lag the float32 rounding of P itself (6e-8 |P|) dominates the short lags, for the vector
+    float32 kernel too, which is why the float32 bar is a scale-relative one.  (b) The result does not depend
+    on the unit of P: inputs scaled by 1e-6 and 1e+5 give results scaled by the square of the product, to
+    the same 2e-6 (the norm slot's exact 1 never meets a norm in a sum).  (c) float32 device slabs
+    ("stage_device_f32") feed the product kernel as they are: same bits as float64 slabs of the same
+    float32-representable values."""
+    from oracle import numpy_oracle as orc
+
+    T = 3000
+    v, x = step(T)
+    m = np.array([1.0, 2.0])
+    v = np.repeat(v[:, :1], 2, axis=1) * np.array([1.0, 0.5])[None, :, None]
+    x = np.repeat(x[:, :1], 2, axis=1)
+    ts64, _ = run_helfand(ctx, v, x, m, 1.0, False)
+    ctx.set_option("direct_f32", 1)
+    try:
+        ts32, _ = run_helfand(ctx, v, x, m, 1.0, False)
+        assert scale_rel_err(ts32, ts64) < TOL_F32
+        # (b) units
+        T2, A2 = 700, 13
+        v2, x2, m2, vol = orc.synthetic_helfand(T2, A2, 3, seed=99)
+        base, _ = run_helfand(ctx, v2, x2, m2, 1.0, False)
+        for sv, sx in ((1e-6, 1.0), (1e5, 1e5), (1e-4, 1e-4)):
+            got, _ = run_helfand(ctx, v2 * sv, x2 * sx, m2, 1.0, False)
+            assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL_F32, (sv, sx)
+        # (c) float32 device slabs
+        v32, x32 = v2.astype(np.float32), x2.astype(np.float32)
+        want, _ = run_helfand(ctx, v32.astype(np.float64), x32.astype(np.float64), m2, 1.0, False)
+        ctx.set_option("stage_device_f32", 1)
+        try:
+            sv_, sx_ = ctx.stage_alloc(T2, A2, 3, n_slabs=2, dtype=np.float32)
+            sv_[...] = v32
+            sx_[...] = x32
+            ctx.stage_commit(0, T2)
+            ctx.set_option("timeline", 1)
+            got, _ = ctx.helfand_msd(m2, 1.0, by_particle=False)
+            assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_lags"]
+        finally:
+            ctx.set_option("timeline", 0)
+            ctx.set_option("stage_device_f32", 0)
+            ctx.stage_free()
+        assert np.array_equal(got, want)
+    finally:
+        ctx.set_option("direct_f32", 0)
+
+
 @pytest.mark.parametrize("T,A,D", [(100, 700, 3), (1000, 300, 2), (2561, 90, 3), (5121, 70, 3),
                                    (10000, 50, 1), (640, 203, 3)])
 def test_fft_many_units_per_workgroup(ctx, T, A, D):

@@ -45,10 +45,11 @@ struct DevPlan {
     void free_all() { (void)hipFree(pieces), (void)hipFree(slot_begin), (void)hipFree(slot_pieces), (void)hipFree(group_begin), (void)hipFree(partial); }
 };
 
+static unsigned long long* g_stamps = nullptr;
 static void run(DevPlan& d, const float* pm, long pitch, int T, long n_cols, double* lagsum, int nwg) {
     const long n_pairs = (n_cols + 1) / 2;
     hipLaunchKernelGGL((k_band32_lags<B32_NW, B32_PF, B32_NS>), dim3(nwg), dim3(64 * B32_NW), 0, 0, pm, pitch, T, n_pairs, d.p.n_labels,
-                       d.p.n_ph, d.pieces, (int)d.p.pieces.size(), d.slot_begin, d.slot_pieces, d.partial);
+                       d.p.n_ph, d.pieces, (int)d.p.pieces.size(), d.slot_begin, d.slot_pieces, d.partial, g_stamps);
     hipLaunchKernelGGL(k_band_gather, dim3((T + 255) / 256), dim3(256), 0, 0, d.partial, d.p.n_labels, (int)d.p.pieces.size(),
                        d.p.n_ph, d.p.per_phase, d.group_begin, d.p.n_groups, T, -2.0, 1, lagsum);
 }
@@ -169,6 +170,7 @@ int main(int argc, char** argv) {
     d.upload();
     printf("T=%d A=%ld D=%d: groups %d, n_ph %d, pieces %zu, slot cost max/mean %.1f / %.1f steps per sextet\n", T, A, D, d.p.n_groups,
            d.p.n_ph, d.p.pieces.size(), d.p.max_cost, d.p.mean_cost);
+    CK(hipMalloc(&g_stamps, 16 * (size_t)nwg_full * B32_NW));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -184,6 +186,16 @@ int main(int argc, char** argv) {
         const double terms = (double)T * (T - 1) / 2 * (double)n_cols;
         printf("  %.3f ms  %.1f reference TFLOP/s (3 per term), matrix pipe issues %.1f TFLOP/s (2 per term on 6 of 8 slots)\n", ms,
                3.0 * terms / (ms * 1e-3) / 1e12, 2.0 * (8.0 / 6.0) * terms / (ms * 1e-3) / 1e12);
+    }
+    {   // the clock the kernel held and its cycles per step (busiest wave), from the last launch's stamps
+        std::vector<unsigned long long> st(2 * (size_t)nwg_full * B32_NW);
+        CK(hipMemcpy(st.data(), g_stamps, st.size() * 8, hipMemcpyDeviceToHost));
+        double cyc = 0, ticks = 0, cmax = 0;
+        for (size_t w = 0; w < st.size() / 2; ++w) cyc += (double)st[2 * w], ticks += (double)st[2 * w + 1], cmax = std::max(cmax, (double)st[2 * w]);
+        const long n_sext = (n_pairs + 2) / 3;
+        const double steps_busiest = d.p.max_cost * (double)((n_sext + 7) / 8) / d.p.n_ph;
+        printf("  in-kernel clock %.0f MHz (mean over waves), busiest wave %.3e cycles = %.0f per step (%.0f MFMA cycles of them)\n",
+               cyc / ticks * 100.0, cmax, cmax / steps_busiest, 32.0 * 32.0);
     }
     std::vector<double> hh(4);
     CK(hipMemcpy(hh.data(), out, 32, hipMemcpyDeviceToHost));

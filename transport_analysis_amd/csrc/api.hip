@@ -172,6 +172,22 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
     // and run on the FP64 matrix cores (band_kernels.hpp).  The by-particle arrays and the float32
     // option stay on the vector kernels below.
     const bool band_ok = !d_bp && !f32 && !src_f32 && ctx->opt_direct_mfma && T < ((int64_t)1 << 24);
+    // ... and the float32 option's Helfand lag sums on the FP32 matrix cores (band32_kernels.hpp): P rounded once
+    // to float32 like the float32 vector kernel's staged values, float32 products, float64 accumulation
+    if (!d_bp && f32 && mode == MODE_HELFAND && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
+        const int64_t n_cols = A * D;
+        if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK) {
+            tl_mark(ctx, "k_helfand_product32", st);
+            TA_HIP_TRY(ctx, launch_helfand_product32(d_vel, d_pos, src_f32, d_masses, pitch, T, n_cols, D, (float*)ctx->helf_p.p, st));
+            tl_mark(ctx, "k_band32_lags", st);
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+            TA_HIP_TRY(ctx, launch_band32_lags(&ctx->band, ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, n_cols,
+                                               scale / (double)D, d_lagsum, st));
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+            return TA_OK;
+        }
+        (void)hipGetLastError();  // out of memory for the product slab: the vector kernel needs none
+    }
     if (band_ok && mode == MODE_VACF) {
         tl_mark(ctx, "k_band_lags", st);
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));

@@ -38,8 +38,10 @@ static hipError_t band_upload(V** dst, const std::vector<V>& src) {
     return src.empty() ? hipSuccess : hipMemcpy(*dst, src.data(), sizeof(V) * src.size(), hipMemcpyHostToDevice);
 }
 
-hipError_t launch_band_lags(BandCache** cache, int n_cu, bool helfand, const double* pm, long pitch, int T, long n_cols,
-                            double factor, double* lagsum, hipStream_t st) {
+// the cut of the band for (T, this device) and its device copies, built on first use and kept in *cache
+hipError_t band_tables(BandCache** cache, int n_cu, int T, hipStream_t st, int* nwg_out, int* n_ph, int* n_pieces, int* per_phase,
+                       int* n_groups, const BandPiece** pieces, const int** slot_begin, const int** slot_pieces,
+                       const int** group_begin, double** partial) {
     constexpr int kLabels = 8;  // one per XCD, as the hardware deals workgroups round-robin to them
     const int nwg = std::max(kLabels, n_cu / kLabels * kLabels);
     if (!*cache) *cache = new BandCache;
@@ -62,17 +64,31 @@ hipError_t launch_band_lags(BandCache** cache, int n_cu, bool helfand, const dou
             return e;
         }
     }
+    *nwg_out = nwg, *n_ph = c.plan.n_ph, *n_pieces = (int)c.plan.pieces.size(), *per_phase = c.plan.per_phase;
+    *n_groups = c.plan.n_groups, *pieces = c.pieces, *slot_begin = c.slot_begin, *slot_pieces = c.slot_pieces;
+    *group_begin = c.group_begin, *partial = c.partial;
+    return hipSuccess;
+}
+
+hipError_t launch_band_lags(BandCache** cache, int n_cu, bool helfand, const double* pm, long pitch, int T, long n_cols,
+                            double factor, double* lagsum, hipStream_t st) {
+    constexpr int kLabels = 8;
+    int nwg = 0, n_ph = 0, n_pieces = 0, per_phase = 0, n_groups = 0;
+    const BandPiece* pieces = nullptr;
+    const int *slot_begin = nullptr, *slot_pieces = nullptr, *group_begin = nullptr;
+    double* partial = nullptr;
+    hipError_t e = band_tables(cache, n_cu, T, st, &nwg, &n_ph, &n_pieces, &per_phase, &n_groups, &pieces, &slot_begin, &slot_pieces,
+                               &group_begin, &partial);
+    if (e != hipSuccess) return e;
     const long n_pairs = (n_cols + 1) / 2;
-    const int n_pieces = (int)c.plan.pieces.size();
     if (helfand)  // accumulators hold -1/2 the squared differences
-        hipLaunchKernelGGL(k_band_lags<true>, dim3(nwg), dim3(512), 0, st, pm, pitch, T, n_pairs, kLabels, c.plan.n_ph, c.pieces,
-                           n_pieces, c.slot_begin, c.slot_pieces, c.partial);
+        hipLaunchKernelGGL(k_band_lags<true>, dim3(nwg), dim3(512), 0, st, pm, pitch, T, n_pairs, kLabels, n_ph, pieces, n_pieces,
+                           slot_begin, slot_pieces, partial);
     else
-        hipLaunchKernelGGL(k_band_lags<false>, dim3(nwg), dim3(512), 0, st, pm, pitch, T, n_pairs, kLabels, c.plan.n_ph, c.pieces,
-                           n_pieces, c.slot_begin, c.slot_pieces, c.partial);
-    hipLaunchKernelGGL(k_band_gather, dim3((T + 255) / 256), dim3(256), 0, st, c.partial, kLabels, n_pieces, c.plan.n_ph,
-                       c.plan.per_phase, c.group_begin, c.plan.n_groups, T, helfand ? -2.0 * factor : factor, helfand ? 1 : 0,
-                       lagsum);
+        hipLaunchKernelGGL(k_band_lags<false>, dim3(nwg), dim3(512), 0, st, pm, pitch, T, n_pairs, kLabels, n_ph, pieces, n_pieces,
+                           slot_begin, slot_pieces, partial);
+    hipLaunchKernelGGL(k_band_gather, dim3((T + 255) / 256), dim3(256), 0, st, partial, kLabels, n_pieces, n_ph, per_phase, group_begin,
+                       n_groups, T, helfand ? -2.0 * factor : factor, helfand ? 1 : 0, lagsum);
     return hipGetLastError();
 }
 

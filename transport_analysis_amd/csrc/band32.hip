@@ -1,0 +1,47 @@
+// band32.hip — launcher of the FP32 matrix-core evaluation of the Einstein-Helfand lag sums (band32_kernels.hpp):
+// BASELINE configs[4]'s float32 path without the by-particle array
+// (/root/reference/transport_analysis/viscosity.py:201-233 summed over particles, P rounded once to float32).
+// The cut of the band is band.hip's (same wave slots per XCD: 8 waves per workgroup, one workgroup per CU).
+#include "band32_kernels.hpp"
+
+#include "../../include/ta_hip.h"
+#include "ta_internal.hpp"
+
+namespace ta {
+
+// P32 = float32((m v) x), pair-major 8-byte rows; vel / pos: pair-major float64 or (src_f32) float32 slabs
+hipError_t launch_helfand_product32(const void* vel, const void* pos, bool src_f32, const double* masses, long pitch, long T,
+                                    long n_cols, int D, float* P32, hipStream_t st) {
+    const long n_pairs = (n_cols + 1) / 2;
+    // grid.x covers the rows two at a time, grid.y walks the pairs
+    const unsigned gx = (unsigned)std::max<long>(1, std::min<long>(64, (T / 2 + 255) / 256));
+    const unsigned gy = (unsigned)std::max<long>(1, std::min<long>(n_pairs, 65535));
+    if (src_f32)
+        hipLaunchKernelGGL(k_helfand_product32<float>, dim3(gx, gy), dim3(256), 0, st, (const float*)vel, (const float*)pos, masses,
+                           pitch, T, n_cols, D, P32);
+    else
+        hipLaunchKernelGGL(k_helfand_product32<double>, dim3(gx, gy), dim3(256), 0, st, (const double*)vel, (const double*)pos,
+                           masses, pitch, T, n_cols, D, P32);
+    return hipGetLastError();
+}
+
+// lagsum[k] = factor * sum over columns and origins of (P32[i, c] - P32[i + k, c])^2 / (n_frames - k), lagsum[0] = 0
+hipError_t launch_band32_lags(BandCache** cache, int n_cu, const float* pm32, long pitch, int T, long n_cols, double factor,
+                              double* lagsum, hipStream_t st) {
+    constexpr int kLabels = 8, kWaves = 8;
+    int nwg = 0, n_ph = 0, n_pieces = 0, per_phase = 0, n_groups = 0;
+    const BandPiece* pieces = nullptr;
+    const int *slot_begin = nullptr, *slot_pieces = nullptr, *group_begin = nullptr;
+    double* partial = nullptr;
+    hipError_t e = band_tables(cache, n_cu, T, st, &nwg, &n_ph, &n_pieces, &per_phase, &n_groups, &pieces, &slot_begin, &slot_pieces,
+                               &group_begin, &partial);
+    if (e != hipSuccess) return e;
+    static_assert(kWaves == 8, "band_tables cuts the band for 8 wave slots per workgroup");
+    hipLaunchKernelGGL((k_band32_lags<kWaves, 2, 4>), dim3(nwg), dim3(64 * kWaves), 0, st, pm32, pitch, T, (n_cols + 1) / 2, kLabels,
+                       n_ph, pieces, n_pieces, slot_begin, slot_pieces, partial, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_band_gather, dim3((T + 255) / 256), dim3(256), 0, st, partial, kLabels, n_pieces, n_ph, per_phase, group_begin,
+                       n_groups, T, -2.0 * factor, 1, lagsum);
+    return hipGetLastError();
+}
+
+}  // namespace ta

@@ -52,7 +52,7 @@ struct BandSrc32 {
     // inside inline assembly; tools/check_isa.py verifies the nop is there); s_nop 0: M0 write -> LDS-DMA
     __device__ __forceinline__ void dma(unsigned lds_addr, unsigned voff) const {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs)
-                     : "memory", "m0");
+                     : "memory");
     }
     __device__ __forceinline__ band_f2 load_now(int b) const {  // compiler-visible, waited for at its use
         return __builtin_bit_cast(band_f2, __builtin_amdgcn_raw_buffer_load_b64(crs, lane_off + (unsigned)b * 128u, 0, 0));
@@ -75,6 +75,9 @@ __device__ __forceinline__ float band32_sum_rows(float s) {
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;  // ... + the same of lane l ^ 16
 }
+
+__device__ __forceinline__ band_f2 band32_sub(band_f2 a, band_f2 b) { return a - b; }
+__device__ __forceinline__ band_f2 band32_add(band_f2 a, band_f2 b) { return a + b; }
 
 struct BandHelf32 {
     int T, i;
@@ -108,36 +111,117 @@ struct BandHelf32 {
         }
         return c;
     }
-    // A operand of a step whose window reaches the end of the series: (valid, -nA/2) through the product
-    __device__ __forceinline__ band_f2 prep_a_edge(band_f2 raw, band_f2 r, int b) const {
-        const bool valid = 16 * b + i < T;
-        band_f2 c = raw - r;
+    // The operands of a step, for any block (inside the series or reaching past its end): rows centred, frames
+    // past the end zeroed, -1/2 the squared norm over the sextet in the fourth lane group beside the
+    // validity flag — (valid, -nA/2) for the A operand, (-nB/2, valid) for the B operand.  (raw - r) is (1, 0) in
+    // the fourth lane group, so masking alone leaves the flag in c.x.
+    __device__ __forceinline__ band_f2 centred(band_f2 raw, band_f2 r, int b, float& n) const {
+        band_f2 c = band32_sub(raw, r);
+        const bool valid = i < T - 16 * b;
         if (!valid) c = band_f2{0.0f, 0.0f};
-        const float n = -0.5f * band32_sum_rows(slot ? 0.0f : c.x * c.x + c.y * c.y);
-        if (slot) c = band_f2{valid ? 1.0f : 0.0f, n};
+        n = -0.5f * band32_sum_rows(slot ? 0.0f : c.x * c.x + c.y * c.y);
         return c;
     }
-    // ... and of every other step: its rows' norms would add the same -nA[m]/2 to all 16 accumulators, so they
-    // are summed per lane (fourth group: exactly 0) and subtracted once in the epilogue
+    // A operand of a step whose whole window lies inside the series: its rows' norms would add the same -nA[m]/2
+    // to all 16 accumulators, so they are summed per lane (fourth group: exactly 0) and subtracted once in the
+    // epilogue
     __device__ __forceinline__ band_f2 prep_a_bulk(band_f2 raw, band_f2 r, float& na) const {
-        const band_f2 c = raw - r;
+        const band_f2 c = band32_sub(raw, r);
         na += norm2(c);
+        return c;
+    }
+    __device__ __forceinline__ band_f2 prep_a(band_f2 raw, band_f2 r, int b) const {
+        float n;
+        band_f2 c = centred(raw, r, b, n);
+        if (slot) c.y = n;
+        return c;
+    }
+    __device__ __forceinline__ band_f2 prep_b(band_f2 raw, band_f2 r, int b) const {
+        float n;
+        band_f2 c = centred(raw, r, b, n);
+        if (slot) c = band_f2{n, c.x};
         return c;
     }
 };
 
-constexpr int kBand32Flush = 16;  // steps a float32 accumulator holds before it is added into float64
+#ifndef TA_BAND32_ABL  // timing ablations (wrong results), bit mask: 1 no request / ring read in the loop, 2 no preparation of
+#define TA_BAND32_ABL 0  // the window's new fragment, 4 no re-centring, 8 no flush, 16 no preparation of the A operand
+#endif
+#ifndef TA_BAND32_FLUSH  // (harness: 16 ... 512 measured, tools/band/build32.sh; 20000 x 25000 x 3: 394 / 346 / 337 / 333 / 332 ms
+#define TA_BAND32_FLUSH 128  // at 16 / 64 / 128 / 256 / 512, the lag sums equal to 1e-10 between 16 and 512)
+#endif
+constexpr int kBand32Flush = TA_BAND32_FLUSH;  // steps a float32 accumulator holds before it is added into float64
+
+// Where the float32 accumulators go every kBand32Flush steps.  Only the 31 diagonals of a 16 x 16 accumulator
+// matter (element (m, n) of block lag d belongs to lag 16 d + n - m), so a flush sums the diagonals in float32
+// — at most 16 values each — through a wave-private LDS image and adds the 272 lag values of the wave's 16
+// block lags into float64: five doubles per lane instead of the 64 a lane would need to keep every element
+// (128 registers: what held this kernel to one wave per SIMD).
+//   D    [32][17] floats, element (m, n) at [n - m + 15][m]: a diagonal is a row; entries no element maps to
+//        (and row 31) are zeroed once and never written;
+//   ds   [16][32] floats, ds[d][e + 15] = diagonal e of accumulator d;
+//   s[k] lag slot lane + 64 k of this piece: slot q holds lag offset q - 15 = 16 d + e from block lag d0, i.e.
+//        diagonal e >= 0 of accumulator d plus diagonal e - 16 of accumulator d + 1.
+struct Band32Diag {
+    float* D;
+    float* ds;
+    double s[5];
+    int lane;
+    __device__ __forceinline__ void init(float* lds, int lane_) {
+        D = lds, ds = lds + 32 * 17, lane = lane_;
+        for (int q = lane; q < 32 * 17; q += 64) D[q] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s[k] = 0.0;
+    }
+    // acc (float32, C layout row m = 4 (lane >> 4) + r, column n = lane & 15) -> s; acc is zeroed
+    __device__ __forceinline__ void flush(band_f4 (&acc)[16]) {
+        const int g = lane >> 4, n = lane & 15, t = lane & 31, hh = lane >> 5;
+        float* wr = D + (n - 4 * g + 15) * 17 + 4 * g - 48;  // register r at wr[16 (3 - r)]
+        const float* rd = D + t * 17 + 8 * hh;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wr[16 * (3 - r)] = acc[d][r];
+            acc[d] = band_f4{0.0f, 0.0f, 0.0f, 0.0f};
+            __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order: this pins the compiler's order)
+            float u = ((rd[0] + rd[1]) + (rd[2] + rd[3])) + ((rd[4] + rd[5]) + (rd[6] + rd[7]));
+            float v = u;
+            asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(v));
+            if (lane < 32) ds[d * 32 + t] = u + v;
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int off = lane + 64 * k - 15;            // -15 ... 304
+            const int d = (off + 16) / 16 - 1, e = off - 16 * d;  // e in [0, 15]
+            float v = 0.0f;
+            if (d >= 0 && d <= 15) v = ds[d * 32 + e + 15];
+            if (e >= 1 && d + 1 >= 0 && d + 1 <= 15) v += ds[(d + 1) * 32 + e - 1];
+            s[k] += (double)v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+};
 
 // one piece on one sextet.  ring: this wave's LDS ring, NS slots of 128 rows (1 KiB); the request of step x
 // (A block x, window block x + d0 + 15) is issued PF steps ahead into slot (x - i0) % NS and read into
-// registers one step ahead.
-// The float32 accumulators are added into `sum` every 16 steps (a pass of the unrolled ring) and at the end
-// of the visit, and never zeroed: the first MFMAs of every pass take the constant 0 as their C operand.
+// registers one step ahead.  Every 16 steps the reference row moves to the A block's first frame and the 15
+// older window fragments follow it.
+// (Measured, DESIGN.md 4.3.2: v_mfma_f32_16x16x4_f32 and vector instructions do NOT overlap on gfx950 any more
+// than the FP64 form's do — making step x + 1's operands between step x's MFMAs, one MFMA : two vector
+// instructions, took 424 ms where this form took 389 (20000 x 25000 x 3, one wave per SIMD): a vector
+// instruction costs its time wherever it stands, and with one wave per SIMD that time is its latency (the
+// window fragment's preparation is one dependent chain).  So the loop is kept to the fewest instructions —
+// blocks inside the series take a path without masks, the A rows' norms are summed per lane instead of going
+// through the product — and the kernel runs TWO waves per SIMD, which the diagonal flush above makes room for.)
 template <int PF, int NS>
 __device__ __forceinline__ void band32_visit(const BandSrc32& src, band_f2* ring, int d0, int i0, int i1, band_f4 (&acc)[16],
-                                             band_d4 (&sum)[16], double& na) {
+                                             Band32Diag& sums, double& na, int& since) {
     static_assert(16 % NS == 0 && NS >= 2 * PF && PF >= 1, "slots are indexed by the unrolled step; a slot is rewritten PF steps after it was read");
-    static_assert(kBand32Flush == 16, "one flush per pass of the ring");
+    static_assert(kBand32Flush % 16 == 0, "flushes happen between passes of the ring");
     const BandHelf32 h{src.T, src.i, src.slot, src.slot ? 1.0f : 0.0f};
     const int lane = (int)(threadIdx.x & 63);
     // LDS byte address of the ring (low half of the flat address; the same in every lane of the wave)
@@ -154,82 +238,82 @@ __device__ __forceinline__ void band32_visit(const BandSrc32& src, band_f2* ring
     r = h.first_row(anext);
     if (16 * (i0 + d0 + 15) <= src.T) {  // the 15 blocks lie inside the series
 #pragma unroll
-        for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<true, true>(W[d] - r, 0);
+        for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<true, true>(band32_sub(W[d], r), 0);
     } else {
 #pragma unroll
-        for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<true, false>(W[d] - r, i0 + d0 + d);
+        for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<true, false>(band32_sub(W[d], r), i0 + d0 + d);
     }
-    auto flush = [&]() {  // four values at a time (the accumulators live in AGPRs)
-#pragma unroll
-        for (int d = 0; d < 16; ++d) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sum[d][q] += (double)acc[d][q];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        na += (double)na32;
-        na32 = 0.0f;
-    };
-    const band_f4 zero4 = band_f4{0.0f, 0.0f, 0.0f, 0.0f};
     int I = i0;
     for (bool more = true; more;) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const band_f2 araw = anext, wraw = wnext;
-            src.dma(ring_addr + 1024u * ((j + PF) % NS), voff0 + 128u * (unsigned)(I + PF));
-            TA_BAND32_WAIT(PF - 1);  // the request of step I + 1 has landed
-            anext = ring[128 * ((j + 1) % NS) + lane];
-            wnext = ring[128 * ((j + 1) % NS) + 64 + lane];
-            if (j == 0 && I != i0) {  // a new pass: flush, and a new reference row that the 15 older window fragments follow
-                flush();
+            if (!(TA_BAND32_ABL & 1)) {
+                src.dma(ring_addr + 1024u * ((j + PF) % NS), voff0 + 128u * (unsigned)(I + PF));
+                TA_BAND32_WAIT(PF - 1);  // the request of step I + 1 has landed
+                anext = ring[128 * ((j + 1) % NS) + lane];
+                wnext = ring[128 * ((j + 1) % NS) + 64 + lane];
+            }
+            if (j == 0 && !(TA_BAND32_ABL & 8) && ++since == kBand32Flush / 16) {  // (a visit's first pass counts: a piece of
+                sums.flush(acc);                                                    // short visits must not outrun the limit)
+                since = 0;
+            }
+            if (j == 0 && I != i0 && !(TA_BAND32_ABL & 4)) {  // a new pass: a new reference row that the 15 older window fragments follow
                 const band_f2 rn = h.first_row(araw);
-                const band_f2 delta = r - rn;
+                const band_f2 delta = band32_sub(r, rn);
                 r = rn;
                 if (16 * (I + d0 + 15) <= src.T) {
 #pragma unroll
-                    for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<false, true>(W[d] + delta, 0);
+                    for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<false, true>(band32_add(W[d], delta), 0);
                 } else {
 #pragma unroll
-                    for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<false, false>(W[d] + delta, I + d0 + d);
+                    for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<false, false>(band32_add(W[d], delta), I + d0 + d);
                 }
             }
             band_f2 A;
-            if (16 * (I + d0 + 16) <= src.T) {  // this step's whole window inside the series
+            if (TA_BAND32_ABL & 18) {
+                A = (TA_BAND32_ABL & 16) ? araw : h.prep_a_bulk(araw, r, na32);
+                W[(j + 15) & 15] = (TA_BAND32_ABL & 2) ? wraw : h.template finish_b<true, true>(band32_sub(wraw, r), 0);
+            } else if (16 * (I + d0 + 16) <= src.T) {  // this step's whole window inside the series
                 A = h.prep_a_bulk(araw, r, na32);
-                W[(j + 15) & 15] = h.template finish_b<true, true>(wraw - r, 0);
+                W[(j + 15) & 15] = h.template finish_b<true, true>(band32_sub(wraw, r), 0);
             } else {
-                A = h.prep_a_edge(araw, r, I);
-                W[(j + 15) & 15] = h.template finish_b<true, false>(wraw - r, I + d0 + 15);
+                A = h.prep_a(araw, r, I);
+                W[(j + 15) & 15] = h.prep_b(wraw, r, I + d0 + 15);
             }
 #pragma unroll
-            for (int d = 0; d < 16; ++d) acc[d] = TA_BAND32_MFMA(A.x, W[(j + d) & 15].x, j == 0 ? zero4 : acc[d]);
+            for (int d = 0; d < 16; ++d) acc[d] = TA_BAND32_MFMA(A.x, W[(j + d) & 15].x, acc[d]);
 #pragma unroll
             for (int d = 0; d < 16; ++d) acc[d] = TA_BAND32_MFMA(A.y, W[(j + d) & 15].y, acc[d]);
-            if (++I == i1) {  // (one common tail: sixteen copies of the flush would be most of the kernel's code)
+            if (++I == i1) {  // (one common tail)
                 more = false;
                 break;
             }
         }
     }
     TA_BAND32_WAIT(0);  // the requests past the piece: the ring is reused by the next visit
-    flush();
+    na += (double)na32;  // (float32 over one visit's steps: a few hundred terms per lane)
 }
 
 // pm: pair-major FLOAT32 product slab (8-byte rows).  grid: n_labels * (slots / NW) workgroups of 64 NW threads.
-// Results: partial[label][piece][272] = -1/2 the squared differences (k_band_gather applies -2 factor).
+// Results: partial[label][piece][272] = -1/2 the squared differences (k_band_gather applies the factor -2).
 template <int NW, int PF, int NS>
 __global__ void __launch_bounds__(64 * NW)
     k_band32_lags(const float* __restrict__ pm, long pitch, int T, long n_pairs, int n_labels, int n_ph,
                   const BandPiece* __restrict__ pieces, int n_pieces, const int* __restrict__ slot_begin,
-                  const int* __restrict__ slot_pieces, double* __restrict__ partial) {
-    __shared__ double red[NW][272 + 16 * 32];
+                  const int* __restrict__ slot_pieces, double* __restrict__ partial, unsigned long long* __restrict__ stamps) {
+    // stamps (diagnostics; NULL in the library): per wave, shader cycles and 100 MHz ticks from entry to exit
+    __shared__ float diag[NW][32 * 17 + 16 * 32];
+    __shared__ double na_half[NW][16];
     __shared__ band_f2 rings[NW][NS * 128];
+    const unsigned long long t_c0 = stamps ? __builtin_amdgcn_s_memtime() : 0, t_r0 = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int label = blockIdx.x % n_labels;
     const int slot = (blockIdx.x / n_labels) * NW + wave;
     const long n_sext = (n_pairs + 2) / 3;
     const int kk = lane >> 4;
-    double* blk = red[wave];
-    double* dsum = blk + 272;
+    Band32Diag sums;
+    sums.init(diag[wave], lane);
     const int pb = __builtin_amdgcn_readfirstlane(slot_begin[slot]), pe = __builtin_amdgcn_readfirstlane(slot_begin[slot + 1]);
     for (int pi = pb; pi < pe; ++pi) {
         const int idx = __builtin_amdgcn_readfirstlane(slot_pieces[pi]);
@@ -237,10 +321,13 @@ __global__ void __launch_bounds__(64 * NW)
         const int d0 = __builtin_amdgcn_readfirstlane(pc.d0), i0 = __builtin_amdgcn_readfirstlane(pc.i0),
                   i1 = __builtin_amdgcn_readfirstlane(pc.i1), phase = __builtin_amdgcn_readfirstlane(pc.phase);
         band_f4 acc[16];
-        band_d4 sum[16];
-        double na = 0.0;
+        double na = 0.0;  // squared norms of the A rows of the steps that did not put them through the product
+        // passes since the last flush; the second wave of a SIMD (waves w and w + NW / 2 share one) starts half a
+        // period in, so that the two do not stand in their flushes — LDS round trips — at the same time
+        int since = (NW >= 8 && wave >= NW / 2) ? kBand32Flush / 32 : 0;
+        sums.clear();
 #pragma unroll
-        for (int d = 0; d < 16; ++d) acc[d] = band_f4{0.0f, 0.0f, 0.0f, 0.0f}, sum[d] = band_d4{0.0, 0.0, 0.0, 0.0};
+        for (int d = 0; d < 16; ++d) acc[d] = band_f4{0.0f, 0.0f, 0.0f, 0.0f};
         for (long o = label + (long)n_labels * phase; o < n_sext; o += (long)n_labels * n_ph) {
             const long left = n_pairs - 3 * o;  // pairs of this sextet that exist
             BandSrc32 src;
@@ -255,44 +342,39 @@ __global__ void __launch_bounds__(64 * NW)
             src.T = T;
             src.i = lane & 15;
             src.slot = kk == 3;
-            band32_visit<PF, NS>(src, rings[wave], d0, i0, i1, acc, sum, na);
+            band32_visit<PF, NS>(src, rings[wave], d0, i0, i1, acc, sums, na, since);
         }
-        // diagonals: sum[d][r] of lane l is C_d[m = 4 (l >> 4) + r][n = l & 15], lag 16 (d0 + d) + n - m
-        double na_m[4];
-        {  // nA[m] / 2 of the lane's four rows, through the LDS
-            const double t0 = band_sum_rows(na);  // (fourth group: exactly 0)
-            if (lane < 16) dsum[lane] = 0.5 * t0;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) na_m[r] = dsum[4 * (lane >> 4) + r];
+        sums.flush(acc);
+        // the A norms left out of the products: nA[m] / 2 of block row m, on every diagonal that row m lies on
+        {
+            const double t0 = band_sum_rows(na);  // (fourth lane group: exactly 0)
+            if (lane < 16) na_half[wave][lane] = 0.5 * t0;
             __builtin_amdgcn_wave_barrier();
         }
-#pragma unroll
-        for (int d = 0; d < 16; ++d) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) blk[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = sum[d][r] - na_m[r];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 31) {
-                const int e = lane - 15;
-                const int m_lo = e < 0 ? -e : 0, m_hi = e > 0 ? 16 - e : 16;
-                double s = 0.0;
-                for (int m = m_lo; m < m_hi; ++m) s += blk[m * 17 + m + e];
-                dsum[d * 32 + lane] = s;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
+        auto corr = [&](int e) {  // sum of nA[m] / 2 over the rows of diagonal e
+            const int m_lo = e < 0 ? -e : 0, m_hi = e > 0 ? 16 - e : 16;
+            double c = 0.0;
+            for (int m = m_lo; m < m_hi; ++m) c += na_half[wave][m];
+            return c;
+        };
         double* out = partial + ((long)label * n_pieces + idx) * kBandPartial;
-        for (int q = lane; q < kBandPartial; q += 64) {
-            const int off = q - 15;
-            const int d = off >= 0 ? off >> 4 : -1, e = off - 16 * d;
-            double s = 0.0;
-            if (off <= 255) {
-                if (d >= 0) s = dsum[d * 32 + e + 15];
-                if (e >= 1 && d + 1 <= 15) s += dsum[(d + 1) * 32 + e - 16 + 15];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int q = lane + 64 * k;
+            if (q < kBandPartial) {
+                const int off = q - 15;
+                const int d = (off + 16) / 16 - 1, e = off - 16 * d;
+                double c = 0.0;
+                if (d >= 0 && d <= 15) c = corr(e);
+                if (e >= 1 && d + 1 >= 0 && d + 1 <= 15) c += corr(e - 16);
+                out[q] = off <= 255 ? sums.s[k] - c : 0.0;
             }
-            out[q] = s;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (stamps && lane == 0) {
+        stamps[2 * ((long)blockIdx.x * NW + wave)] = __builtin_amdgcn_s_memtime() - t_c0;
+        stamps[2 * ((long)blockIdx.x * NW + wave) + 1] = __builtin_amdgcn_s_memrealtime() - t_r0;
     }
 }
 

@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(512)
 
 // lagsum[k] = factor * (sum over labels and over the pieces that hold lag k) / (T - k), fixed order;
 // zero_lag0: lagsum[0] = 0 exactly (viscosity.py:205-233 leaves row 0 at 0)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)  // (static: this header is included by band.hip and band32.hip)
     k_band_gather(const double* __restrict__ partial, int n_labels, int n_pieces, int n_ph, int per_phase,
                   const int* __restrict__ group_begin, int n_groups, int T, double factor, int zero_lag0,
                   double* __restrict__ lagsum) {
