@@ -73,6 +73,10 @@ def test_band_plan_covers_every_step_once():
             if T >= 2000 and n_cu == 256:
                 assert info["max_over_mean"] < 1.10, (T, info)
     assert _lib.band_plan_info(0) is None and _lib.band_plan_info(1 << 24) is None
+    # the largest frame count the call accepts: checked by intervals, not cell by cell (which was ~137 GB of
+    # bookkeeping and took the process down)
+    big = _lib.band_plan_info((1 << 24) - 1)
+    assert big is not None and big["n_pieces"] >= 256
 
 
 def test_atom_shard_partition():

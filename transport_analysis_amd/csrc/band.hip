@@ -5,6 +5,8 @@
 // the partial-sum buffer are cached per context.
 #include "band_kernels.hpp"
 
+#include <new>
+
 #include "../../include/ta_hip.h"
 #include "ta_internal.hpp"
 
@@ -97,7 +99,17 @@ hipError_t launch_band_lags(BandCache** cache, int n_cu, bool helfand, const dou
 // Host only: the cut of the band for n_frames on a device of n_cu compute units, checked cell by
 // cell (every step of every group belongs to exactly one piece of every phase, every piece to
 // exactly one wave slot of its phase).
+static int band_plan_info_impl(int64_t n_frames, int n_cu, int* n_pieces, int* octets_in_flight, double* max_over_mean);
 extern "C" int ta_band_plan_info(int64_t n_frames, int n_cu, int* n_pieces, int* octets_in_flight, double* max_over_mean) {
+    try {  // (no exception leaves an extern "C" function)
+        return band_plan_info_impl(n_frames, n_cu, n_pieces, octets_in_flight, max_over_mean);
+    } catch (const std::bad_alloc&) {
+        return TA_E_NOMEM;
+    } catch (...) {
+        return TA_E_UNSUPPORTED;
+    }
+}
+static int band_plan_info_impl(int64_t n_frames, int n_cu, int* n_pieces, int* octets_in_flight, double* max_over_mean) {
     using namespace ta;
     if (n_frames < 1 || n_frames >= ((int64_t)1 << 24) || n_cu < 8) return TA_E_INVALID;
     constexpr int kLabels = 8;
@@ -105,18 +117,17 @@ extern "C" int ta_band_plan_info(int64_t n_frames, int n_cu, int* n_pieces, int*
     const BandPlan p = band_plan((int)n_frames, nwg / kLabels * 8, kLabels);
     const int per = p.per_phase;
     if ((int)p.pieces.size() != per * p.n_ph || (int)p.slot_begin.size() != p.slots + 1) return TA_E_UNSUPPORTED;
-    // coverage of the band by one phase's pieces
-    std::vector<std::vector<int>> seen(p.n_groups);
-    for (int g = 0; g < p.n_groups; ++g) seen[g].assign(p.nblk - 16 * g, 0);
-    for (int g = 0; g < p.n_groups; ++g)
+    // coverage of the band by one phase's pieces: within a group they are sorted by i0 (band_plan hands the steps out
+    // in order), so "every step in exactly one piece" is "the intervals tile [0, steps of the group)"
+    for (int g = 0; g < p.n_groups; ++g) {
+        int next = 0;
         for (int li = p.group_begin[g]; li < p.group_begin[g + 1]; ++li) {
             const BandPiece& q = p.pieces[li];
-            if (q.d0 != 16 * g || q.i0 < 0 || q.i1 > p.nblk - 16 * g || q.i0 >= q.i1) return TA_E_UNSUPPORTED;
-            for (int i = q.i0; i < q.i1; ++i) ++seen[g][i];
+            if (q.d0 != 16 * g || q.i0 != next || q.i1 <= q.i0) return TA_E_UNSUPPORTED;
+            next = q.i1;
         }
-    for (auto& row : seen)
-        for (int c : row)
-            if (c != 1) return TA_E_UNSUPPORTED;
+        if (next != p.nblk - 16 * g) return TA_E_UNSUPPORTED;
+    }
     // every piece of every phase in exactly one slot, of its own phase
     std::vector<int> owner(p.pieces.size(), 0);
     const int wslots = p.slots / p.n_ph;

@@ -247,19 +247,13 @@ __device__ __forceinline__ void band32_visit(const BandSrc32& src, band_f2* ring
     for (bool more = true; more;) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const band_f2 araw = anext, wraw = wnext;
-            if (!(TA_BAND32_ABL & 1)) {
-                src.dma(ring_addr + 1024u * ((j + PF) % NS), voff0 + 128u * (unsigned)(I + PF));
-                TA_BAND32_WAIT(PF - 1);  // the request of step I + 1 has landed
-                anext = ring[128 * ((j + 1) % NS) + lane];
-                wnext = ring[128 * ((j + 1) % NS) + 64 + lane];
-            }
             if (j == 0 && !(TA_BAND32_ABL & 8) && ++since == kBand32Flush / 16) {  // (a visit's first pass counts: a piece of
                 sums.flush(acc);                                                    // short visits must not outrun the limit)
                 since = 0;
             }
+            // this step's operands from the rows read during the previous step ...
             if (j == 0 && I != i0 && !(TA_BAND32_ABL & 4)) {  // a new pass: a new reference row that the 15 older window fragments follow
-                const band_f2 rn = h.first_row(araw);
+                const band_f2 rn = h.first_row(anext);
                 const band_f2 delta = band32_sub(r, rn);
                 r = rn;
                 if (16 * (I + d0 + 15) <= src.T) {
@@ -272,14 +266,21 @@ __device__ __forceinline__ void band32_visit(const BandSrc32& src, band_f2* ring
             }
             band_f2 A;
             if (TA_BAND32_ABL & 18) {
-                A = (TA_BAND32_ABL & 16) ? araw : h.prep_a_bulk(araw, r, na32);
-                W[(j + 15) & 15] = (TA_BAND32_ABL & 2) ? wraw : h.template finish_b<true, true>(band32_sub(wraw, r), 0);
+                A = (TA_BAND32_ABL & 16) ? anext : h.prep_a_bulk(anext, r, na32);
+                W[(j + 15) & 15] = (TA_BAND32_ABL & 2) ? wnext : h.template finish_b<true, true>(band32_sub(wnext, r), 0);
             } else if (16 * (I + d0 + 16) <= src.T) {  // this step's whole window inside the series
-                A = h.prep_a_bulk(araw, r, na32);
-                W[(j + 15) & 15] = h.template finish_b<true, true>(band32_sub(wraw, r), 0);
+                A = h.prep_a_bulk(anext, r, na32);
+                W[(j + 15) & 15] = h.template finish_b<true, true>(band32_sub(wnext, r), 0);
             } else {
-                A = h.prep_a(araw, r, I);
-                W[(j + 15) & 15] = h.prep_b(wraw, r, I + d0 + 15);
+                A = h.prep_a(anext, r, I);
+                W[(j + 15) & 15] = h.prep_b(wnext, r, I + d0 + 15);
+            }
+            // ... then the next step's rows leave the ring (their latency is this step's MFMAs)
+            if (!(TA_BAND32_ABL & 1)) {
+                src.dma(ring_addr + 1024u * ((j + PF) % NS), voff0 + 128u * (unsigned)(I + PF));
+                TA_BAND32_WAIT(PF - 1);  // the request of step I + 1 has landed
+                anext = ring[128 * ((j + 1) % NS) + lane];
+                wnext = ring[128 * ((j + 1) % NS) + 64 + lane];
             }
 #pragma unroll
             for (int d = 0; d < 16; ++d) acc[d] = TA_BAND32_MFMA(A.x, W[(j + d) & 15].x, acc[d]);

@@ -135,73 +135,85 @@ typedef unsigned band_u4 __attribute__((ext_vector_type(4)));
 // outside the resource instead, so the bounds check returns zeros.  (A slab's unpaired last
 // column is paired with zeros by everything that writes slabs: layout.hip.)
 //
-// The loads are inline assembly with hand-placed s_waitcnt: as compiler-visible loads they are
-// sunk next to their first use (they are only used several basic blocks later, behind the
-// early exits of the unrolled ring), and every step then waits out a full memory latency.  The
-// compiler does not know these loads are in flight: band_visit drains them (vmcnt(0)) before it
-// returns, and nothing else in the kernel's loop is a vector memory operation.
+// Rows are requested by LDS-DMA (buffer_load_dwordx4 ... lds, inline assembly with hand-placed s_waitcnt)
+// into a per-wave ring in LDS, kBandPF steps ahead: lane l's 16 bytes land at slot + 16 l, which IS the
+// fragment layout, and the fragments are read from the ring one step ahead by ordinary LDS loads that the
+// compiler schedules and waits for itself.  Round 4 requested into REGISTERS from inline assembly (the
+// compiler sinks visible loads to their first use, behind the step's exit test: a memory latency per step):
+// the compiler then believes the destination is defined at the asm statement, and a copy or a spill of it
+// before the hand-placed wait reads stale data — nothing forbade that (the float32 form, under more
+// register pressure, showed exactly such copies).  A load whose target is the LDS has no register to copy.
+// What is left to inline assembly is checked in the generated code by tools/check_isa.py at build time.
+constexpr int kBandPF = 2;  // steps a row request runs ahead of its use
+constexpr int kBandNS = 4;  // ring slots (A block + window block, 2 KiB each); 16 % kBandNS == 0, kBandNS >= 2 kBandPF
 struct BandSrc {
-    band_u4 rs;         // buffer resource of the octet
-    unsigned lane_off;  // (kk pitch + i) * 16
-    int T, i;           // frames; this lane's frame inside a block (lane & 15)
-    bool slot;          // Helfand form: lane group 3 carries the norms instead of columns (reads zeros)
-    // (lane_off of the Helfand form's fourth lane group is outside the resource: it reads zeros)
-    // "s_nop 4": the resource may have just been restored from a spilled SGPR by v_readlane — a VALU
-    // write of an SGPR that a VMEM instruction reads needs 5 wait states, and the compiler's hazard
-    // recogniser does not look inside inline assembly.  (Found with the block offset in the
-    // instruction's scalar-offset field, which saves the per-request vector add: restored by
-    // v_readlane right in front of the load it read stale, wrong rows; with the nop that form is
-    // correct and no faster — 54.2 / 410.6 / 638.8 ms either way — so the plain form stays.)
-    __device__ __forceinline__ void request(band_d2& dst, int b) const {
+    band_u4 rs;                  // buffer resource of the octet (LDS-DMA, inline assembly)
+    __amdgpu_buffer_rsrc_t crs;  // the same for the compiler-visible loads of a visit's first 15 fragments
+    unsigned lane_off;           // (kk pitch + i) * 16
+    int T, i;                    // frames; this lane's frame inside a block (lane & 15)
+    bool slot;                   // Helfand form: lane group 3 carries the norms instead of columns (reads zeros)
+    __device__ __forceinline__ unsigned offset(int b) const {
         unsigned off = lane_off + (unsigned)b * 256u;
         if (16 * b + 16 > T) off = 16 * b + i < T ? off : 0xfffffff0u;  // wave-uniform: a block at the end of the series
-        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(dst) : "v"(off), "s"(rs));
+        return off;
+    }
+    // "s_nop 4": an SGPR of the resource (or M0) may have just been written by a VALU instruction (v_readlane
+    // restoring a spilled SGPR): 5 wait states before a VMEM instruction reads it, and the hazard recogniser
+    // does not look inside inline assembly.  It also covers the one wait state between the M0 write and the DMA.
+    __device__ __forceinline__ void dma(unsigned lds_addr, int b) const {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(offset(b)), "s"(rs)
+                     : "memory");
+    }
+    __device__ __forceinline__ band_d2 load_now(int b) const {  // compiler-visible: waited for at its use
+        return __builtin_bit_cast(band_d2, __builtin_amdgcn_raw_buffer_load_b128(crs, offset(b), 0, 0));
+    }
+    // step x's two requests: rows of block x into the slot's first KiB, of block x + dw into its second
+    __device__ __forceinline__ void request_step(unsigned ring_addr, int slot_idx, int x, int dw) const {
+        dma(ring_addr + 2048u * (unsigned)slot_idx, x);
+        dma(ring_addr + 2048u * (unsigned)slot_idx + 1024u, x + dw);
     }
 };
-#define TA_BAND_WAIT(N, REG) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(REG))
+#define TA_BAND_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 #define TA_BAND_MFMA(A, B, C) __builtin_amdgcn_mfma_f64_16x16x4f64((A), (B), (C), 0, 0, 0)
 
 // one piece on one octet: acc[d] += sum_{I in [i0, i1)} F_I^T F_{I + d0 + d}
-// In flight, oldest first, when step I starts: A_I, Wn_{I-3}, A_{I+1}, Wn_{I-2}, A_{I+2}, Wn_{I-1}, A_{I+3}
-// (A_x: the A operand of step x, requested three steps ahead into a ring of four; Wn_x: the window's new
-// fragment requested in step x, used last in step x + 1).
-__device__ __forceinline__ void band_visit(const BandSrc& src, int d0, int i0, int i1, band_d4 (&acc)[16]) {
-    band_d2 W[16], a[4];
-    src.request(a[0], i0);
+// ring: this wave's LDS ring (kBandNS slots of 128 rows).  Step x's rows — A block x and the window's newest
+// block x + d0 + 15 — are requested kBandPF steps ahead into slot (x - i0) % kBandNS and read into registers
+// during step x - 1.
+__device__ __forceinline__ void band_visit(const BandSrc& src, band_d2* ring, int d0, int i0, int i1, band_d4 (&acc)[16]) {
+    static_assert(16 % kBandNS == 0 && kBandNS >= 2 * kBandPF && kBandPF >= 1, "slots are indexed by the unrolled step");
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)ring);  // LDS byte address
+    band_d2 W[16];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) src.request(W[d], i0 + d0 + d);
-    src.request(a[1], i0 + 1);
-    src.request(a[2], i0 + 2);
-    TA_BAND_WAIT(0, a[2]);
+    for (int d = 0; d < 15; ++d) W[d] = src.load_now(i0 + d0 + d);
 #pragma unroll
-    for (int d = 0; d < 16; ++d) TA_BAND_WAIT(0, W[d]);
-    TA_BAND_WAIT(0, a[0]);
-    TA_BAND_WAIT(0, a[1]);
+    for (int s = 0; s < kBandPF; ++s) src.request_step(ring_addr, s % kBandNS, i0 + s, d0 + 15);
+    TA_BAND_WAIT(2 * (kBandPF - 1));
+    band_d2 anext = ring[lane], wnext = ring[64 + lane];
     int I = i0;
-    for (;;) {
+    for (bool more = true; more;) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            // window slot (j + d) & 15 holds F_{I + d0 + d}; the newest one (d = 15) is used last
-            src.request(a[(j + 3) & 3], I + 3);
-            TA_BAND_WAIT(6, a[j & 3]);
-            const band_d2 A = a[j & 3];
+            // window slot (j + d) & 15 holds F_{I + d0 + d}
+            const band_d2 A = anext;
+            W[(j + 15) & 15] = wnext;
+            src.request_step(ring_addr, (j + kBandPF) % kBandNS, I + kBandPF, d0 + 15);
+            TA_BAND_WAIT(2 * (kBandPF - 1));  // the requests of step I + 1 have landed
+            anext = ring[128 * ((j + 1) % kBandNS) + lane];
+            wnext = ring[128 * ((j + 1) % kBandNS) + 64 + lane];
 #pragma unroll
-            for (int d = 0; d < 15; ++d) acc[d] = TA_BAND_MFMA(A.x, W[(j + d) & 15].x, acc[d]);
-            acc[0] = TA_BAND_MFMA(A.y, W[j].y, acc[0]);
-            src.request(W[j], I + d0 + 16);  // slot of d = 0 is free: next step's d = 15
+            for (int d = 0; d < 16; ++d) acc[d] = TA_BAND_MFMA(A.x, W[(j + d) & 15].x, acc[d]);
 #pragma unroll
-            for (int d = 1; d < 15; ++d) acc[d] = TA_BAND_MFMA(A.y, W[(j + d) & 15].y, acc[d]);
-            __builtin_amdgcn_sched_barrier(0);  // or the wait moves up to the request above
-            TA_BAND_WAIT(2, W[(j + 15) & 15]);
-            acc[15] = TA_BAND_MFMA(A.x, W[(j + 15) & 15].x, acc[15]);
-            acc[15] = TA_BAND_MFMA(A.y, W[(j + 15) & 15].y, acc[15]);
-            if (++I == i1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                return;
+            for (int d = 0; d < 16; ++d) acc[d] = TA_BAND_MFMA(A.y, W[(j + d) & 15].y, acc[d]);
+            if (++I == i1) {  // one common tail
+                more = false;
+                break;
             }
         }
     }
+    TA_BAND_WAIT(0);  // the requests past the piece: the ring is reused by the next visit
 }
 
 // ---- Einstein-Helfand form: sum over column c of (P[i,c] - P[j,c])^2 for every pair of frames --------
@@ -295,31 +307,33 @@ struct BandHelf {
     }
 };
 
-// In flight when step I starts (A operand one step ahead, ring of two): A_I, Wn_{I-1}, A_{I+1}.
 // The reference row (frame 16 I of every column, every kBandRef steps) is lane i = 0 of the A fragment itself.
-__device__ __forceinline__ void band_visit_helfand(const BandSrc& src, int d0, int i0, int i1, band_d4 (&acc)[16], double& na) {
+// Requests and the ring: as band_visit.
+__device__ __forceinline__ void band_visit_helfand(const BandSrc& src, band_d2* ring, int d0, int i0, int i1, band_d4 (&acc)[16],
+                                                   double& na) {
     const BandHelf h{src.T, src.i, src.slot};
-    band_d2 W[16], a[2], r;
-    src.request(a[0], i0);
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)ring);
+    band_d2 W[16], r;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) src.request(W[d], i0 + d0 + d);
-    TA_BAND_WAIT(0, a[0]);
+    for (int d = 0; d < 15; ++d) W[d] = src.load_now(i0 + d0 + d);
 #pragma unroll
-    for (int d = 0; d < 16; ++d) TA_BAND_WAIT(0, W[d]);
-    r = h.first_row(a[0]);
+    for (int s = 0; s < kBandPF; ++s) src.request_step(ring_addr, s % kBandNS, i0 + s, d0 + 15);
+    TA_BAND_WAIT(2 * (kBandPF - 1));
+    band_d2 anext = ring[lane], wnext = ring[64 + lane];
+    r = h.first_row(anext);
 #pragma unroll
     for (int d = 0; d < 15; ++d) {  // (the 16th is prepared by the first step, like every step's newest)
         W[d] = h.prep_b(W[d], r, i0 + d0 + d);
         if (d % 3 == 2) __builtin_amdgcn_sched_barrier(0);  // three chains at a time: registers
     }
     int I = i0;
-    for (;;) {
+    for (bool more = true; more;) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            src.request(a[(j + 1) & 1], I + 1);
-            TA_BAND_WAIT(2, a[j & 1]);
+            // this step's operands from the rows read during the previous step ...
             if (TA_BAND_ABL == 0 && j % kBandRef == 0 && I != i0) {  // new reference: the 15 older window fragments follow it
-                const band_d2 rn = h.first_row(a[j & 1]);
+                const band_d2 rn = h.first_row(anext);
                 const band_d2 delta = r - rn;
                 r = rn;
 #pragma unroll
@@ -329,26 +343,26 @@ __device__ __forceinline__ void band_visit_helfand(const BandSrc& src, int d0, i
                 }
             }
             band_d2 A;
-            if (TA_BAND_ABL >= 2) A = a[j & 1];
-            else if (16 * (I + d0 + 16) <= src.T) A = h.prep_a_bulk(a[j & 1], r, na);
-            else A = h.prep_a_edge(a[j & 1], r, I);
+            if (TA_BAND_ABL >= 2) A = anext;
+            else if (16 * (I + d0 + 16) <= src.T) A = h.prep_a_bulk(anext, r, na);
+            else A = h.prep_a_edge(anext, r, I);
+            W[(j + 15) & 15] = TA_BAND_ABL < 2 ? h.prep_b(wnext, r, I + d0 + 15) : wnext;
+            // ... then the next step's rows leave the ring (their latency is this step's MFMAs)
+            src.request_step(ring_addr, (j + kBandPF) % kBandNS, I + kBandPF, d0 + 15);
+            TA_BAND_WAIT(2 * (kBandPF - 1));
+            anext = ring[128 * ((j + 1) % kBandNS) + lane];
+            wnext = ring[128 * ((j + 1) % kBandNS) + 64 + lane];
 #pragma unroll
-            for (int d = 0; d < 15; ++d) acc[d] = TA_BAND_MFMA(A.x, W[(j + d) & 15].x, acc[d]);
-            acc[0] = TA_BAND_MFMA(A.y, W[j].y, acc[0]);
-            src.request(W[j], I + d0 + 16);
+            for (int d = 0; d < 16; ++d) acc[d] = TA_BAND_MFMA(A.x, W[(j + d) & 15].x, acc[d]);
 #pragma unroll
-            for (int d = 1; d < 15; ++d) acc[d] = TA_BAND_MFMA(A.y, W[(j + d) & 15].y, acc[d]);
-            __builtin_amdgcn_sched_barrier(0);
-            TA_BAND_WAIT(2, W[(j + 15) & 15]);
-            if (TA_BAND_ABL < 2) W[(j + 15) & 15] = h.prep_b(W[(j + 15) & 15], r, I + d0 + 15);
-            acc[15] = TA_BAND_MFMA(A.x, W[(j + 15) & 15].x, acc[15]);
-            acc[15] = TA_BAND_MFMA(A.y, W[(j + 15) & 15].y, acc[15]);
+            for (int d = 0; d < 16; ++d) acc[d] = TA_BAND_MFMA(A.y, W[(j + d) & 15].y, acc[d]);
             if (++I == i1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                return;
+                more = false;
+                break;
             }
         }
     }
+    TA_BAND_WAIT(0);
 }
 
 // pm: pair-major float64 slab (layout.hip).  grid: n_labels * (slots / 8) workgroups of 512.
@@ -361,6 +375,7 @@ __global__ void __launch_bounds__(512)
     // per wave: one accumulator block as [m][n] with a row stride of 17, and the 16 x 31 diagonal sums
     // (LDS operations of one wave complete in order: wave_barrier only pins the compiler's order)
     __shared__ double red[8][272 + 16 * 32];
+    __shared__ band_d2 rings[8][kBandNS * 128];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int label = blockIdx.x % n_labels;
     const int slot = (blockIdx.x / n_labels) * 8 + wave;
@@ -384,16 +399,17 @@ __global__ void __launch_bounds__(512)
             BandSrc src;
             const unsigned long long base = reinterpret_cast<unsigned long long>(pm + kPairs * o * pitch * 2);
             // raw buffer resource: base, stride 0, num_records in bytes, the gfx9 data format word
-            src.rs = band_u4{(unsigned)base, (unsigned)(base >> 32) & 0xffffu,
-                             (unsigned)((left < kPairs ? left : kPairs) * pitch) * 16u, 0x00020000u};
+            const unsigned n_bytes = (unsigned)((left < kPairs ? left : kPairs) * pitch) * 16u;
+            src.rs = band_u4{(unsigned)base, (unsigned)(base >> 32) & 0xffffu, n_bytes, 0x00020000u};
+            src.crs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pm + kPairs * o * pitch * 2), 0, (int)n_bytes, 0x00020000);
             // (Helfand form: the fourth lane group reads just past the resource's last byte: zeros)
             src.lane_off = (unsigned)(kk * pitch + (lane & 15)) * 16u;
             if (HELF && kk == 3) src.lane_off = (unsigned)(3 * pitch) * 16u + (unsigned)(lane & 15) * 16u;
             src.T = T;
             src.i = lane & 15;
             src.slot = HELF && kk == 3;
-            if constexpr (HELF) band_visit_helfand(src, d0, i0, i1, acc, na);
-            else band_visit(src, d0, i0, i1, acc);
+            if constexpr (HELF) band_visit_helfand(src, rings[wave], d0, i0, i1, acc, na);
+            else band_visit(src, rings[wave], d0, i0, i1, acc);
         }
         // diagonals: acc[d] register r of lane l is C_d[m = 4 r + (l >> 4)][n = l & 15], lag 16 (d0 + d) + n - m
         double na_m[4] = {0.0, 0.0, 0.0, 0.0};
