@@ -83,7 +83,9 @@ int ta_abi_version(void);
  * frames [frame_lo, frame_hi) of every slab host->device asynchronously in
  * their native width (<= 64 MiB pieces) and transposes them into the device
  * slabs there (the transposition of one piece runs while the next one crosses
- * PCIe).  Frames never committed read as zeros (np.zeros in the reference).
+ * PCIe).  The rows of a committed range must not be written again before the next compute / ta_stage_* call
+ * on the context has returned (the copies are asynchronous, and by default queued to a worker thread:
+ * option "async_commit").  Frames never committed read as zeros (np.zeros in the reference).
  * ta_stage_alloc_device: device slabs only, for data that is already on the
  * GPU; fill them with ta_stage_commit_dev (frame-major float32/float64 rows
  * [frame_lo, frame_hi) at d_src, row stride ld_row elements; asynchronous on
@@ -96,6 +98,22 @@ int ta_stage_alloc(ta_ctx *ctx, int64_t n_frames, int64_t n_atoms, int dim, int 
                    int n_slabs, void **h_slabs);
 int ta_stage_alloc_device(ta_ctx *ctx, int64_t n_frames, int64_t n_atoms, int dim, int n_slabs);
 int ta_stage_commit(ta_ctx *ctx, int64_t frame_lo, int64_t frame_hi);
+/* The per-frame fill itself, natively: replaces
+ *     self._velocities[i] = self.atomgroup.velocities[:, self._dim]        (velocityautocorr.py:192-194,
+ *     viscosity.py:189-199; `atomgroup.velocities` is a gather ts.velocities[atomgroup.ix] into a temporary)
+ * by ONE pass from the Timestep's own array into row `frame` of pinned slab `slab`:
+ *     slab[frame, a, k] = (slab dtype) h_src[row(a) * ld_row + col0 + k * col_step],   a < n_atoms, k < n_col,
+ *     row(a) = h_index ? h_index[a] : atom_lo + a
+ * h_src: the frame's (n_atoms_universe, ld_row) float32 / float64 (src_dtype) rows, ld_row = 3 for an MDAnalysis
+ * Timestep; n_col and n_atoms must equal the slab's dim and atom count.  The copy runs on a few host threads
+ * ($TA_AMD_STAGE_THREADS, default 4 including the caller; ta_stage_threads() says how many); a ctypes caller's
+ * GIL is released meanwhile.  ta_group_stage_frame: the same into every member's slab, member i taking atoms
+ * [lo_i, hi_i) of the n_atoms (h_index + lo_i, or atom_lo + lo_i).  Callers keep the reference's guards
+ * (ts.has_velocities etc.) in front of it; a source that is not a dense float array is staged through the
+ * NumPy view of ta_stage_alloc instead.                                                        */
+int ta_stage_frame(ta_ctx *ctx, int slab, int64_t frame, const void *h_src, int src_dtype, int64_t ld_row,
+                   int col0, int col_step, int n_col, int64_t atom_lo, const int64_t *h_index, int64_t n_atoms);
+int ta_stage_threads(void);
 int ta_stage_commit_dev(ta_ctx *ctx, int slab, const void *d_src, int dtype, int64_t ld_row,
                         int64_t frame_lo, int64_t frame_hi, void *stream);
 int ta_stage_read_dev(ta_ctx *ctx, int slab, double *d_dst, int64_t ld_row, void *stream);
@@ -215,6 +233,8 @@ int ta_group_set_option(ta_group *g, const char *key, int64_t value);
 int ta_group_stage_alloc(ta_group *g, int64_t n_frames, int64_t n_atoms, int dim, int dtype,
                          int n_slabs, void **h_slabs);
 int ta_group_stage_commit(ta_group *g, int64_t frame_lo, int64_t frame_hi);
+int ta_group_stage_frame(ta_group *g, int slab, int64_t frame, const void *h_src, int src_dtype, int64_t ld_row,
+                         int col0, int col_step, int n_col, int64_t atom_lo, const int64_t *h_index, int64_t n_atoms);
 /* device slabs only + the benchmark generator on every member's columns of the one synthetic
  * tensor (member i: col_offset + lo_i * dim), as ta_stage_alloc_device / ta_stage_synth          */
 int ta_group_stage_alloc_device(ta_group *g, int64_t n_frames, int64_t n_atoms, int dim, int n_slabs);
@@ -309,7 +329,12 @@ int ta_band_plan_info(int64_t n_frames, int n_cu, int *n_pieces, int *octets_in_
  *   "bp_prefetch" 0..3 : sub-series of the next atom's spectrum the inverse kernel requests
  *                      ahead (default 2);
  *   "timeline" 0|1   : record an event before every kernel launch of a compute call
- *                      (ta_kernel_timeline).   Unknown keys return TA_E_INVALID.          */
+ *                      (ta_kernel_timeline);
+ *   "async_commit" 1|0 : ta_stage_commit hands its frame range to a worker thread of the context, which
+ *                      makes the HIP calls (the caller's frame loop never waits on the runtime, e.g. while
+ *                      another thread page-locks a result array); every call that touches the slabs joins
+ *                      the queue first and returns a queued commit's error.  0: the calls are made by
+ *                      ta_stage_commit itself.   Unknown keys return TA_E_INVALID.          */
 int ta_set_option(ta_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

@@ -18,7 +18,7 @@ def test_library_exports_header_symbols():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ta_abi_version() == 4
+    assert L.ta_abi_version() == 5
 
 
 def test_no_cpu_fallback():

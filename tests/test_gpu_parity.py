@@ -1391,3 +1391,66 @@ def test_stage_commit_through_both_landing_buffers(ctx):
     assert ts[0] == pytest.approx((keep * keep).sum() / (T * A), rel=1e-12)
     assert ts[T - 1] == pytest.approx((keep[0] * keep[T - 1]).sum() / A, rel=1e-10, abs=1e-12 * abs(ref))
     ctx.stage_free()
+
+
+# ------------------------------------------------------------------ native per-frame staging
+@pytest.mark.parametrize("src_dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("stage_dtype", [np.float32, np.float64])
+def test_stage_frame_native_equals_numpy_fill(ctx, src_dtype, stage_dtype):
+    """ta_stage_frame (the reference's `slab[i] = atomgroup.velocities[:, dim]`, velocityautocorr.py:192-194,
+    as one native pass from the Timestep's array): every dim_type's columns, a block of consecutive atoms
+    and a gather by index, float32 / float64 on both sides, a padded source row — bit-equal to the NumPy
+    expression, frame by frame, through several threads' chunks (70000 atoms) and below one chunk."""
+    from transport_analysis_amd import _lib
+
+    rng = np.random.default_rng(11)
+    for n_univ, ld in ((70001, 3), (300, 4)):
+        wide = rng.standard_normal((n_univ, ld)).astype(src_dtype)
+        frame_arr = wide[:, :3] if ld == 4 else wide  # (ld 4: rows padded, as a view of a wider array)
+        for cols in ([0], [1], [2], [0, 1], [0, 2], [1, 2], [0, 1, 2]):
+            for ix in (np.arange(5, n_univ - 7), rng.permutation(n_univ)[: n_univ // 2], np.array([n_univ - 1])):
+                n = len(ix)
+                (slab,) = ctx.stage_alloc(3, n, len(cols), n_slabs=1, dtype=stage_dtype)
+                src = _lib.frame_source(frame_arr)
+                assert src is not None and src[2] == ld
+                ctx.stage_frame(0, 1, src, cols, _lib.atom_rows(ix))
+                want = frame_arr[ix][:, cols].astype(stage_dtype)
+                assert np.array_equal(slab[1], want)
+                assert not slab[0].any() and not slab[2].any()  # only the frame asked for
+    assert _lib.frame_source(np.zeros((4, 3), dtype=np.float32)[:, ::-1]) is None  # negative stride: NumPy path
+    assert _lib.frame_source(np.zeros((4, 3), dtype=np.int32)) is None
+    with pytest.raises(_lib.TAError):  # a slab of 2 columns cannot take 3
+        (slab,) = ctx.stage_alloc(2, 5, 2, n_slabs=1)
+        ctx.stage_frame(0, 0, _lib.frame_source(np.zeros((9, 3))), [0, 1, 2], _lib.atom_rows(np.arange(5)))
+    ctx.stage_free()
+
+
+@pytest.mark.parametrize("subset", [False, True])
+def test_classes_native_and_numpy_staging_bit_equal(subset, monkeypatch):
+    """Both classes stage every frame through ta_stage_frame (from ts.velocities / ts.positions, gathering
+    by the group's atom indices) and, with $TA_AMD_NATIVE_STAGING=0, through the NumPy views as before: the
+    staged slabs and every result are bit-equal; a sub-group that is not a block of consecutive atoms takes
+    the index path; devices=[0, 0] fills both members' slabs from one call."""
+    from oracle import numpy_oracle as orc
+    from transport_analysis_amd import VelocityAutocorr, ViscosityHelfand
+    from transport_analysis_amd._mini_mda import ArrayUniverse
+
+    T, A = 300, 41
+    v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=5)
+    u = ArrayUniverse(positions=x.astype(np.float32), velocities=v.astype(np.float32), masses=m,
+                      dimensions=[60, 60, 60, 90, 90, 90])
+    ag = u.atoms[np.array([3, 4, 9, 1, 30, 17, 18, 19])] if subset else u.atoms
+    out = {}
+    for native in ("1", "0"):
+        monkeypatch.setenv("TA_AMD_NATIVE_STAGING", native)
+        a = VelocityAutocorr(ag, dim_type="xz", fft=True).run()
+        assert (a._rows is not None) == (native == "1")
+        h = ViscosityHelfand(ag).run()
+        g = VelocityAutocorr(ag, fft=False, devices=[0, 0]).run()
+        out[native] = (np.array(a._velocities), a.results.timeseries, a.results.vacf_by_particle,
+                       np.array(h._velocities), np.array(h._positions), h.results.timeseries, h.results.visc_by_particle,
+                       np.concatenate([np.array(s) for s in g._velocities if s is not None], axis=1), g.results.timeseries)
+    for got, want in zip(out["1"], out["0"]):
+        assert np.array_equal(got, want)
+    if subset:
+        assert out["1"][0].shape == (T, 8, 2)

@@ -139,3 +139,46 @@ def stage_columns(dst, src, lo, hi, dim):
         dst[:n] = src[lo:hi, dim[0]:dim[-1] + 1:step]
     else:  # not reachable from parse_dim_type's table
         dst[:n] = src[lo:hi][:, dim]
+
+
+def native_rows(group):
+    """How ta_stage_frame finds the group's atoms in a Timestep's arrays: (first atom, index array or None,
+    count, largest index) from MDAnalysis' ``AtomGroup.ix`` (the stand-in's ``indices``); None when the
+    group has neither or $TA_AMD_NATIVE_STAGING=0 (the frames are then staged through NumPy views)."""
+    import os
+
+    from . import _lib
+
+    if os.environ.get("TA_AMD_NATIVE_STAGING", "1") == "0":
+        return None
+    ix = getattr(group, "ix", None)
+    if ix is None:
+        ix = getattr(group, "indices", None)
+    if ix is None:
+        return None
+    ix = np.asarray(ix)
+    if ix.ndim != 1 or ix.size == 0 or not np.issubdtype(ix.dtype, np.integer) or int(ix.min()) < 0:
+        return None
+    lo, index, n = _lib.atom_rows(ix)
+    return (lo, index, n), int(ix.max())
+
+
+def stage_frame_native(ctx, slab, frame, ts, attr, cols, rows):
+    """slab[frame] = ts.<attr>[group's atoms][:, cols] in one native pass (ta_stage_frame: gather, column
+    selection, conversion, on a few host threads, GIL released) -- what the reference's
+    ``self.atomgroup.<attr>[:, self._dim]`` computes through two temporaries
+    (velocityautocorr.py:192-194, viscosity.py:189-199).  False when the Timestep's array is not
+    something the native call can read in place (the caller falls back to the NumPy path)."""
+    from . import _lib
+
+    if rows is None or not hasattr(ctx, "stage_frame"):
+        return False
+    try:
+        arr = getattr(ts, attr)
+    except Exception:
+        return False
+    src = _lib.frame_source(arr)
+    if src is None or rows[1] >= arr.shape[0] or cols[-1] >= arr.shape[1]:
+        return False
+    ctx.stage_frame(slab, frame, src, cols, rows[0])
+    return True

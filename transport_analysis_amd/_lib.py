@@ -20,7 +20,7 @@ TA_F32, TA_F64 = 0, 1
 #: every symbol include/ta_hip.h declares
 EXPORTS = (
     "ta_abi_version", "ta_device_count", "ta_last_error", "ta_ctx_create", "ta_ctx_destroy",
-    "ta_stage_alloc", "ta_stage_alloc_device", "ta_stage_commit", "ta_stage_commit_dev",
+    "ta_stage_alloc", "ta_stage_alloc_device", "ta_stage_commit", "ta_stage_frame", "ta_stage_threads", "ta_stage_commit_dev",
     "ta_stage_read_dev", "ta_stage_device", "ta_stage_free", "ta_stage_synth", "ta_trim",
     "ta_vacf_fft", "ta_vacf_direct", "ta_helfand_msd",
     "ta_vacf_fft_dev", "ta_vacf_direct_dev", "ta_helfand_msd_dev",
@@ -30,7 +30,7 @@ EXPORTS = (
     "ta_host_alloc", "ta_host_alloc_on", "ta_host_free",
     "ta_group_create", "ta_group_destroy", "ta_group_last_error", "ta_group_size", "ta_group_member",
     "ta_group_shard", "ta_group_reduce_kind", "ta_group_reduce_note", "ta_group_rccl_ranks", "ta_group_set_option", "ta_group_stage_alloc",
-    "ta_group_stage_commit", "ta_group_stage_free", "ta_group_stage_alloc_device", "ta_group_stage_synth", "ta_group_vacf_fft", "ta_group_vacf_direct",
+    "ta_group_stage_commit", "ta_group_stage_frame", "ta_group_stage_free", "ta_group_stage_alloc_device", "ta_group_stage_synth", "ta_group_vacf_fft", "ta_group_vacf_direct",
     "ta_group_helfand_msd",
 )
 
@@ -100,6 +100,8 @@ def lib():
     L.ta_ctx_destroy.argtypes = [vp]
     L.ta_stage_alloc.argtypes = [vp, i64, i64, ci, ci, ci, ctypes.POINTER(vp)]
     L.ta_stage_commit.argtypes = [vp, i64, i64]
+    L.ta_stage_frame.argtypes = [vp, ci, i64, vp, ci, i64, ci, ci, ci, i64, vp, i64]
+    L.ta_group_stage_frame.argtypes = [vp, ci, i64, vp, ci, i64, ci, ci, ci, i64, vp, i64]
     L.ta_stage_alloc_device.argtypes = [vp, i64, i64, ci, ci]
     L.ta_stage_commit_dev.argtypes = [vp, ci, vp, ci, i64, i64, i64, vp]
     L.ta_stage_read_dev.argtypes = [vp, ci, vp, i64, vp]
@@ -179,6 +181,32 @@ def band_plan_info(n_frames, n_cu=256):
 
 def _ptr(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else ctypes.c_void_p(None)
+
+
+def frame_source(arr):
+    """(pointer, dtype code, ld_row) of a frame's (n_atoms, n_coord) array if ta_stage_frame can read it in
+    place -- float32 / float64, unit stride along the coordinates, a non-negative whole-element row stride --
+    else None (the caller then stages through the NumPy view of the slab)."""
+    if not isinstance(arr, np.ndarray) or arr.ndim != 2 or arr.dtype not in (np.float32, np.float64):
+        return None
+    isz = arr.dtype.itemsize
+    if arr.shape[1] > 1 and arr.strides[1] != isz:
+        return None
+    if arr.strides[0] < isz * arr.shape[1] or arr.strides[0] % isz:
+        return None
+    return arr.ctypes.data, (TA_F32 if arr.dtype == np.float32 else TA_F64), arr.strides[0] // isz
+
+
+def atom_rows(ix):
+    """(atom_lo, index array or None, n) for ta_stage_frame from an AtomGroup's atom indices: a group of
+    consecutive atoms is a block (no index array), anything else is gathered by index."""
+    ix = np.ascontiguousarray(ix, dtype=np.int64)
+    n = int(ix.size)
+    if n == 0:
+        return 0, None, 0
+    if int(ix[-1]) - int(ix[0]) + 1 == n and (n == 1 or bool(np.all(np.diff(ix) == 1))):
+        return int(ix[0]), None, n
+    return 0, ix, n
 
 
 class _PinnedBlock:
@@ -321,6 +349,15 @@ class Context:
 
     def stage_commit(self, frame_lo, frame_hi):
         self._check(lib().ta_stage_commit(self._h, int(frame_lo), int(frame_hi)))
+
+    def stage_frame(self, slab, frame, source, cols, rows):
+        """slab[frame] = source[rows][:, cols] natively (ta_stage_frame).  source: frame_source(...) of the
+        Timestep's array; cols: the dim_type's column list (an arithmetic progression); rows: atom_rows(...)."""
+        ptr, code, ld = source
+        lo, index, n = rows
+        step = cols[1] - cols[0] if len(cols) > 1 else 1
+        self._check(lib().ta_stage_frame(self._h, int(slab), int(frame), ctypes.c_void_p(ptr), code, int(ld), int(cols[0]),
+                                         int(step), len(cols), int(lo), _ptr(index), int(n)))
 
     def stage_alloc_device(self, n_frames, n_atoms, dim, n_slabs=1):
         """Device slabs only (pair-major), for data that is already on the GPU."""
@@ -554,6 +591,14 @@ class Group:
 
     def stage_commit(self, frame_lo, frame_hi):
         self._check(lib().ta_group_stage_commit(self._h, int(frame_lo), int(frame_hi)))
+
+    def stage_frame(self, slab, frame, source, cols, rows):
+        """every member's slab[frame] = its atoms of source[rows][:, cols] (ta_group_stage_frame)"""
+        ptr, code, ld = source
+        lo, index, n = rows
+        step = cols[1] - cols[0] if len(cols) > 1 else 1
+        self._check(lib().ta_group_stage_frame(self._h, int(slab), int(frame), ctypes.c_void_p(ptr), code, int(ld),
+                                               int(cols[0]), int(step), len(cols), int(lo), _ptr(index), int(n)))
 
     def stage_alloc_device(self, n_frames, n_atoms, dim, n_slabs=1):
         self._drop_views()

@@ -123,6 +123,12 @@ class ArrayUniverse:
 
     def __init__(self, positions=None, velocities=None, masses=None, dimensions=None, dt=1.0,
                  n_atoms=None, n_frames=None):
+        # like an MDAnalysis Timestep, the trajectory holds float32 coordinates: ts.velocities / ts.positions
+        # and AtomGroup.velocities / .positions hand out the same values (no copy when float32 came in)
+        if positions is not None:
+            positions = np.ascontiguousarray(positions, dtype=np.float32)
+        if velocities is not None:
+            velocities = np.ascontiguousarray(velocities, dtype=np.float32)
         ref = positions if positions is not None else velocities
         if ref is None:
             if n_atoms is None or n_frames is None:

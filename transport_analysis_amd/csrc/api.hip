@@ -4,9 +4,13 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ta_hip.h"
@@ -81,7 +85,23 @@ struct ta_ctx {
     int64_t opt_bp_spec_atoms = 0;
     int64_t opt_bp_prefetch = 2;
     int64_t opt_stage_device_f32 = 0;
+    // ta_stage_commit hands its frame range to a worker thread that makes the HIP calls (copies in pieces, the
+    // transposition launches): the caller's frame loop never waits on the runtime — which it did, for as long
+    // as another thread's hipHostMalloc of the by-particle result held the runtime's lock (0.17 s of a 0.6 s
+    // loop at 10000 x 50000 x 3).  Everything that touches the slabs or the streams joins the queue first
+    // (commit_flush); an error of a queued commit is returned there.
+    int64_t opt_async_commit = 1;
+    std::thread cq_thread;
+    std::mutex cq_m;
+    std::condition_variable cq_cv;
+    std::deque<std::pair<int64_t, int64_t>> cq;
+    bool cq_stop = false, cq_busy = false;
+    int cq_rc = TA_OK;
+    std::string cq_err;
 };
+
+int commit_flush(ta_ctx* ctx);  // (defined with ta_stage_commit)
+static void commit_stop(ta_ctx* ctx);
 
 namespace {
 
@@ -525,6 +545,7 @@ int dev_entry(ta_ctx* ctx, int which, const double* d_vel, const double* d_pos, 
 // frames committed by ta_stage_commit travel on the context's own stream: a caller's stream that
 // is about to touch the slabs waits for them (a no-op when nothing is pending)
 int order_after_staging(ta_ctx* ctx, hipStream_t st) {
+    if (int rc = commit_flush(ctx)) return rc;  // queued commits have made their calls on ctx->stream
     if (st == ctx->stream) return TA_OK;
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev_stage, ctx->stream));
     TA_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_stage, 0));
@@ -550,7 +571,7 @@ int staged_entry(ta_ctx* ctx, int which, const double* d_masses, double scale, d
 
 extern "C" {
 
-int ta_abi_version(void) { return 4; }
+int ta_abi_version(void) { return 5; }
 
 int ta_device_count(void) {
     int n = 0;
@@ -593,6 +614,7 @@ int ta_ctx_create(int device, ta_ctx** out) {
 
 int ta_stage_free(ta_ctx* ctx) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    (void)commit_flush(ctx);  // (an error of a commit into slabs that are going away is dropped with them)
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->relayout_stream) hipStreamSynchronize(ctx->relayout_stream);
@@ -609,6 +631,8 @@ int ta_stage_free(ta_ctx* ctx) {
 
 int ta_ctx_destroy(ta_ctx* ctx) {
     if (!ctx) return TA_OK;
+    (void)commit_flush(ctx);
+    commit_stop(ctx);
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ta_stage_free(ctx);
@@ -637,6 +661,7 @@ int ta_ctx_destroy(ta_ctx* ctx) {
 
 int ta_trim(ta_ctx* ctx) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    if (int rc = commit_flush(ctx)) return rc;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
     band_cache_free(ctx->band);
@@ -666,6 +691,10 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "bp_prefetch")) ctx->opt_bp_prefetch = value;
     else if (!strcmp(key, "stage_device_f32")) ctx->opt_stage_device_f32 = value;
     else if (!strcmp(key, "timeline")) ctx->opt_timeline = value;
+    else if (!strcmp(key, "async_commit")) {
+        if (int rc = commit_flush(ctx)) return rc;
+        ctx->opt_async_commit = value;
+    }
     else return fail(ctx, TA_E_INVALID, std::string("unknown option ") + key);
     return TA_OK;
 }
@@ -735,7 +764,7 @@ static int stage_alloc_common(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, in
             ta_stage_free(ctx);
             return fail(ctx, TA_E_NOMEM, std::string("staging allocation failed: ") + hipGetErrorString(e));
         }
-        if (h) memset(h, 0, n * esz);  // the reference starts from np.zeros (velocityautocorr.py:150)
+        if (h) host_zero(h, n * esz);  // the reference starts from np.zeros (velocityautocorr.py:150)
         ctx->h_slabs.push_back(h);
         ctx->d_slabs.push_back(d);
         // frames never committed read as zeros, like the reference's np.zeros slab
@@ -764,7 +793,9 @@ int ta_stage_alloc_device(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, int di
     return stage_alloc_common(ctx, n_frames, n_atoms, dim, TA_F64, n_slabs, nullptr);
 }
 
-int ta_stage_commit(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
+}  // extern "C"
+
+static int stage_commit_now(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     if (ctx->st_nslabs == 0) return fail(ctx, TA_E_STATE, "ta_stage_alloc has not been called");
     if (frame_lo < 0 || frame_hi > ctx->st_T || frame_lo > frame_hi)
@@ -813,6 +844,73 @@ int ta_stage_commit(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
     // whatever follows on the context's stream sees the transposed frames
     for (int b = 0; b < 2; ++b)
         if (used[b]) TA_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_done[b], 0));
+    return TA_OK;
+}
+
+static void commit_worker(ta_ctx* ctx) {
+    (void)hipSetDevice(ctx->device);
+    std::unique_lock<std::mutex> lk(ctx->cq_m);
+    for (;;) {
+        ctx->cq_cv.wait(lk, [&] { return ctx->cq_stop || !ctx->cq.empty(); });
+        if (ctx->cq.empty()) return;  // stop requested and nothing left
+        const auto job = ctx->cq.front();
+        ctx->cq.pop_front();
+        ctx->cq_busy = true;
+        lk.unlock();
+        const int rc = stage_commit_now(ctx, job.first, job.second);
+        lk.lock();
+        if (rc && ctx->cq_rc == TA_OK) ctx->cq_rc = rc, ctx->cq_err = ctx->err;  // the first failure is the one reported
+        ctx->cq_busy = false;
+        ctx->cq_cv.notify_all();
+    }
+}
+
+// every queued commit has made its HIP calls (their work is queued on the context's streams); returns the
+// first error one of them hit
+int commit_flush(ta_ctx* ctx) {
+    if (!ctx->cq_thread.joinable()) return TA_OK;
+    std::unique_lock<std::mutex> lk(ctx->cq_m);
+    ctx->cq_cv.wait(lk, [&] { return ctx->cq.empty() && !ctx->cq_busy; });
+    const int rc = ctx->cq_rc;
+    if (rc) {
+        const std::string msg = ctx->cq_err;
+        ctx->cq_rc = TA_OK;
+        lk.unlock();
+        return fail(ctx, rc, "queued ta_stage_commit: " + msg);
+    }
+    return TA_OK;
+}
+
+static void commit_stop(ta_ctx* ctx) {
+    if (!ctx->cq_thread.joinable()) return;
+    {
+        std::lock_guard<std::mutex> lk(ctx->cq_m);
+        ctx->cq_stop = true;
+    }
+    ctx->cq_cv.notify_all();
+    ctx->cq_thread.join();
+    ctx->cq_stop = false;
+}
+
+extern "C" {
+
+int ta_stage_commit(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
+    if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    if (ctx->st_nslabs == 0) return fail(ctx, TA_E_STATE, "ta_stage_alloc has not been called");
+    if (frame_lo < 0 || frame_hi > ctx->st_T || frame_lo > frame_hi)
+        return fail(ctx, TA_E_INVALID, "frame range out of bounds");
+    if (!ctx->h_slabs[0]) return fail(ctx, TA_E_STATE, "device-only slabs: use ta_stage_commit_dev");
+    if (frame_hi == frame_lo) return TA_OK;
+    if (!ctx->opt_async_commit) {
+        if (int rc = commit_flush(ctx)) return rc;
+        return stage_commit_now(ctx, frame_lo, frame_hi);
+    }
+    if (!ctx->cq_thread.joinable()) ctx->cq_thread = std::thread(commit_worker, ctx);
+    {
+        std::lock_guard<std::mutex> lk(ctx->cq_m);
+        ctx->cq.emplace_back(frame_lo, frame_hi);
+    }
+    ctx->cq_cv.notify_all();
     return TA_OK;
 }
 
@@ -1084,6 +1182,13 @@ hipStream_t ctx_stream(ta_ctx* ctx) { return ctx->stream; }
 int ctx_device(const ta_ctx* ctx) { return ctx->device; }
 int64_t ctx_staged_frames(const ta_ctx* ctx) { return ctx->st_nslabs ? ctx->st_T : 0; }
 int ctx_fail(ta_ctx* ctx, int code, const std::string& msg) { return fail(ctx, code, msg); }
+int ctx_host_slab(ta_ctx* ctx, int slab, void** h, int64_t* T, int64_t* A, int* D, int* dtype) {
+    if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
+    if (!ctx->h_slabs[slab]) return fail(ctx, TA_E_STATE, "device-only slabs have no host side to fill");
+    *h = ctx->h_slabs[slab], *T = ctx->st_T, *A = ctx->st_A, *D = ctx->st_D, *dtype = ctx->st_dtype;
+    return TA_OK;
+}
 }  // namespace ta
 
 extern "C" {

@@ -22,6 +22,7 @@ hipStream_t ctx_stream(ta_ctx* ctx);
 int ctx_device(const ta_ctx* ctx);
 int64_t ctx_staged_frames(const ta_ctx* ctx);
 int ctx_fail(ta_ctx* ctx, int code, const std::string& msg);  // records the message, returns code
+void host_zero(void* p, size_t bytes);  // stage_host.hip: memset 0 on several threads, streaming stores
 
 // direct.hip
 // vel / pos: pair-major slabs (layout.hip) of `pitch` rows per pair, float64 or (src_f32, with the

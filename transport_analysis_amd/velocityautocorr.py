@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 from . import _lib
-from ._base import stage_columns, AnalysisBase, NoDataError, UpdatingAtomGroup, parse_dim_type
+from ._base import (stage_columns, AnalysisBase, NoDataError, UpdatingAtomGroup, native_rows, parse_dim_type,
+                    stage_frame_native)
 
 #: frames staged on the host before an asynchronous host->device copy is queued
 _COMMIT_BYTES = 32 << 20
@@ -165,6 +166,8 @@ class VelocityAutocorr(AnalysisBase):
             # (columns of the source group: the distributed source is the block itself)
             self._targets = [(self._velocities, 0, self._n_local)] if self._distributed else \
                 [(self._velocities, self._lo, self._hi)]
+        # the per-frame fill reads the Timestep's own array natively (ta_stage_frame) where it can
+        self._rows = native_rows(self._source) if self._n_local else None
         frame_bytes = max(1, self._n_local * self.dim_fac * dtype.itemsize)
         self._commit_every = max(1, _COMMIT_BYTES // frame_bytes)
         self._committed = 0
@@ -181,7 +184,7 @@ class VelocityAutocorr(AnalysisBase):
         if not self._ts.has_velocities:
             raise NoDataError("VACF computation requires velocities in the trajectory")
         i = self._frame_index
-        if self._n_local:
+        if self._n_local and not stage_frame_native(self._ctx, 0, i, self._ts, "velocities", self._dim, self._rows):
             vel = np.asarray(self._source.velocities)
             for view, lo, hi in self._targets:
                 stage_columns(view[i], vel, lo, hi, self._dim)

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 from . import _lib
-from ._base import stage_columns, BOLTZMANN, AnalysisBase, NoDataError, UpdatingAtomGroup, parse_dim_type
+from ._base import (stage_columns, BOLTZMANN, AnalysisBase, NoDataError, UpdatingAtomGroup, native_rows,
+                    parse_dim_type, stage_frame_native)
 
 _COMMIT_BYTES = 32 << 20
 
@@ -153,6 +154,8 @@ class ViscosityHelfand(AnalysisBase):
         self.boltzmann = BOLTZMANN
         frame_bytes = max(1, 2 * self._n_local * self.dim_fac * dtype.itemsize)
         self._commit_every = max(1, _COMMIT_BYTES // frame_bytes)
+        # the per-frame fill reads the Timestep's own arrays natively (ta_stage_frame) where it can
+        self._rows = native_rows(self._source) if self._n_local else None
         self._committed = 0
         self.results.visc_by_particle = None
         # pinned home of the (n_frames, n_particles) result (:117-119), page-locked on a helper thread
@@ -177,10 +180,14 @@ class ViscosityHelfand(AnalysisBase):
         i = self._frame_index
         self._volumes[i] = ts.volume
         if self._n_local:
-            vel, pos = np.asarray(self._source.velocities), np.asarray(self._source.positions)
-            for vview, xview, lo, hi in self._targets:
-                stage_columns(vview[i], vel, lo, hi, self._dim)
-                stage_columns(xview[i], pos, lo, hi, self._dim)
+            if not stage_frame_native(self._ctx, 0, i, ts, "velocities", self._dim, self._rows):
+                vel = np.asarray(self._source.velocities)
+                for vview, xview, lo, hi in self._targets:
+                    stage_columns(vview[i], vel, lo, hi, self._dim)
+            if not stage_frame_native(self._ctx, 1, i, ts, "positions", self._dim, self._rows):
+                pos = np.asarray(self._source.positions)
+                for vview, xview, lo, hi in self._targets:
+                    stage_columns(xview[i], pos, lo, hi, self._dim)
         if i + 1 - self._committed >= self._commit_every:
             self._ctx.stage_commit(self._committed, i + 1)
             self._committed = i + 1
