@@ -95,6 +95,11 @@ class AtomGroup:
     def n_atoms(self):
         return len(self.indices)
 
+    @property
+    def ix(self):
+        """the atoms' indices in the universe (MDAnalysis' AtomGroup.ix)"""
+        return self.indices
+
     def _frame(self, arr, what):
         if arr is None:
             from ._base import NoDataError
