@@ -306,7 +306,7 @@ struct WPlan {
 #ifndef WF_SPREAD_ALL
     static constexpr bool kSpreadRows = R0 >= 9 && R0 <= 16;
 #else
-    static constexpr bool kSpreadRows = WF_SPREAD_ALL && R0 < 18;
+    static constexpr bool kSpreadRows = WF_SPREAD_ALL && (R0 < 18 || R0 == WF_NW_R0);  // (a 4-wave experiment plan has 512 registers)
 #endif
     // One of two (three) sub-series in flight takes its first exchange through the register file
     // (gfx950 permlane swaps + DPP) instead of the LDS: same-box A/B per 30000 pairs R0 = 16: 1.63
