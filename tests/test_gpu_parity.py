@@ -1454,3 +1454,22 @@ def test_classes_native_and_numpy_staging_bit_equal(subset, monkeypatch):
         assert np.array_equal(got, want)
     if subset:
         assert out["1"][0].shape == (T, 8, 2)
+
+
+def test_helfand_matrix_cores_do_not_depend_on_the_unit(ctx):
+    """The float64 matrix-core Helfand lag sums for P scaled by 1e-12 ... 1e+8 (velocities and positions in other
+    units): the result scales with the square, to the float64 bar.  (The norm slot's exact 1 must never be
+    added to a squared norm: beside 1, a norm of 1e-20 has no digits left.)"""
+    from oracle import numpy_oracle as orc
+
+    T, A = 700, 13
+    v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=98)
+    base, _ = run_helfand(ctx, v, x, m, 1.0, False)
+    ctx.set_option("timeline", 1)
+    try:
+        for sv, sx in ((1e-6, 1e-6), (1e4, 1e4), (1e-3, 1.0)):
+            got, _ = run_helfand(ctx, v * sv, x * sx, m, 1.0, False)
+            assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_lags"]
+            assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL, (sv, sx)
+    finally:
+        ctx.set_option("timeline", 0)

@@ -257,6 +257,7 @@ __device__ __forceinline__ double band_sum_rows(double s) { return band_sum_row_
 struct BandHelf {
     int T, i;
     bool slot;
+    double slot_one;  // 1 in the fourth lane group, 0 elsewhere
     // Every VALU instruction of this kernel costs matrix-pipe time (measured: FP64 MFMAs and vector
     // instructions do not overlap on gfx950, interleaved or not), so the common case — a block that lies
     // inside the series — is kept to the fewest instructions; blocks that reach the end take the
@@ -270,12 +271,15 @@ struct BandHelf {
         return r;
     }
     // B operand of block b from rows that are already centred except for `shift` (rows - r, or old + delta)
-    // `exact_one`: the fourth group holds exactly (1, 0), so its "norm" 1 is taken off the sum instead of masked
+    // `exact_one`: the fourth group holds exactly (1, 0); its square is taken off BEFORE the sum over the lane
+    // groups (fma(c.x, c.x, -slot_one) = 0 there), never after it: 1 + (a norm of 1e-20) - 1 is 0 — round 4's
+    // form did that and lost every digit of small-valued data (P in other units: 70 % wrong at P ~ 1e-10;
+    // tests/test_gpu_parity.py::test_helfand_matrix_cores_do_not_depend_on_the_unit)
     template <bool exact_one>
     __device__ __forceinline__ band_d2 finish_b(band_d2 c, int b) const {
         if (16 * b + 16 <= T) {
             double n;
-            if constexpr (exact_one) n = __builtin_fma(-0.5, band_sum_rows(c.x * c.x + c.y * c.y), 0.5);
+            if constexpr (exact_one) n = -0.5 * band_sum_rows(__builtin_fma(c.y, c.y, __builtin_fma(c.x, c.x, -slot_one)));
             else n = -0.5 * band_sum_rows(slot ? 0.0 : c.x * c.x + c.y * c.y);
             if (slot) c = band_d2{n, 1.0};
         } else {
@@ -311,7 +315,7 @@ struct BandHelf {
 // Requests and the ring: as band_visit.
 __device__ __forceinline__ void band_visit_helfand(const BandSrc& src, band_d2* ring, int d0, int i0, int i1, band_d4 (&acc)[16],
                                                    double& na) {
-    const BandHelf h{src.T, src.i, src.slot};
+    const BandHelf h{src.T, src.i, src.slot, src.slot ? 1.0 : 0.0};
     const int lane = (int)(threadIdx.x & 63);
     const unsigned ring_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)ring);
     band_d2 W[16], r;
