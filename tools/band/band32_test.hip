@@ -14,11 +14,11 @@
 #include "../../transport_analysis_amd/csrc/band32_kernels.hpp"
 using namespace ta;
 
-#ifndef B32_NW
-#define B32_NW 4
+#ifndef B32_NW  // defaults = what band32.hip launches: 8 waves per workgroup (two per SIMD), requests 2 steps ahead
+#define B32_NW 8
 #endif
 #ifndef B32_PF
-#define B32_PF 4
+#define B32_PF 2
 #endif
 #ifndef B32_NS
 #define B32_NS (2 * B32_PF)

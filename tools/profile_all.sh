@@ -4,12 +4,12 @@
 #      >= 3 warm-ups, next to the hipEvent medians of the SAME run; FETCH/WRITE/TCC passes
 #   2. HBM-traffic passes (FETCH_SIZE, WRITE_SIZE in separate runs) of the other workloads:
 #      by-particle, direct configs[3] (matrix-core lag sums; vector kernel with the by-particle array), Helfand
-#      float64 (matrix cores) and float32 share, helfand_fft, 20000-frame path
+#      float64 (FP64 matrix cores) and float32 (FP32 matrix cores) share, helfand_fft, 20000-frame path
 # Everything lands in gpurun_out/prof_<tag>*/; hbm_traffic.json accumulates the entries, keyed by
 # the library's hash.  usage: profile_all.sh TAG [quick]
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r04}
+TAG=${1:-r05}
 QUICK=${2:-}
 COMMON="--no-cpu-baseline --no-other-configs --no-host-path --no-check --no-kernel-split --no-clock-probe"
 export TA_TRAFFIC_MERGE=$R/gpurun_out/hbm_traffic_$TAG.json
@@ -26,7 +26,7 @@ run c3bp fft_10000x100000x3_bp k_wsplit_accum+k_winverse+k_bp_transpose+k_sum_pa
 run direct direct_5000x50000x3 k_band_lags 3 --steps 2 --warmup 1 --mode direct --frames 5000 --atoms 50000
 run directbp direct_5000x50000x3_bp k_direct+k_sum_partials+k_bp_transpose 3 --steps 2 --warmup 1 --mode direct --frames 5000 --atoms 50000 --by-particle
 run helf64 helfand_20000x25000x3 k_helfand_product+k_band_lags+k_band_gather 2 --steps 1 --warmup 1 --mode helfand --frames 20000 --atoms 25000
-run helf32 helfand_20000x25000x3_f32 k_direct 2 --steps 1 --warmup 1 --mode helfand --float32 --frames 20000 --atoms 25000
+run helf32 helfand_20000x25000x3_f32 k_helfand_product32+k_band32_lags+k_band_gather 2 --steps 1 --warmup 1 --mode helfand --float32 --frames 20000 --atoms 25000
 run hfft helfand_20000x25000x3_hfft k_helfand_product+k_wsplit_accum+k_sum_partials+k_winverse+k_helfand_combine 3 --steps 2 --warmup 1 --mode helfand --helfand-fft --frames 20000 --atoms 25000
 run long fft_20000x25000x3 k_wsplit_accum 4 --steps 3 --warmup 1 --frames 20000 --atoms 25000
 run longbp fft_20000x25000x3_bp k_wsplit_accum+k_winverse+k_bp_transpose+k_sum_partials 3 --steps 2 --warmup 1 --frames 20000 --atoms 25000 --by-particle
