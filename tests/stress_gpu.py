@@ -40,6 +40,9 @@ def host_cases(n_cases, seed):
             ctx.stage_commit(lo, hi)
         v64, x64 = v.astype(np.float64), x.astype(np.float64)
         by_particle = bool(rng.random() < 0.5)
+        f32 = bool(kind == "helfand" and T <= 2500 and rng.random() < 0.4)  # float32 option (FP32 matrix cores without bp)
+        ctx.set_option("direct_f32", int(f32))
+        tol_host = 2e-6 if f32 else 1e-10
         if kind == "helfand":
             scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
             ts, bp = ctx.helfand_msd(m, scale, by_particle=by_particle)
@@ -61,9 +64,9 @@ def host_cases(n_cases, seed):
         e = float(np.max(np.abs(ts - want_ts))) / sc
         if by_particle:
             e = max(e, float(np.max(np.abs(bp - want_bp))) / sc)
-        worst = max(worst, e / 1e-10)
-        if e > 1e-10:
-            print("FAIL host", case, kind, T, A, D, dtype, by_particle, e, flush=True)
+        worst = max(worst, e / tol_host)
+        if e > tol_host:
+            print("FAIL host", case, kind, T, A, D, dtype, by_particle, f32, e, flush=True)
             return 1
         ctx.close()
     print("host stress ok:", n_cases, "cases, worst err/tol %.3g" % worst)
@@ -137,9 +140,9 @@ def main(n_cases, seed=1234):
             e = int(rng.choice(edges))
             T = int(np.clip(e + rng.integers(-3, 2), 1, 10240)) if rng.random() < 0.6 else int(rng.integers(1, 10241))
             A_all = int(rng.integers(1, 24 if T > 3000 else 60))
-        else:
-            T = int(rng.integers(1, 700))
-            A_all = int(rng.integers(1, 50))
+        else:  # (the matrix-core band kernels: several 256-lag groups now and then)
+            T = int(rng.integers(1, 700)) if rng.random() < 0.8 else int(rng.integers(700, 3000))
+            A_all = int(rng.integers(1, 50 if T < 700 else 12))
         D = int(rng.integers(1, 4))
         lo = int(rng.integers(0, A_all))
         hi = int(rng.integers(lo + 1, A_all + 1))
