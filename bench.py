@@ -315,13 +315,15 @@ class Case:
     def on_matrix_cores(self):
         """lag sums alone of the O(T^2) correlators: FP64 MFMA band kernel (band_kernels.hpp); the float32 option's
         Helfand lag sums: FP32 MFMA (band32_kernels.hpp)"""
-        if self.bp is not None or (self.mode == "helfand" and self.helfand_fft):
+        if self.mode == "helfand" and self.helfand_fft:
             return False
+        if self.bp is not None:  # by-particle arrays: only the float32 Helfand form (dim = 3) has a matrix-core kernel
+            return self.mode == "helfand" and self.float32 and self.D == 3
         return self.mode == "helfand" or (self.mode == "direct" and not self.float32)
 
     def kernel_name(self):
         if self.on_matrix_cores():
-            return "k_band32_lags" if self.float32 else "k_band_lags"
+            return ("k_band32_bp" if self.bp is not None else "k_band32_lags") if self.float32 else "k_band_lags"
         if self.mode != "fft" and not (self.mode == "helfand" and self.helfand_fft):
             return "k_direct"
         if self.T > 163840:
@@ -403,9 +405,11 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
             # fourth lane group carries the norms).  The reference's own arithmetic (difference, square, add =
             # 3 flop per term; what the vector kernel's line counts) is `reference_flops_*`:
             # a larger number that says nothing about the pipe
-            issued = 2.0 * (8.0 / 6.0) * D * A * T * (T - 1) / 2 / (kernel_ms * 1e-3) / 1e12
+            # (by-particle form: 3 of 4 slots, and units of 16 block lags own 15: 16/15 of the MFMAs)
+            slots = (4.0 / 3.0) * (16.0 / 15.0) if case.bp is not None else 8.0 / 6.0
+            issued = 2.0 * slots * D * A * T * (T - 1) / 2 / (kernel_ms * 1e-3) / 1e12
             out.update({"achieved": issued, "frac": issued / mpeak,
-                        "issued_flops_per_launch": 2.0 * (8.0 / 6.0) * D * A * T * (T - 1) / 2,
+                        "issued_flops_per_launch": 2.0 * slots * D * A * T * (T - 1) / 2,
                         "reference_flops_tflops": tf, "reference_flops_frac": tf / mpeak})
         return out
     return {"bound": "valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
@@ -890,6 +894,7 @@ def other_configs(torch, dist, _lib, ctx, dev):
         ("configs[3] shape with vacf_by_particle (vector kernel): windowed VACF 5000 x 50000 x 3", "direct", 5000, 50000, True, False, False, 2, 1),
         ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float64 (matrix cores)", "helfand", 20000, 25000, False, False, False, 2, 1),
         ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float32 path (FP32 matrix cores)", "helfand", 20000, 25000, False, True, False, 2, 1),
+        ("configs[4] per-GPU share, float32 path with visc_by_particle (the class default output; FP32 matrix cores): 20000 x 25000 x 3", "helfand", 20000, 25000, True, True, False, 2, 1),
         ("configs[4] per-GPU share, helfand_fft option (float64): 20000 x 25000 x 3", "helfand", 20000, 25000, False, False, True, 3, 1),
         ("long trajectory: FFT VACF timeseries 20000 x 25000 x 3", "fft", 20000, 25000, False, False, False, 5, 1),
         ("long trajectory with vacf_by_particle: FFT VACF 20000 x 25000 x 3", "fft", 20000, 25000, True, False, False, 3, 1),

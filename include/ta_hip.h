@@ -289,10 +289,13 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  * (TA_E_UNSUPPORTED otherwise: a bug); *max_over_mean: the busiest wave's share over the average.  */
 int ta_band_plan_info(int64_t n_frames, int n_cu, int *n_pieces, int *octets_in_flight, double *max_over_mean);
 /* options (key, value):
- *   "direct_f32" 0|1 : direct correlators (ta_vacf_direct*, ta_helfand_msd*) evaluate
- *                      products / squared differences and 32-term block sums in float32
- *                      and add them into float64 accumulators (BASELINE configs[4]'s
- *                      float32 path; ~1e-6 relative accuracy).  Default 0 = float64.
+ *   "direct_f32" 0|1 : direct correlators (ta_vacf_direct*, ta_helfand_msd*) round the staged values (Helfand:
+ *                      P = (m v) x, formed in float64) ONCE to float32, form products / squared differences
+ *                      in float32 and accumulate in float64 (BASELINE configs[4]'s float32 path; within 2e-6
+ *                      of the series' scale).  Helfand runs on the FP32 matrix cores (band32_kernels.hpp:
+ *                      v_mfma_f32_16x16x4_f32 on a float32 product slab, T*A*D*4 bytes more): the lag sums
+ *                      alone 1.7x faster than the float32 vector kernel, with the by-particle array (dim = 3)
+ *                      1.4x; the windowed VACF and dim < 3 stay on the vector kernels.  Default 0 = float64.
  *   "direct_mfma" 1|0: ta_vacf_direct* and ta_helfand_msd* WITHOUT a by-particle array (lag sums only,
  *                      float64) run on the FP64 matrix cores (band_kernels.hpp): the windowed VACF's
  *                      lag sums are the diagonal sums of the frames' Gram matrix
@@ -300,8 +303,9 @@ int ta_band_plan_info(int64_t n_frames, int n_cu, int *n_pieces, int *octets_in_
  *                      Helfand squared differences (viscosity.py:201-233) are formed from products of
  *                      rows centred on a nearby frame (1.5x; every lag within 1e-10 of the
  *                      difference-first vector kernel even for a pure trend; needs T*A*D*8 bytes for
- *                      the product slab, else the vector kernel runs).  0 = the vector kernels.  With a
- *                      by-particle array or "direct_f32" the vector kernels run whatever this says.
+ *                      the product slab, else the vector kernel runs).  0 = the vector kernels, also for
+ *                      "direct_f32".  In float64 the by-particle arrays come from the vector kernels whatever
+ *                      this says.
  *   "helfand_fft" 0|1: ta_helfand_msd* evaluate the mean squared differences in O(T log T)
  *                      (n_frames <= 163840, else as default): sum (P[i]-P[i+k])^2 = S1(k) - 2 S2(k), S2 by the FFT
  *                      lag sums of the product slab P = (m v) x, S1 by prefix sums.  An

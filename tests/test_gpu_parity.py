@@ -259,6 +259,38 @@ def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D):
         assert scale_rel_err(ts_m, want_ts) > 0.0  # really float32 arithmetic
 
 
+@pytest.mark.parametrize("T,A", [(1, 2), (2, 3), (16, 5), (17, 3), (239, 2), (240, 3), (241, 2), (257, 7), (481, 5), (1000, 9),
+                                 (2049, 3), (300, 300)])
+def test_helfand_float32_by_particle_on_the_matrix_cores(ctx, T, A):
+    """The float32 option WITH results.visc_by_particle (the class default output), dim = 3: k_band32_bp — a particle's
+    x, y, z in three of the MFMA's four k-slots, units of 16 block lags that own 240 lags each — against the
+    oracle at 2e-6 of the scale, frame counts on both sides of the 16-frame blocks and of the 240-lag units; the
+    timeseries is the mean of the by-particle array; dim < 3 stays on the vector kernel."""
+    from oracle import numpy_oracle as orc
+
+    v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=2900 + T)
+    x = x + 50.0 + 0.01 * np.arange(T)[:, None, None]
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+    want_bp, want_ts = orc.helfand(v, x, m, vol, 300.0)
+    ctx.set_option("direct_f32", 1)
+    ctx.set_option("timeline", 1)
+    try:
+        ts, bp = run_helfand(ctx, v, x, m, scale, True)
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_bp", "k_bp_transpose", "k_sum_partials"]
+        ts2, bp2 = ctx.helfand_msd(m, scale, by_particle=True)
+        assert np.array_equal(bp, bp2) and np.array_equal(ts, ts2)
+        _, bp_d2 = run_helfand(ctx, v[:, :, :2], x[:, :, :2], m, scale, True)
+        assert "k_direct" in [n for n, _ in ctx.kernel_timeline()]
+    finally:
+        ctx.set_option("direct_f32", 0)
+        ctx.set_option("timeline", 0)
+    assert np.all(bp[0] == 0.0) and ts[0] == 0.0
+    assert scale_rel_err(bp, want_bp) < TOL_F32
+    assert scale_rel_err(ts, want_ts) < TOL_F32
+    np.testing.assert_allclose(ts, bp.mean(axis=1), rtol=1e-12, atol=1e-13 * np.abs(ts).max())
+    assert scale_rel_err(bp_d2, orc.helfand(v[:, :, :2], x[:, :, :2], m, vol, 300.0)[0]) < TOL_F32
+
+
 def test_helfand_float32_matrix_cores_trend_units_and_float32_slabs(ctx):
     """Three properties of the float32 matrix-core Helfand path.  (a) The pure cubic trend (v = t, x = t^2 / 2:
     P grows by nine orders of magnitude): every lag within 2e-6 of the SCALE of the float64 difference-first

@@ -30,7 +30,7 @@ def test_library_build_passes(isa_files):
     r = run_check(*isa_files)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if "k_band" in ln and "gather" not in ln]
-    assert len(lines) == 3 and all(ln.rstrip().endswith("ok") for ln in lines), r.stdout  # two float64 forms + float32
+    assert len(lines) == 4 and all(ln.rstrip().endswith("ok") for ln in lines), r.stdout  # two float64 forms + two float32 kernels
     assert all(" 0 inline" not in ln for ln in lines)  # ... and it did look at inline loads
 
 

@@ -137,8 +137,101 @@ __global__ void k_fill(float* p, size_t n) {
     }
 }
 
+// by-particle kernel: every particle's own mean squared differences, atom-major output
+static int bp_check_one(int T, long A, int kind) {
+    const long n_cols = 3 * A, n_pairs = (n_cols + 1) / 2, pitch = (T + 7) / 8 * 8;
+    std::vector<float> h((size_t)n_pairs * pitch * 2);
+    unsigned long long s = 99 + T * 17 + A + 7 * kind;
+    for (long pr = 0; pr < n_pairs; ++pr)
+        for (int c = 0; c < 2; ++c) {
+            double walk = 0;
+            for (long t = 0; t < pitch; ++t) {
+                double v = kind == 0 ? rnd(s) + 1000.0 : kind == 1 ? (walk += rnd(s) + 0.05) + 300.0 : 1e-12 * (rnd(s) + 3.0);
+                h[(pr * pitch + t) * 2 + c] = (float)v;
+            }
+        }
+    if (n_cols & 1)
+        for (long t = 0; t < pitch; ++t) h[((n_pairs - 1) * pitch + t) * 2 + 1] = 0.0f;
+    float* pm;
+    double* out;
+    CK(hipMalloc(&pm, h.size() * 4));
+    CK(hipMemcpy(pm, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&out, 8 * (size_t)A * pitch));
+    CK(hipMemset(out, 0xff, 8 * (size_t)A * pitch));
+    hipLaunchKernelGGL((k_band32_bp<B32_NW, B32_PF, B32_NS>), dim3(256), dim3(64 * B32_NW), 0, 0, pm, pitch, T, A, 1.0, out, pitch);
+    CK(hipDeviceSynchronize());
+    std::vector<double> got((size_t)A * pitch);
+    CK(hipMemcpy(got.data(), out, got.size() * 8, hipMemcpyDeviceToHost));
+    double worst = 0;
+    long wa = -1;
+    int wk = -1;
+    for (long a = 0; a < A; ++a) {
+        double scale = 0;
+        std::vector<double> ref(T, 0.0);
+        for (int k = 1; k < T; ++k) {
+            double acc = 0;
+            for (int d = 0; d < 3; ++d) {
+                const long c = 3 * a + d;
+                const float* col = h.data() + (c >> 1) * pitch * 2 + (c & 1);
+                for (int i = 0; i + k < T; ++i) {
+                    const double df = (double)col[2 * i] - (double)col[2 * (i + k)];
+                    acc += df * df;
+                }
+            }
+            ref[k] = acc / (T - k);
+            scale = std::max(scale, ref[k]);
+        }
+        for (int k = 0; k < T; ++k) {
+            const double e = std::fabs(got[a * pitch + k] - ref[k]) / (scale > 0 ? scale : 1.0);
+            if (!(e <= worst)) worst = e, wa = a, wk = k;
+        }
+    }
+    const bool ok = worst < 2e-6;
+    printf("by-particle kind %d T=%6d A=%5ld : worst %.2e of the particle's scale (particle %ld lag %d) %s\n", kind, T, A, worst, wa, wk, ok ? "ok" : "FAIL");
+    (void)hipFree(pm), (void)hipFree(out);
+    return ok ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
     const char* mode = argc > 1 ? argv[1] : "check";
+    if (!strcmp(mode, "bpcheck")) {
+        int bad = 0;
+        const int shapes[][2] = {{1, 2}, {2, 3}, {15, 4}, {16, 5}, {17, 3}, {239, 2}, {240, 3}, {241, 2}, {255, 3}, {257, 7}, {480, 3},
+                                 {481, 5}, {1000, 9}, {2049, 3}, {5000, 2}, {300, 700}};
+        for (auto& sh : shapes) bad += bp_check_one(sh[0], sh[1], 0);
+        for (int kind : {1, 2}) bad += bp_check_one(1000, 5, kind) + bp_check_one(4100, 2, kind);
+        printf(bad ? "FAILED %d\n" : "all ok\n", bad);
+        return bad ? 1 : 0;
+    }
+    if (!strcmp(mode, "bptime")) {
+        const int T = argc > 2 ? atoi(argv[2]) : 20000;
+        const long A = argc > 3 ? atol(argv[3]) : 25000;
+        const int reps = argc > 4 ? atoi(argv[4]) : 2;
+        const long n_cols = 3 * A, n_pairs = (n_cols + 1) / 2, pitch = (T + 7) / 8 * 8;
+        hipDeviceProp_t prop;
+        CK(hipGetDeviceProperties(&prop, 0));
+        float* pm;
+        double* out;
+        CK(hipMalloc(&pm, (size_t)n_pairs * pitch * 8));
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, pm, (size_t)n_pairs * pitch * 2);
+        CK(hipMalloc(&out, 8 * (size_t)A * pitch));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        const int wg_per_cu = getenv("B32_WG_PER_CU") ? atoi(getenv("B32_WG_PER_CU")) : 1;
+        for (int r = 0; r <= reps; ++r) {
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL((k_band32_bp<B32_NW, B32_PF, B32_NS>), dim3(prop.multiProcessorCount * wg_per_cu), dim3(64 * B32_NW), 0, 0, pm,
+                               pitch, T, A, 1.0, out, pitch);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r) printf("  by-particle Helfand (float32 matrix cores) %d x %ld x 3: %.3f ms  %.1f TFLOP/s (3 flop per term)\n", T, A, ms,
+                          3.0 * (double)T * (T - 1) / 2 * n_cols / (ms * 1e-3) / 1e12);
+        }
+        return 0;
+    }
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int wg_per_cu = getenv("B32_WG_PER_CU") ? atoi(getenv("B32_WG_PER_CU")) : 1;

@@ -208,6 +208,27 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         }
         (void)hipGetLastError();  // out of memory for the product slab: the vector kernel needs none
     }
+    // ... and with the by-particle array (dim = 3: a particle's x, y, z in three of the MFMA's four k-slots)
+    if (d_bp && f32 && mode == MODE_HELFAND && D == 3 && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
+        const int64_t n_cols = A * D, Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
+        if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK &&
+            ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
+            ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T) == TA_OK) {
+            tl_mark(ctx, "k_helfand_product32", st);
+            TA_HIP_TRY(ctx, launch_helfand_product32(d_vel, d_pos, src_f32, d_masses, pitch, T, n_cols, D, (float*)ctx->helf_p.p, st));
+            tl_mark(ctx, "k_band32_bp", st);
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+            TA_HIP_TRY(ctx, launch_band32_bp(ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, A, scale / (double)D,
+                                             (double*)ctx->bp_scratch.p, Tp, st));
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+            tl_mark(ctx, "k_bp_transpose", st);
+            TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp, (double*)ctx->ts_partial.p, st));
+            tl_mark(ctx, "k_sum_partials", st);
+            TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)n_tiles, T, d_lagsum, st));
+            return TA_OK;
+        }
+        (void)hipGetLastError();
+    }
     if (band_ok && mode == MODE_VACF) {
         tl_mark(ctx, "k_band_lags", st);
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));

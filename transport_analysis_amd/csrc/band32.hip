@@ -44,4 +44,13 @@ hipError_t launch_band32_lags(BandCache** cache, int n_cu, const float* pm32, lo
     return hipGetLastError();
 }
 
+// the float32 option WITH the by-particle array, dim = 3: bp_am[particle * ld_am + lag] (atom-major scratch), every lag written
+hipError_t launch_band32_bp(int n_cu, const float* pm32, long pitch, int T, long n_atoms, double factor, double* bp_am, long ld_am,
+                            hipStream_t st) {
+    constexpr int kWaves = 12;  // three per SIMD (156 registers; harness: 8 / 12 / 16 waves 423 / 389 / 388 ms, 16 with scratch)
+    hipLaunchKernelGGL((k_band32_bp<kWaves, 2, 4>), dim3(std::max(1, n_cu)), dim3(64 * kWaves), 0, st, pm32, pitch, T, n_atoms, factor,
+                       bp_am, ld_am);
+    return hipGetLastError();
+}
+
 }  // namespace ta

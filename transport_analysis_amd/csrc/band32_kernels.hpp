@@ -379,6 +379,208 @@ __global__ void __launch_bounds__(64 * NW)
     }
 }
 
+// ---- Einstein-Helfand WITH the by-particle array (dim = 3) on the FP32 matrix cores ------------------------
+// results.visc_by_particle of viscosity.py:201-233 under the float32 option: every particle's own mean squared
+// differences.  The contraction of a product is then over ONE particle's three columns: lane groups 0..2 carry
+// x, y, z (ONE float32 per lane, a single MFMA per block lag and step), the fourth carries valid_A | -nB/2 as
+// above: 3 of the instruction's 4 k-slots do arithmetic.  (The FP64 form of this, tools/band/helfand_bp_mfma.patch,
+// tied with the vector kernel; here the matrix instruction is twice as fast and the float32 vector kernel needs a
+// subtraction and an FMA per term.)
+// A unit = (particle, 16 block lags starting at 15 g): it owns lags 240 g ... 240 g + 239 — a lag needs block lags
+// d and d + 1, so consecutive units overlap by one block lag (16/15 of the MFMAs) instead of adding up halves —
+// runs the whole band of those block lags, and writes its 240 values into the atom-major scratch that
+// k_bp_transpose turns into (n_frames, n_particles).  Units are dealt round-robin to the waves: the ~T/240 units of
+// a particle run on different waves at about the same time, on the same 12 T bytes.
+// Rows: two LDS-DMA requests of one dword per lane and step (A block, window block): lane (k, i) fetches column
+// 3 p + k of frame i — 4 bytes at ((c >> 1) pitch + t) * 8 + (c & 1) * 4 — which lands at slot + 4 lane: the
+// fragment itself.
+struct BandSrc32s {
+    band_u4 rs;         // the two column pairs that hold the particle's three columns
+    unsigned lane_off;  // byte offset of the lane's column at frame i (fourth lane group: out of range)
+    int T, i;
+    bool slot;
+    __device__ __forceinline__ void dma(unsigned lds_addr, int b) const {
+        const unsigned off = lane_off + (unsigned)b * 128u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(off), "s"(rs)
+                     : "memory");
+    }
+};
+
+struct BandHelf32s {
+    int T, i;
+    bool slot;
+    float slot_one;
+    __device__ __forceinline__ float first_row(float raw) const {
+        const float r = __shfl(raw, (int)(threadIdx.x & 48));
+        return slot ? -1.0f : r;  // "row - r" = 1 = valid_A in the fourth lane group (its rows read as zeros)
+    }
+    // B operand: centred row, fourth lane group -nB/2 (inside: the block lies inside the series; one_in_slot: the
+    // fourth group holds exactly 1, taken off before the sum over the lane groups)
+    template <bool one_in_slot, bool inside>
+    __device__ __forceinline__ float finish_b(float c, int b) const {
+        if constexpr (!inside)
+            if (!(i < T - 16 * b)) c = 0.0f;
+        const float q = (one_in_slot && inside) ? __builtin_fmaf(c, c, -slot_one) : (slot ? 0.0f : c * c);
+        const float n = -0.5f * band32_sum_rows(q);
+        return slot ? n : c;
+    }
+};
+
+// one unit: acc[d] += sum over I in [0, nsteps) and the particle's columns of -(a - b)^2 / 2 for block lags d0 + d
+template <int PF, int NS>
+__device__ __forceinline__ void band32_unit_bp(const BandSrc32s& src, float* ring, int d0, int nsteps, band_f4 (&acc)[16],
+                                               Band32Diag& sums, double& na) {
+    static_assert(16 % NS == 0 && NS >= 2 * PF && PF >= 1, "slots are indexed by the unrolled step");
+    const BandHelf32s h{src.T, src.i, src.slot, src.slot ? 1.0f : 0.0f};
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned ring_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)ring);
+    auto request_step = [&](int slot_idx, int x) {  // step x: A block x, window block x + d0 + 15
+        src.dma(ring_addr + 512u * (unsigned)slot_idx, x);
+        src.dma(ring_addr + 512u * (unsigned)slot_idx + 256u, x + d0 + 15);
+    };
+    float W[16], r, na32 = 0.0f;
+    // the first 15 window fragments through the ring as well: one block per 64-float half slot, 2 NS at a time
+#pragma unroll
+    for (int base = 0; base < 15; base += 2 * NS) {
+#pragma unroll
+        for (int q = 0; q < 2 * NS; ++q)
+            if (base + q < 15) src.dma(ring_addr + 256u * (unsigned)q, d0 + base + q);
+        TA_BAND32_WAIT(0);
+#pragma unroll
+        for (int q = 0; q < 2 * NS; ++q)
+            if (base + q < 15) W[base + q] = ring[64 * q + lane];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read before the next requests may overwrite the half slots
+    }
+#pragma unroll
+    for (int s = 0; s < PF; ++s) request_step(s % NS, s);
+    TA_BAND32_WAIT(2 * (PF - 1));
+    float anext = ring[lane], wnext = ring[64 + lane];
+    r = h.first_row(anext);
+    if (16 * (d0 + 15) <= src.T) {
+#pragma unroll
+        for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<true, true>(W[d] - r, 0);
+    } else {
+#pragma unroll
+        for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<true, false>(W[d] - r, d0 + d);
+    }
+    int I = 0, since = 0;
+    for (bool more = true; more;) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j == 0 && ++since == kBand32Flush / 16) {
+                sums.flush(acc);
+                since = 0;
+            }
+            if (j == 0 && I != 0) {  // a new pass: a new reference row that the 15 older window fragments follow
+                const float rn = h.first_row(anext);
+                const float delta = r - rn;
+                r = rn;
+                if (16 * (I + d0 + 15) <= src.T) {
+#pragma unroll
+                    for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<false, true>(W[d] + delta, 0);
+                } else {
+#pragma unroll
+                    for (int d = 0; d < 15; ++d) W[d] = h.template finish_b<false, false>(W[d] + delta, I + d0 + d);
+                }
+            }
+            const bool bulk = 16 * (I + d0 + 16) <= src.T;  // every pair of this step is valid
+            float A = anext - r, na_half = 0.0f;
+            if (bulk) {
+                na32 = __builtin_fmaf(A, A, na32 - h.slot_one);  // (fourth lane group: 1 - 1 = 0 exactly)
+                W[(j + 15) & 15] = h.template finish_b<true, true>(wnext - r, 0);
+            } else {
+                const bool valid = src.i < src.T - 16 * I;
+                if (!valid) A = 0.0f;
+                na_half = -0.5f * band32_sum_rows(src.slot ? 0.0f : A * A);
+                W[(j + 15) & 15] = h.template finish_b<true, false>(wnext - r, I + d0 + 15);
+            }
+            request_step((j + PF) % NS, I + PF);
+            TA_BAND32_WAIT(2 * (PF - 1));
+            anext = ring[128 * ((j + 1) % NS) + lane];
+            wnext = ring[128 * ((j + 1) % NS) + 64 + lane];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) acc[d] = TA_BAND32_MFMA(A, W[(j + d) & 15], acc[d]);
+            if (!bulk) {  // the window reaches the end of the series: -nA[m]/2 only where frame n exists
+                const float A2 = src.slot ? na_half : 0.0f;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const float B2 = (src.slot && src.i < src.T - 16 * (I + d0 + d)) ? 1.0f : 0.0f;
+                    acc[d] = TA_BAND32_MFMA(A2, B2, acc[d]);
+                }
+            }
+            if (++I == nsteps) {
+                more = false;
+                break;
+            }
+        }
+    }
+    TA_BAND32_WAIT(0);
+    na += (double)na32;
+}
+
+// P32: pair-major float32 product slab, dim = 3.  bp_am[particle * ld_am + lag] = factor * sum_i sum_d (dP)^2 / (T - lag),
+// lag 0: exactly 0.  grid: any number of workgroups of 64 NW threads.
+template <int NW, int PF, int NS>
+__global__ void __launch_bounds__(64 * NW)
+    k_band32_bp(const float* __restrict__ P32, long pitch, int T, long n_atoms, double factor, double* __restrict__ bp_am, long ld_am) {
+    __shared__ float diag[NW][32 * 17 + 16 * 32];
+    __shared__ double na_half[NW][16];
+    __shared__ float rings[NW][NS * 128];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kk = lane >> 4;
+    Band32Diag sums;
+    sums.init(diag[wave], lane);
+    const int nblk = (T + 15) / 16, n_groups = (nblk + 14) / 15;
+    const long n_units = n_atoms * n_groups, n_waves = (long)gridDim.x * NW;
+    for (long u = (long)blockIdx.x * NW + wave; u < n_units; u += n_waves) {
+        // (uniform per wave; readfirstlane tells the compiler)
+        const long atom = __builtin_amdgcn_readfirstlane((int)(u / n_groups));
+        const int g = __builtin_amdgcn_readfirstlane((int)(u - atom * n_groups)), d0 = 15 * g;
+        const long c0 = 3 * atom, p0 = c0 >> 1;  // first column, first pair
+        const unsigned long long base = reinterpret_cast<unsigned long long>(P32 + p0 * pitch * 2);
+        BandSrc32s src;
+        src.rs = band_u4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base),
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(base >> 32) & 0xffffu)),
+                         (unsigned)(2 * pitch) * 8u, 0x00020000u};
+        const long c = c0 + kk;  // this lane group's column
+        src.lane_off = kk == 3 ? 0x80000000u : (unsigned)(((c >> 1) - p0) * pitch + (lane & 15)) * 8u + (unsigned)(c & 1) * 4u;
+        src.T = T;
+        src.i = lane & 15;
+        src.slot = kk == 3;
+        band_f4 acc[16];
+        double na = 0.0;
+        sums.clear();
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc[d] = band_f4{0.0f, 0.0f, 0.0f, 0.0f};
+        band32_unit_bp<PF, NS>(src, rings[wave], d0, nblk - d0, acc, sums, na);
+        sums.flush(acc);
+        {
+            const double t0 = band_sum_rows(na);
+            if (lane < 16) na_half[wave][lane] = 0.5 * t0;
+            __builtin_amdgcn_wave_barrier();
+        }
+        auto corr = [&](int e) {
+            const int m_lo = e < 0 ? -e : 0, m_hi = e > 0 ? 16 - e : 16;
+            double cc = 0.0;
+            for (int m = m_lo; m < m_hi; ++m) cc += na_half[wave][m];
+            return cc;
+        };
+        double* out = bp_am + atom * ld_am;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int off = lane + 64 * k - 15;  // lag 240 g + off, complete for 0 <= off < 240
+            const long lag = 240L * g + off;
+            if (off >= 0 && off < 240 && lag < T) {
+                const int d = off >> 4, e = off & 15;
+                double cc = corr(e);
+                if (e >= 1) cc += corr(e - 16);
+                out[lag] = lag == 0 ? 0.0 : factor * -2.0 * (sums.s[k] - cc) / (double)(T - lag);
+                (void)d;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // P = (m v) x per column, the reference's evaluation order (viscosity.py:212-219), formed in float64 and
 // rounded once to float32; pair-major slabs in (float64 16-byte rows or float32 8-byte rows), pair-major
 // float32 out.  A thread takes two consecutive rows of a pair: 16-byte stores.

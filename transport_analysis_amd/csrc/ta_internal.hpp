@@ -51,6 +51,8 @@ hipError_t band_tables(BandCache** cache, int n_cu, int T, hipStream_t st, int* 
 //   lagsum[k] = factor * sum of (P32[i, c] - P32[i + k, c])^2 / (n_frames - k), lagsum[0] = 0
 hipError_t launch_helfand_product32(const void* vel, const void* pos, bool src_f32, const double* masses, long pitch, long T,
                                     long n_cols, int D, float* P32, hipStream_t st);
+hipError_t launch_band32_bp(int n_cu, const float* pm32, long pitch, int T, long n_atoms, double factor, double* bp_am, long ld_am,
+                            hipStream_t st);
 hipError_t launch_band32_lags(BandCache** cache, int n_cu, const float* pm32, long pitch, int T, long n_cols, double factor,
                               double* lagsum, hipStream_t st);
 
