@@ -1107,6 +1107,25 @@ def test_vacf_by_particle_config2_full_size(ctx, T, A):
     torch.cuda.empty_cache()
 
 
+def test_blocked_by_particle_waits_for_the_commit_worker(ctx):
+    """A host-facing call whose atoms go in blocks does not pass through staged_entry: it joins the
+    commit worker itself.  A commit large enough to still be page-locking its chunks and issuing its
+    copies when the compute call arrives (200 MB, several chunks) must be complete in every block."""
+    from oracle import numpy_oracle as orc
+
+    T, A, D = 4096, 2048, 3
+    rng = np.random.default_rng(17)
+    v = rng.standard_normal((T, A, D))
+    ctx.set_option("bp_block", 256)
+    try:
+        ts, bp = run_vacf(ctx, v, True, True)
+    finally:
+        ctx.set_option("bp_block", 0)
+    want_bp, want_ts = orc.vacf_fft_batched(v)
+    assert scale_rel_err(ts, want_ts) < TOL
+    assert scale_rel_err(bp, want_bp) < TOL
+
+
 @pytest.mark.parametrize("mode,D", [("fft", 3), ("fft", 1), ("direct", 2), ("helfand", 3)])
 def test_host_path_by_particle_in_atom_blocks(ctx, mode, D):
     """Host-facing calls with a by-particle array process atoms in blocks (copy of block c

@@ -8,6 +8,7 @@
 // ctypes releases the GIL for the duration of the call.
 #include <hip/hip_runtime.h>
 #include <emmintrin.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
@@ -258,6 +259,44 @@ int ta_stage_threads(void) { return Pool::get().helpers() + 1; }
 }  // extern "C"
 
 namespace ta {
+// ---- host blocks: where pinned slabs and result arrays live -------------------------------------------------
+// hipHostMalloc of 6 GiB takes 0.7-1.4 s on the boxes of this pool (and hipHostFree another 0.5-1.0 s), all of it
+// inside _prepare, before the first frame.  An anonymous mapping is there at once, zero-filled by the kernel (the
+// reference's np.zeros: no memset), backed by transparent huge pages where the system allows, and
+// hipHostRegister page-locks it at 23 GB/s — chunk by chunk, when a chunk is first committed (on the commit
+// worker's thread, under the frame loop), or in one piece for a result array.  A hipMemcpy may not span two
+// separately registered ranges ("invalid argument"), so copies out of a slab are cut at chunk boundaries
+// (tools/ubench/hostreg_probe.hip, profiles/r05_hostreg_probe.txt).
+int host_block_map(size_t bytes, HostBlock* b) {
+    const size_t len = (std::max<size_t>(bytes, 1) + (HostBlock::kChunk - 1)) / HostBlock::kChunk * HostBlock::kChunk;
+    void* m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return -1;
+    (void)madvise(m, len, MADV_HUGEPAGE);
+    b->base = (char*)m, b->bytes = len;
+    b->locked.assign(len / HostBlock::kChunk, 0);
+    return 0;
+}
+hipError_t host_block_lock(HostBlock& b, size_t b0, size_t b1) {  // page-lock the chunks that cover [b0, b1)
+    for (size_t k = b0 / HostBlock::kChunk; k < b.locked.size() && k * HostBlock::kChunk < b1; ++k) {
+        if (b.locked[k]) continue;
+        const hipError_t e = hipHostRegister(b.base + k * HostBlock::kChunk, HostBlock::kChunk, hipHostRegisterPortable);
+        if (e != hipSuccess) return e;
+        b.locked[k] = 1;
+    }
+    return hipSuccess;
+}
+void host_block_unmap(HostBlock& b) {
+    if (!b.base) return;
+    for (size_t k = 0; k < b.locked.size(); ++k)
+        if (b.locked[k]) {
+            const hipError_t e = hipHostUnregister(b.base + k * HostBlock::kChunk);
+            if (e != hipSuccess)  // the pages would stay pinned behind a mapping that is going away: say so
+                fprintf(stderr, "transport_analysis_amd: hipHostUnregister(%p): %s\n", (void*)(b.base + k * HostBlock::kChunk), hipGetErrorString(e));
+        }
+    munmap(b.base, b.bytes);
+    b.base = nullptr, b.bytes = 0, b.locked.clear();
+}
+
 // api.hip (ta_stage_alloc): the reference's np.zeros for a fresh pinned slab, on the staging threads with
 // streaming stores (6 GB at 10000 x 50000 x 3 x float32: a single memset is a third of _prepare)
 void host_zero(void* p, size_t bytes) {

@@ -23,6 +23,17 @@ int ctx_device(const ta_ctx* ctx);
 int64_t ctx_staged_frames(const ta_ctx* ctx);
 int ctx_fail(ta_ctx* ctx, int code, const std::string& msg);  // records the message, returns code
 void host_zero(void* p, size_t bytes);  // stage_host.hip: memset 0 on several threads, streaming stores
+// stage_host.hip: an anonymous, zero-filled, huge-page backed mapping that is page-locked (hipHostRegister) chunk by
+// chunk on demand; copies out of it must not span two chunks
+struct HostBlock {
+    static constexpr size_t kChunk = (size_t)64 << 20;
+    char* base = nullptr;
+    size_t bytes = 0;               // mapped length: a multiple of kChunk
+    std::vector<unsigned char> locked;  // per chunk
+};
+int host_block_map(size_t bytes, HostBlock* b);                    // 0, or -1 when the mapping fails
+hipError_t host_block_lock(HostBlock& b, size_t b0, size_t b1);    // page-lock the chunks covering [b0, b1)
+void host_block_unmap(HostBlock& b);
 
 // direct.hip
 // vel / pos: pair-major slabs (layout.hip) of `pitch` rows per pair, float64 or (src_f32, with the
