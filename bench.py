@@ -317,13 +317,15 @@ class Case:
         Helfand lag sums: FP32 MFMA (band32_kernels.hpp)"""
         if self.mode == "helfand" and self.helfand_fft:
             return False
-        if self.bp is not None:  # by-particle arrays: only the float32 Helfand form (dim = 3) has a matrix-core kernel
-            return self.mode == "helfand" and self.float32 and self.D == 3
+        if self.bp is not None:  # by-particle arrays: the float32 Helfand form (dim = 3) and the float64 windowed VACF
+            return (self.mode == "helfand" and self.float32 and self.D == 3) or (self.mode == "direct" and not self.float32)
         return self.mode == "helfand" or (self.mode == "direct" and not self.float32)
 
     def kernel_name(self):
         if self.on_matrix_cores():
-            return ("k_band32_bp" if self.bp is not None else "k_band32_lags") if self.float32 else "k_band_lags"
+            if self.bp is not None:
+                return "k_band32_bp" if self.float32 else "k_band_bp_vacf"
+            return "k_band32_lags" if self.float32 else "k_band_lags"
         if self.mode != "fft" and not (self.mode == "helfand" and self.helfand_fft):
             return "k_direct"
         if self.T > 163840:
@@ -891,7 +893,7 @@ def other_configs(torch, dist, _lib, ctx, dev):
          "ONE GPU: a prediction of the per-GPU term of that curve, the all-reduce not included)", "fft", 10000, 12500, False, False, False, 10, 3),
         ("configs[2] shape with vacf_by_particle: FFT VACF 10000 x 100000 x 3", "fft", 10000, 100000, True, False, False, 3, 1),
         ("configs[3]: windowed (direct) VACF 5000 x 50000 x 3", "direct", 5000, 50000, False, False, False, 3, 1),
-        ("configs[3] shape with vacf_by_particle (vector kernel): windowed VACF 5000 x 50000 x 3", "direct", 5000, 50000, True, False, False, 2, 1),
+        ("configs[3] shape with vacf_by_particle (the class default output; FP64 matrix cores, k-slots from the time axis): windowed VACF 5000 x 50000 x 3", "direct", 5000, 50000, True, False, False, 2, 1),
         ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float64 (matrix cores)", "helfand", 20000, 25000, False, False, False, 2, 1),
         ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float32 path (FP32 matrix cores)", "helfand", 20000, 25000, False, True, False, 2, 1),
         ("configs[4] per-GPU share, float32 path with visc_by_particle (the class default output; FP32 matrix cores): 20000 x 25000 x 3", "helfand", 20000, 25000, True, True, False, 2, 1),

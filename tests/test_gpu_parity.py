@@ -169,6 +169,40 @@ def test_vacf_direct_lag_sums_on_the_matrix_cores(ctx, T, A, D):
     assert scale_rel_err(ts_m, ts_v) < 1e-12
 
 
+@pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 2, 3), (15, 3, 1), (16, 5, 3), (17, 2, 2), (63, 3, 3), (64, 4, 3), (65, 2, 3),
+                                   (240, 4, 3), (241, 3, 3), (255, 7, 3), (256, 3, 3), (257, 9, 1), (271, 4, 2),
+                                   (272, 4, 3), (511, 6, 3), (513, 11, 3), (1000, 37, 3), (2049, 8, 3), (4100, 3, 3),
+                                   (5000, 21, 3), (9000, 3, 1), (300, 2001, 3), (300, 1001, 1)])
+def test_vacf_direct_by_particle_on_the_matrix_cores(ctx, T, A, D):
+    """Windowed VACF WITH the by-particle array (the class default): k_band_bp_vacf (bandbp_kernels.hpp: the
+    MFMA's k-slots filled from the time axis, a particle's column in a per-wave LDS ring) against the oracle
+    and against the vector kernel it replaces ("direct_mfma" 0); frame counts on both sides of the 16-frame
+    blocks, the 64-frame chunks and the 256-lag units, every dim, odd particle counts (columns that start in the
+    second half of a pair), and the same bits on every launch although two units add their halves of some lags."""
+    from oracle import numpy_oracle as orc
+
+    v = orc.synthetic_velocities(T, A, D, seed=2800 + T)
+    want_bp, want_ts = orc.vacf_windowed(v) if T <= 1000 else orc.vacf_fft_batched(v)
+    ctx.set_option("timeline", 1)
+    try:
+        ts_m, bp_m = run_vacf(ctx, v, False, True)
+        assert "k_band_bp_vacf" in [n for n, _ in ctx.kernel_timeline()]
+        ts_again, bp_again = ctx.vacf_direct(by_particle=True)
+        assert np.array_equal(bp_m, bp_again) and np.array_equal(ts_m, ts_again)
+        ctx.set_option("direct_mfma", 0)
+        ts_v, bp_v = ctx.vacf_direct(by_particle=True)
+        assert "k_direct" in [n for n, _ in ctx.kernel_timeline()]
+    finally:
+        ctx.set_option("direct_mfma", 1)
+        ctx.set_option("timeline", 0)
+    assert bp_m.shape == (T, A)
+    assert scale_rel_err(bp_m, want_bp) < TOL and scale_rel_err(ts_m, want_ts) < TOL
+    assert scale_rel_err(bp_m, bp_v) < 1e-12 and scale_rel_err(ts_m, ts_v) < 1e-12
+    # every particle on its own scale (a quiet particle next to a loud one)
+    for n in range(0, A, max(1, A // 7)):
+        assert scale_rel_err(bp_m[:, n], want_bp[:, n]) < TOL
+
+
 @pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 2, 3), (15, 3, 1), (16, 5, 3), (17, 2, 2), (241, 3, 3), (256, 3, 3),
                                    (257, 9, 1), (272, 4, 3), (273, 5, 2), (513, 11, 3), (1000, 37, 3), (2049, 8, 3),
                                    (4100, 3, 3), (5000, 7, 3), (300, 2001, 1)])

@@ -1,0 +1,130 @@
+// bandbp_test.hip — harness for bandbp_kernels.hpp (windowed VACF with the by-particle array on the FP64 matrix cores).
+//   bandbp_test check            small shapes (every dim) against a CPU double loop
+//   bandbp_test time T A [reps]  synthetic slab, dim = 3: ms per launch, TFLOP/s (2 flop per term)
+// build: tools/band/buildbp.sh [SUFFIX] [-DBP_NW=8]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../transport_analysis_amd/csrc/bandbp_kernels.hpp"
+using namespace ta;
+
+#ifndef BP_NW
+#define BP_NW 8
+#endif
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+static double rnd(unsigned long long& s) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    return (double)(s >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+}
+
+__global__ void k_fill(double* p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = (i + 99) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        p[i] = ((double)((z ^ (z >> 31)) >> 11) * (1.0 / 9007199254740992.0) - 0.5) * 2.0;
+    }
+}
+
+template <int D>
+static void launch(int nwg, const double* pm, long pitch, int T, long A, double* out, long ld) {
+    static unsigned long long* counter = nullptr;
+    if (!counter) CK(hipMalloc(&counter, 8));
+    CK(hipMemsetAsync(counter, 0, 8, 0));
+    hipLaunchKernelGGL((k_band_bp_vacf<D, BP_NW>), dim3(nwg), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A, out, ld, counter);
+}
+static void launch_d(int D, int nwg, const double* pm, long pitch, int T, long A, double* out, long ld) {
+    if (D == 1) launch<1>(nwg, pm, pitch, T, A, out, ld);
+    else if (D == 2) launch<2>(nwg, pm, pitch, T, A, out, ld);
+    else launch<3>(nwg, pm, pitch, T, A, out, ld);
+}
+
+static int check_one(int T, long A, int D, int nwg) {
+    const long n_cols = D * A, n_pairs = (n_cols + 1) / 2, pitch = (T + 7) / 8 * 8;
+    std::vector<double> h((size_t)n_pairs * pitch * 2);
+    unsigned long long s = 99 + T * 17 + A + 7 * D;
+    // the rows between T and the pitch hold garbage on purpose: nothing may read them as data
+    for (auto& x : h) x = rnd(s) + 0.25;
+    if (n_cols & 1)
+        for (long t = 0; t < pitch; ++t) h[((n_pairs - 1) * pitch + t) * 2 + 1] = 0.0;
+    double *pm, *out;
+    CK(hipMalloc(&pm, h.size() * 8));
+    CK(hipMemcpy(pm, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&out, 8 * (size_t)A * pitch));
+    CK(hipMemset(out, 0, 8 * (size_t)A * pitch));
+    launch_d(D, nwg, pm, pitch, T, A, out, pitch);
+    CK(hipDeviceSynchronize());
+    std::vector<double> got((size_t)A * pitch);
+    CK(hipMemcpy(got.data(), out, got.size() * 8, hipMemcpyDeviceToHost));
+    double worst = 0;
+    long wa = -1;
+    int wk = -1;
+    for (long a = 0; a < A; ++a) {
+        double scale = 0;
+        std::vector<double> ref(T, 0.0);
+        for (int k = 0; k < T; ++k) {
+            double acc = 0;
+            for (int d = 0; d < D; ++d) {
+                const long c = D * a + d;
+                const double* col = h.data() + (c >> 1) * pitch * 2 + (c & 1);
+                for (int i = 0; i + k < T; ++i) acc += col[2 * i] * col[2 * (i + k)];
+            }
+            ref[k] = acc / (T - k);
+            scale = std::max(scale, std::fabs(ref[k]));
+        }
+        for (int k = 0; k < T; ++k) {
+            const double e = std::fabs(got[a * pitch + k] - ref[k]) / (scale > 0 ? scale : 1.0);
+            if (!(e <= worst)) worst = e, wa = a, wk = k;
+        }
+    }
+    const bool ok = worst < 1e-12;
+    printf("T=%6d A=%5ld D=%d nwg=%3d : worst %.2e of the particle's scale (particle %ld lag %d) %s\n", T, A, D, nwg, worst, wa, wk, ok ? "ok" : "FAIL");
+    (void)hipFree(pm), (void)hipFree(out);
+    return ok ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
+    const char* mode = argc > 1 ? argv[1] : "check";
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    if (!strcmp(mode, "check")) {
+        int bad = 0;
+        const int shapes[][2] = {{1, 2}, {2, 3}, {15, 4}, {16, 5}, {17, 3}, {63, 2}, {64, 3}, {65, 2}, {239, 2}, {240, 3}, {241, 2}, {255, 3},
+                                 {257, 7}, {480, 3}, {481, 5}, {511, 2}, {513, 2}, {1000, 9}, {2049, 3}, {5000, 2}, {300, 700}};
+        for (int D = 1; D <= 3; ++D)
+            for (auto& sh : shapes) bad += check_one(sh[0], sh[1], D, D == 3 ? 256 : 7);
+        printf(bad ? "FAILED %d\n" : "all ok\n", bad);
+        return bad ? 1 : 0;
+    }
+    const int T = argc > 2 ? atoi(argv[2]) : 5000;
+    const long A = argc > 3 ? atol(argv[3]) : 50000;
+    const int reps = argc > 4 ? atoi(argv[4]) : 3;
+    const long n_cols = 3 * A, n_pairs = (n_cols + 1) / 2, pitch = (T + 7) / 8 * 8;
+    double *pm, *out;
+    CK(hipMalloc(&pm, (size_t)n_pairs * pitch * 16));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, pm, (size_t)n_pairs * pitch * 2);
+    CK(hipMalloc(&out, 8 * (size_t)A * pitch));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int wg_per_cu = getenv("BP_WG_PER_CU") ? atoi(getenv("BP_WG_PER_CU")) : 1;
+    for (int r = 0; r <= reps; ++r) {
+        CK(hipEventRecord(e0, 0));
+        CK(hipMemsetAsync(out, 0, 8 * (size_t)A * pitch, 0));
+        launch<3>(prop.multiProcessorCount * wg_per_cu, pm, pitch, T, A, out, pitch);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r) printf("  by-particle windowed VACF (FP64 matrix cores) %d x %ld x 3: %.3f ms  %.1f TFLOP/s (2 flop per term)\n", T, A, ms,
+                      2.0 * (double)T * (T + 1) / 2 * n_cols / (ms * 1e-3) / 1e12);
+    }
+    return 0;
+}

@@ -42,6 +42,7 @@ struct ta_ctx {
     DevBuf pm_in[2];  // pair-major copies of frame-major *_dev inputs
     DevBuf bp_scratch;  // atom-major by-particle results before the transposition
     DevBuf bp_spec;     // per-atom power spectra of one block of atoms (two-kernel by-particle path)
+    DevBuf unit_counter;  // k_band_bp_vacf's work counter
     // staging: pinned host slabs keep the reference's (n_frames, n_atoms, dim) layout, the
     // device slabs are pair-major (layout.hip) with st_pitch rows per column pair
     int64_t st_T = 0, st_A = 0, st_pitch = 0;
@@ -222,6 +223,26 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
             TA_HIP_TRY(ctx, launch_band32_bp(ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, A, scale / (double)D,
                                              (double*)ctx->bp_scratch.p, Tp, st));
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+            tl_mark(ctx, "k_bp_transpose", st);
+            TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp, (double*)ctx->ts_partial.p, st));
+            tl_mark(ctx, "k_sum_partials", st);
+            TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)n_tiles, T, d_lagsum, st));
+            return TA_OK;
+        }
+        (void)hipGetLastError();
+    }
+    // ... and the windowed VACF with its by-particle array (the class default) on the FP64 matrix cores: the k-slots
+    // are filled from the time axis (bandbp_kernels.hpp)
+    if (d_bp && !f32 && !src_f32 && mode == MODE_VACF && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
+        const int64_t Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
+        if (ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
+            ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T) == TA_OK &&
+            ensure(ctx, ctx->unit_counter, 8) == TA_OK) {
+            tl_mark(ctx, "k_band_bp_vacf", st);
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+            TA_HIP_TRY(ctx, launch_band_bp_vacf(ctx->n_cu, (const double*)d_vel, pitch, (int)T, A, D, (double*)ctx->bp_scratch.p, Tp,
+                                                (unsigned long long*)ctx->unit_counter.p, st));
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
             tl_mark(ctx, "k_bp_transpose", st);
             TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp, (double*)ctx->ts_partial.p, st));
@@ -667,7 +688,7 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
                       &ctx->masses, &ctx->bounce, &ctx->stage_buf, &ctx->helf_p,
                       &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1], &ctx->bp_scratch, &ctx->bp_spec,
-                      &ctx->bounce2})
+                      &ctx->bounce2, &ctx->unit_counter})
         if (b->p) hipFree(b->p);
     for (auto& q : ctx->ring)
         for (auto& ev : q)
