@@ -317,14 +317,14 @@ class Case:
         Helfand lag sums: FP32 MFMA (band32_kernels.hpp)"""
         if self.mode == "helfand" and self.helfand_fft:
             return False
-        if self.bp is not None:  # by-particle arrays: the float32 Helfand form (dim = 3) and the float64 windowed VACF
-            return (self.mode == "helfand" and self.float32 and self.D == 3) or (self.mode == "direct" and not self.float32)
+        if self.bp is not None:  # by-particle arrays: the float32 Helfand form (dim = 3) and both float64 forms
+            return (self.mode == "helfand" and self.float32 and self.D == 3) or not self.float32
         return self.mode == "helfand" or (self.mode == "direct" and not self.float32)
 
     def kernel_name(self):
         if self.on_matrix_cores():
             if self.bp is not None:
-                return "k_band32_bp" if self.float32 else "k_band_bp_vacf"
+                return "k_band32_bp" if self.float32 else ("k_band_bp_vacf" if self.mode == "direct" else "k_band_bp_helf")
             return "k_band32_lags" if self.float32 else "k_band_lags"
         if self.mode != "fft" and not (self.mode == "helfand" and self.helfand_fft):
             return "k_direct"
@@ -408,7 +408,8 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
             # 3 flop per term; what the vector kernel's line counts) is `reference_flops_*`:
             # a larger number that says nothing about the pipe
             # (by-particle form: 3 of 4 slots, and units of 16 block lags own 15: 16/15 of the MFMAs)
-            slots = (4.0 / 3.0) * (16.0 / 15.0) if case.bp is not None else 8.0 / 6.0
+            # (float64 by-particle form, k_band_bp_helf: k-slots from the time axis, all four used, no overlap of units)
+            slots = ((4.0 / 3.0) * (16.0 / 15.0) if float32 else 1.0) if case.bp is not None else 8.0 / 6.0
             issued = 2.0 * slots * D * A * T * (T - 1) / 2 / (kernel_ms * 1e-3) / 1e12
             out.update({"achieved": issued, "frac": issued / mpeak,
                         "issued_flops_per_launch": 2.0 * slots * D * A * T * (T - 1) / 2,

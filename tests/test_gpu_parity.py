@@ -237,6 +237,67 @@ def test_helfand_lag_sums_on_the_matrix_cores(ctx, T, A, D):
         assert rel.max() < 1e-9, (rel.argmax() + 1, rel.max())
 
 
+@pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 2, 3), (15, 3, 1), (16, 5, 3), (17, 2, 2), (63, 3, 3), (65, 2, 3), (241, 3, 3),
+                                   (256, 3, 3), (257, 9, 1), (272, 4, 3), (273, 5, 2), (449, 3, 3), (513, 11, 3),
+                                   (1000, 37, 3), (2049, 8, 3), (4100, 3, 3), (5000, 7, 3), (300, 2001, 3), (300, 999, 1)])
+def test_helfand_by_particle_on_the_matrix_cores(ctx, T, A, D):
+    """Einstein-Helfand WITH visc_by_particle (the class default), float64: k_band_bp_helf (bandbp_kernels.hpp: k-slots
+    from the time axis, centred columns and their norms in a per-wave LDS ring) against the oracle
+    (viscosity.py:201-233: difference first) and against the vector kernel ("direct_mfma" 0), particle by particle
+    and lag by lag; P far from zero-mean (positions with an offset and a drift); frame counts on both sides of
+    the 16-frame blocks, the 64-frame chunks, the 256-lag units and the 8-chunk ring; same bits every launch."""
+    from oracle import numpy_oracle as orc
+
+    v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=2900 + T)
+    x = x + 50.0 + 0.01 * np.arange(T)[:, None, None]
+    scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+    want_bp, want_ts = orc.helfand(v, x, m, vol, 300.0)
+    ctx.set_option("timeline", 1)
+    try:
+        ts_m, bp_m = run_helfand(ctx, v, x, m, scale, True)
+        assert "k_band_bp_helf" in [n for n, _ in ctx.kernel_timeline()]
+        ts_again, bp_again = ctx.helfand_msd(m, scale, by_particle=True)
+        assert np.array_equal(bp_m, bp_again) and np.array_equal(ts_m, ts_again)
+        ctx.set_option("direct_mfma", 0)
+        ts_v, bp_v = ctx.helfand_msd(m, scale, by_particle=True)
+        assert "k_direct" in [n for n, _ in ctx.kernel_timeline()]
+    finally:
+        ctx.set_option("direct_mfma", 1)
+        ctx.set_option("timeline", 0)
+    assert bp_m.shape == (T, A) and not bp_m[0].any()
+    assert scale_rel_err(bp_m, want_bp) < TOL and scale_rel_err(ts_m, want_ts) < TOL
+    assert scale_rel_err(bp_m, bp_v) < 1e-12
+    if T > 1:  # lag by lag, particle by particle: short lags are orders of magnitude below the long ones
+        rel = np.abs(bp_m[1:] - bp_v[1:]) / np.abs(bp_v[1:])
+        assert rel.max() < 1e-9, (np.unravel_index(rel.argmax(), rel.shape), rel.max())
+
+
+def test_helfand_by_particle_matrix_cores_on_a_pure_trend_and_in_other_units(ctx):
+    """v = t, x = t^2 / 2 (P = m t^3 / 2: nine orders of magnitude, small lag-1 differences) by particle, every lag
+    against the vector kernel; and P scaled by 1e-12 ... 1e+8: the result scales with the square."""
+    from oracle import numpy_oracle as orc
+
+    T = 3000
+    v, x = step(T)
+    m = np.array([1.0, 2.0])
+    v = np.repeat(v[:, :1], 2, axis=1) * np.array([1.0, 0.5])[None, :, None]
+    x = np.repeat(x[:, :1], 2, axis=1)
+    _, bp_m = run_helfand(ctx, v, x, m, 1.0, True)
+    ctx.set_option("direct_mfma", 0)
+    try:
+        _, bp_v = ctx.helfand_msd(m, 1.0, by_particle=True)
+    finally:
+        ctx.set_option("direct_mfma", 1)
+    rel = np.abs(bp_m[1:] - bp_v[1:]) / np.abs(bp_v[1:])
+    assert rel.max() < 1e-10, (np.unravel_index(rel.argmax(), rel.shape), rel.max())
+    T, A = 700, 13
+    v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=98)
+    _, base = run_helfand(ctx, v, x, m, 1.0, True)
+    for sv, sx in ((1e-6, 1e-6), (1e4, 1e4), (1e-3, 1.0)):
+        _, got = run_helfand(ctx, v * sv, x * sx, m, 1.0, True)
+        assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL, (sv, sx)
+
+
 def test_helfand_matrix_cores_on_a_pure_trend(ctx):
     """The case the plain expansion S1 - 2 S2 loses (3.6e-9 on the reference's own
     step trajectory): v = t, x = t^2 / 2, so P = m t^3 / 2 grows by nine orders of magnitude while

@@ -1,6 +1,7 @@
 // bandbp_test.hip — harness for bandbp_kernels.hpp (windowed VACF with the by-particle array on the FP64 matrix cores).
 //   bandbp_test check            small shapes (every dim) against a CPU double loop
 //   bandbp_test time T A [reps]  synthetic slab, dim = 3: ms per launch, TFLOP/s (2 flop per term)
+//   bandbp_test hcheck | htime T A [reps]   the same for the Einstein-Helfand form (k_band_bp_helf)
 // build: tools/band/buildbp.sh [SUFFIX] [-DBP_NW=8]
 #include <hip/hip_runtime.h>
 
@@ -44,6 +45,77 @@ static void launch_d(int D, int nwg, const double* pm, long pitch, int T, long A
     if (D == 1) launch<1>(nwg, pm, pitch, T, A, out, ld);
     else if (D == 2) launch<2>(nwg, pm, pitch, T, A, out, ld);
     else launch<3>(nwg, pm, pitch, T, A, out, ld);
+}
+
+template <int D>
+static void launch_h(int nwg, const double* pm, long pitch, int T, long A, double* out, long ld) {
+    static unsigned long long* counter = nullptr;
+    if (!counter) CK(hipMalloc(&counter, 8));
+    CK(hipMemsetAsync(counter, 0, 8, 0));
+    hipLaunchKernelGGL((k_band_bp_helf<D, BP_NW>), dim3(nwg), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A, 1.0, out, ld, counter);
+}
+static void launch_hd(int D, int nwg, const double* pm, long pitch, int T, long A, double* out, long ld) {
+    if (D == 1) launch_h<1>(nwg, pm, pitch, T, A, out, ld);
+    else if (D == 2) launch_h<2>(nwg, pm, pitch, T, A, out, ld);
+    else launch_h<3>(nwg, pm, pitch, T, A, out, ld);
+}
+
+// Helfand form: kind 0 noise around 1000, 1 a drifting random walk, 2 tiny values, 3 a pure cubic trend
+static int hcheck_one(int T, long A, int D, int nwg, int kind) {
+    const long n_cols = D * A, n_pairs = (n_cols + 1) / 2, pitch = (T + 7) / 8 * 8;
+    std::vector<double> h((size_t)n_pairs * pitch * 2);
+    unsigned long long s = 99 + T * 17 + A + 7 * D + kind;
+    for (long pr = 0; pr < n_pairs; ++pr)
+        for (int c = 0; c < 2; ++c) {
+            double walk = 0;
+            for (long t = 0; t < pitch; ++t) {
+                const double x = (double)t / 100.0 + c;
+                double v = kind == 0 ? rnd(s) + 1000.0 : kind == 1 ? (walk += rnd(s) + 0.05) + 300.0 : kind == 2 ? 1e-12 * (rnd(s) + 3.0)
+                                                                                                            : x * x * x + 5.0 * pr;
+                h[(pr * pitch + t) * 2 + c] = v;  // (rows between T and the pitch hold data too: nothing may read them)
+            }
+        }
+    if (n_cols & 1)
+        for (long t = 0; t < pitch; ++t) h[((n_pairs - 1) * pitch + t) * 2 + 1] = 0.0;
+    double *pm, *out;
+    CK(hipMalloc(&pm, h.size() * 8));
+    CK(hipMemcpy(pm, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMalloc(&out, 8 * (size_t)A * pitch));
+    CK(hipMemset(out, 0, 8 * (size_t)A * pitch));
+    launch_hd(D, nwg, pm, pitch, T, A, out, pitch);
+    CK(hipDeviceSynchronize());
+    std::vector<double> got((size_t)A * pitch);
+    CK(hipMemcpy(got.data(), out, got.size() * 8, hipMemcpyDeviceToHost));
+    double worst = 0, worst_rel = 0;
+    long wa = -1;
+    int wk = -1;
+    for (long a = 0; a < A; ++a) {
+        double scale = 0;
+        std::vector<double> ref(T, 0.0);
+        for (int k = 1; k < T; ++k) {
+            double acc = 0;
+            for (int d = 0; d < D; ++d) {
+                const long c = D * a + d;
+                const double* col = h.data() + (c >> 1) * pitch * 2 + (c & 1);
+                for (int i = 0; i + k < T; ++i) {
+                    const double df = col[2 * i] - col[2 * (i + k)];
+                    acc += df * df;
+                }
+            }
+            ref[k] = acc / (T - k);
+            scale = std::max(scale, ref[k]);
+        }
+        for (int k = 0; k < T; ++k) {
+            const double e = std::fabs(got[a * pitch + k] - ref[k]) / (scale > 0 ? scale : 1.0);
+            if (!(e <= worst)) worst = e, wa = a, wk = k;
+            if (ref[k] > 0) worst_rel = std::max(worst_rel, std::fabs(got[a * pitch + k] - ref[k]) / ref[k]);
+        }
+    }
+    const bool ok = worst < 1e-11 && worst_rel < (kind == 3 ? 1e-9 : 1e-10);
+    printf("helfand kind %d T=%6d A=%5ld D=%d nwg=%3d : worst %.2e of the particle's scale (particle %ld lag %d), lag by lag %.2e %s\n", kind, T, A,
+           D, nwg, worst, wa, wk, worst_rel, ok ? "ok" : "FAIL");
+    (void)hipFree(pm), (void)hipFree(out);
+    return ok ? 0 : 1;
 }
 
 static int check_one(int T, long A, int D, int nwg) {
@@ -103,6 +175,17 @@ int main(int argc, char** argv) {
         printf(bad ? "FAILED %d\n" : "all ok\n", bad);
         return bad ? 1 : 0;
     }
+    if (!strcmp(mode, "hcheck")) {
+        int bad = 0;
+        const int shapes[][2] = {{1, 2}, {2, 3}, {15, 4}, {16, 5}, {17, 3}, {63, 2}, {64, 3}, {65, 2}, {239, 2}, {240, 3}, {241, 2}, {255, 3},
+                                 {257, 7}, {449, 3}, {480, 3}, {481, 5}, {511, 2}, {513, 2}, {1000, 9}, {2049, 3}, {5000, 2}, {300, 700}};
+        for (int D = 1; D <= 3; ++D)
+            for (auto& sh : shapes) bad += hcheck_one(sh[0], sh[1], D, D == 3 ? 256 : 7, 0);
+        for (int kind : {1, 2, 3}) bad += hcheck_one(1000, 5, 3, 256, kind) + hcheck_one(4100, 2, 3, 256, kind) + hcheck_one(700, 3, 2, 3, kind);
+        printf(bad ? "FAILED %d\n" : "all ok\n", bad);
+        return bad ? 1 : 0;
+    }
+    const bool helf = !strcmp(mode, "htime");
     const int T = argc > 2 ? atoi(argv[2]) : 5000;
     const long A = argc > 3 ? atol(argv[3]) : 50000;
     const int reps = argc > 4 ? atoi(argv[4]) : 3;
@@ -118,12 +201,13 @@ int main(int argc, char** argv) {
     for (int r = 0; r <= reps; ++r) {
         CK(hipEventRecord(e0, 0));
         CK(hipMemsetAsync(out, 0, 8 * (size_t)A * pitch, 0));
-        launch<3>(prop.multiProcessorCount * wg_per_cu, pm, pitch, T, A, out, pitch);
+        if (helf) launch_h<3>(prop.multiProcessorCount * wg_per_cu, pm, pitch, T, A, out, pitch);
+        else launch<3>(prop.multiProcessorCount * wg_per_cu, pm, pitch, T, A, out, pitch);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
-        if (r) printf("  by-particle windowed VACF (FP64 matrix cores) %d x %ld x 3: %.3f ms  %.1f TFLOP/s (2 flop per term)\n", T, A, ms,
+        if (r) printf("  by-particle %s (FP64 matrix cores) %d x %ld x 3: %.3f ms  %.1f TFLOP/s (2 flop per term)\n", helf ? "Helfand" : "windowed VACF", T, A, ms,
                       2.0 * (double)T * (T + 1) / 2 * n_cols / (ms * 1e-3) / 1e12);
     }
     return 0;

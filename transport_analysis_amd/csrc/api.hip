@@ -252,6 +252,31 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         }
         (void)hipGetLastError();
     }
+    // ... and the Einstein-Helfand by-particle array (float64) the same way, on the product slab
+    if (d_bp && !f32 && !src_f32 && mode == MODE_HELFAND && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
+        const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2, Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
+        const int n_parts = (int)std::min<int64_t>(1024, n_pairs);
+        if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)) == TA_OK &&
+            ensure(ctx, ctx->helf_small, sizeof(double) * (size_t)n_parts * T) == TA_OK &&
+            ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
+            ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T) == TA_OK &&
+            ensure(ctx, ctx->unit_counter, 8) == TA_OK) {
+            tl_mark(ctx, "k_helfand_product", st);
+            TA_HIP_TRY(ctx, launch_helfand_product((const double*)d_vel, (const double*)d_pos, d_masses, pitch, T, n_cols, D,
+                                                   (double*)ctx->helf_p.p, (double*)ctx->helf_small.p, n_parts, st));
+            tl_mark(ctx, "k_band_bp_helf", st);
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+            TA_HIP_TRY(ctx, launch_band_bp_helf(ctx->n_cu, (const double*)ctx->helf_p.p, pitch, (int)T, A, D, scale / (double)D,
+                                                (double*)ctx->bp_scratch.p, Tp, (unsigned long long*)ctx->unit_counter.p, st));
+            TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+            tl_mark(ctx, "k_bp_transpose", st);
+            TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp, (double*)ctx->ts_partial.p, st));
+            tl_mark(ctx, "k_sum_partials", st);
+            TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, (int)n_tiles, T, d_lagsum, st));
+            return TA_OK;
+        }
+        (void)hipGetLastError();
+    }
     if (band_ok && mode == MODE_VACF) {
         tl_mark(ctx, "k_band_lags", st);
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));

@@ -158,4 +158,224 @@ __global__ void __launch_bounds__(64 * NW)
     }
 }
 
+// ---- Einstein-Helfand WITH the by-particle array (float64) ---------------------------------------------------
+// results.visc_by_particle of /root/reference/transport_analysis/viscosity.py:201-233, the class default:
+//   H[k, n] = factor * sum_{i < T-k} sum_d (P[i, n, d] - P[i+k, n, d])^2 / (T - k),   P = (m v) x (the product slab).
+// Same units, ring and k-slots as k_band_bp_vacf; (a - b)^2 = |a|^2 + |b|^2 - 2 a.b with a = P[i] - r, b = P[j] - r for a
+// reference row r near frame i (the first A frame of every pass of four super-steps, 256 frames: the three terms stay of
+// the size of the result for all but the shortest lags of a smooth series, as in band_kernels.hpp):
+//  * the ring holds the CENTRED columns and, as one more column, the rows' squared norms |b|^2; a new reference moves
+//    the ring's contents by r_old - r_new;
+//  * a.b: dim MFMAs per super-step and block lag, all four k-slots doing arithmetic (the norms need no slot here);
+//  * |b|^2 does not depend on the A row: per block lag ONE vector add of the norm column's window (nbacc), reduced
+//    over the k-slots at the end; |a|^2 does not depend on the block lag: one running sum per lane (na);
+//  * super-steps that touch frames >= T ("tail": the last ~14 of a unit) zero the centred values of such frames and
+//    put |a|^2 through the product with the B side's validity instead (-|a|^2/2 x valid: one more MFMA per block
+//    lag), and skip block lags whose whole window lies behind the series.
+__device__ __forceinline__ double band_first_lane(double x) {
+    const band_u2 w = __builtin_bit_cast(band_u2, x);
+    return __builtin_bit_cast(double, band_u2{(unsigned)__builtin_amdgcn_readfirstlane((int)w.x),
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)w.y)});
+}
+
+// P: pair-major float64 product slab of n_atoms * D columns.  bp_am[particle * ld_am + lag] = factor * H-sum / (T - lag),
+// lag 0 exactly 0; bp_am and *next_unit must be ZERO on entry.  grid: any number of workgroups of 64 NW threads.
+template <int D, int NW>
+__global__ void __launch_bounds__(64 * NW)
+    k_band_bp_helf(const double* __restrict__ P, long pitch, int T, long n_atoms, double factor, double* __restrict__ bp_am,
+                   long ld_am, unsigned long long* __restrict__ next_unit) {
+    static_assert(D >= 1 && D <= 3, "a particle's columns lie in at most two column pairs");
+    constexpr int NR = D + 1;  // rings: the centred columns and the rows' squared norms
+    static_assert(NR * kBpRingFrames >= 2 * 16 * 32 + 16, "the epilogue's scratch reuses the ring");
+    __shared__ double ringB[NW][NR][kBpRingFrames];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nblk = (T + 15) / 16, n_groups = (nblk + 15) / 16;
+    const long n_units = n_atoms * n_groups;
+    double(*rB)[kBpRingFrames] = ringB[wave];
+    for (;;) {
+        unsigned long long taken = 0;
+        if (lane == 0) taken = atomicAdd(next_unit, 1ull);
+        const long u = (long)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(taken >> 32)) << 32) |
+                              (unsigned)__builtin_amdgcn_readfirstlane((int)taken));
+        if (u >= n_units) break;
+        const long atom = __builtin_amdgcn_readfirstlane((int)(u / n_groups));
+        const int g = __builtin_amdgcn_readfirstlane((int)(u - atom * n_groups)), d0 = 16 * g;
+        __amdgpu_buffer_rsrc_t rs[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const long col = (long)D * atom + c;
+            rs[c] = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(P + (col >> 1) * pitch * 2 + (col & 1)), 0,
+                                                      16 * T - 8 * (int)(col & 1), 0x00020000);
+        }
+        auto load = [&](int c, int f0) -> double {  // frames f0 ... f0 + 63 of column c, one per lane; zeros behind the series
+            return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs[c], (f0 + lane) * 16, 0, 0));
+        };
+        const int n_super = (nblk - d0 + 3) / 4, fB = 16 * d0;
+        band_d4 acc[16];
+        double nbacc[16], na = 0.0;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc[d] = band_d4{0.0, 0.0, 0.0, 0.0}, nbacc[d] = 0.0;
+        double sa[D], sb[D], r[D];
+        // raw rows of chunk `pos` (frames fbase ...) -> centred columns and their norms in the ring
+        auto write_chunk = [&]<bool TAIL>(int pos, int fbase, const double(&raw)[D]) {
+            double nb = 0.0;
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double b = raw[c] - r[c];
+                if (TAIL && !(fbase + lane < T)) b = 0.0;
+                rB[c][64 * pos + lane] = b;
+                if (pos == 0) rB[c][64 * kBpChunks + lane] = b;
+                nb = __builtin_fma(b, b, nb);
+            }
+            rB[D][64 * pos + lane] = nb;
+            if (pos == 0) rB[D][64 * kBpChunks + lane] = nb;
+        };
+#pragma unroll
+        for (int c = 0; c < D; ++c) sa[c] = load(c, 0), r[c] = band_first_lane(sa[c]);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            double x[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) x[c] = load(c, fB + 64 * n);
+            write_chunk.template operator()<true>(n, fB + 64 * n, x);
+        }
+#pragma unroll
+        for (int c = 0; c < D; ++c) sb[c] = load(c, fB + 64 * 5);
+        int S = 0;
+        // one super-step; a == S % 8 (a constant once unrolled)
+        auto body = [&]<bool TAIL>(int a) {
+            if (a % 4 == 0 && S != 0) {  // a new pass: a new reference row, which the ring's contents follow
+                double delta[D];
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    const double rn = band_first_lane(sa[c]);
+                    delta[c] = r[c] - rn, r[c] = rn;
+                }
+#pragma unroll
+                for (int q = 0; q <= kBpChunks; ++q) {
+                    const int k = ((q % kBpChunks) - a + kBpChunks) % kBpChunks;  // position q holds chunk S + k (k <= 4) or the dead S + k - 8
+                    const int fbase = fB + 64 * (S + (k <= 4 ? k : k - kBpChunks));
+                    double nb = 0.0;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        double b = rB[c][64 * q + lane] + delta[c];
+                        if (TAIL && !(fbase + lane < T)) b = 0.0;
+                        rB[c][64 * q + lane] = b;
+                        nb = __builtin_fma(b, b, nb);
+                    }
+                    rB[D][64 * q + lane] = nb;
+                }
+            }
+            double A[D], asq = 0.0;
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                A[c] = sa[c] - r[c];
+                if (TAIL && !(64 * S + lane < T)) A[c] = 0.0;
+                asq = __builtin_fma(A[c], A[c], asq);
+            }
+            write_chunk.template operator()<TAIL>((a + 5) % kBpChunks, fB + 64 * (S + 5), sb);  // chunk S + 5 (first read by super-step S + 1)
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                sb[c] = load(c, fB + 64 * (S + 6));
+                sa[c] = load(c, 64 * (S + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the requests stay here, a super-step ahead of their use
+            if constexpr (!TAIL) {
+                na += asq;
+#pragma unroll
+                for (int c = 0; c < D; ++c)
+#pragma unroll
+                    for (int d = 0; d < 16; ++d)
+                        acc[d] = TA_BAND_MFMA(A[c], rB[c][(64 * a + 16 * d) % (64 * kBpChunks) + lane], acc[d]);
+#pragma unroll
+                for (int d = 0; d < 16; ++d) nbacc[d] += rB[D][(64 * a + 16 * d) % (64 * kBpChunks) + lane];
+            } else {
+                const double Ah = -0.5 * asq;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const int j0 = 64 * S + 16 * (d0 + d);  // the window's first frame
+                    if (j0 >= T) continue;                  // (wave-uniform) nothing of this block lag is left
+                    const int w = (64 * a + 16 * d) % (64 * kBpChunks) + lane;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) acc[d] = TA_BAND_MFMA(A[c], rB[c][w], acc[d]);
+                    nbacc[d] += rB[D][w];
+                    acc[d] = TA_BAND_MFMA(Ah, j0 + lane < T ? 1.0 : 0.0, acc[d]);  // -|a|^2 / 2 where the pair's later frame exists
+                }
+            }
+        };
+        // whole passes of 8 super-steps none of whose requests reaches frame T: S + 6 is the farthest chunk touched
+        const int n_ok = (T - fB) / 64 - 6;
+        const int S_bulk = (n_ok < n_super ? (n_ok > 0 ? n_ok : 0) : n_super) / kBpChunks * kBpChunks;
+        while (S < S_bulk) {
+#pragma unroll
+            for (int a = 0; a < kBpChunks; ++a) {
+                body.template operator()<false>(a);
+                ++S;
+            }
+        }
+        for (bool more = S < n_super; more;) {
+#pragma unroll
+            for (int a = 0; a < kBpChunks; ++a) {
+                body.template operator()<true>(a);
+                if (++S == n_super) {
+                    more = false;
+                    break;
+                }
+            }
+        }
+        // (a - b)^2 summed = NA[m] + NB_d[n] - 2 acc_d[m][n]; diagonals as above
+        __builtin_amdgcn_wave_barrier();
+        double* blk = &rB[0][0];   // [16][32]
+        double* dsum = blk + 512;  // [16][32]
+        double* nas = dsum + 512;  // [16]
+        double na_m[4];
+        {
+            const double tot = band_sum_rows(na);  // every lane: NA[lane & 15]
+            if (lane < 16) nas[lane] = tot;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) na_m[r4] = nas[4 * r4 + (lane >> 4)];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) blk[64 * q + lane] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        const int skew = (lane & 15) - (lane >> 4) + 15, half = lane >> 5, col = lane & 31;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const double nbd = band_sum_rows(nbacc[d]);  // NB_d[lane & 15]
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                blk[(4 * r4 + (lane >> 4)) * 32 + skew - 4 * r4] = __builtin_fma(-2.0, acc[d][r4], na_m[r4] + nbd);
+            __builtin_amdgcn_wave_barrier();
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += blk[(8 * half + j) * 32 + col];
+            s = band_sum_halves(s);
+            if (lane < 32) dsum[d * 32 + lane] = s;
+            __builtin_amdgcn_wave_barrier();
+        }
+        double* out = bp_am + atom * ld_am;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int off = lane + 64 * k;
+            const long lag = 256L * g + off;
+            if (lag < T) {
+                const int d = off >> 4, e = off & 15;
+                double s = dsum[d * 32 + e + 15];
+                if (d < 15 || e == 0) {
+                    if (e >= 1) s += dsum[(d + 1) * 32 + e - 16 + 15];
+                    out[lag] = lag == 0 ? 0.0 : factor * s / (double)(T - lag);
+                } else {
+                    unsafeAtomicAdd(out + lag, factor * s / (double)(T - lag));
+                }
+            }
+        }
+        if (g > 0 && lane >= 1 && lane < 16) {
+            const long lag = 256L * g - 16 + lane;
+            if (lag < T) unsafeAtomicAdd(out + lag, factor * dsum[lane - 16 + 15] / (double)(T - lag));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace ta
