@@ -205,12 +205,15 @@ def test_vacf_direct_by_particle_on_the_matrix_cores(ctx, T, A, D):
 
 @pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 2, 3), (15, 3, 1), (16, 5, 3), (17, 2, 2), (241, 3, 3), (256, 3, 3),
                                    (257, 9, 1), (272, 4, 3), (273, 5, 2), (513, 11, 3), (1000, 37, 3), (2049, 8, 3),
-                                   (4100, 3, 3), (5000, 7, 3), (300, 2001, 1)])
-def test_helfand_lag_sums_on_the_matrix_cores(ctx, T, A, D):
-    """Einstein-Helfand mean squared differences without the by-particle array: k_band_lags<helfand>
-    on the product slab (rows centred on a nearby frame, norms carried in the fourth lane group)
-    against the oracle (viscosity.py:201-233: difference first) and against the vector kernel
-    ("direct_mfma" 0); positions with a large offset and a drift, so that P is far from zero-mean."""
+                                   (4100, 3, 3), (5000, 7, 3), (300, 2001, 1), (300, 2001, 3)])
+@pytest.mark.parametrize("form", [1, 2])
+def test_helfand_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
+    """Einstein-Helfand mean squared differences without the by-particle array, both matrix-core forms:
+    "direct_mfma" 1 (the default) k_band_bp_helf with a unit's particles summed in its accumulators (k-slots from
+    the time axis), 2 the column-packed k_band_lags<helfand> (norms carried in the fourth lane group); both on
+    the product slab with rows centred on a nearby frame, against the oracle (viscosity.py:201-233: difference
+    first) and against the vector kernel ("direct_mfma" 0); positions with a large offset and a drift, so that P
+    is far from zero-mean."""
     from oracle import numpy_oracle as orc
 
     v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=2700 + T)
@@ -218,9 +221,10 @@ def test_helfand_lag_sums_on_the_matrix_cores(ctx, T, A, D):
     scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
     want_ts = orc.helfand(v, x, m, vol, 300.0)[1]
     ctx.set_option("timeline", 1)
+    ctx.set_option("direct_mfma", form)
     try:
         ts_m, _ = run_helfand(ctx, v, x, m, scale, False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_lags"]
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_bp_helf" if form == 1 else "k_band_lags"]
         ts_again, _ = ctx.helfand_msd(m, scale, by_particle=False)
         assert np.array_equal(ts_m, ts_again)
         ctx.set_option("direct_mfma", 0)
@@ -298,15 +302,18 @@ def test_helfand_by_particle_matrix_cores_on_a_pure_trend_and_in_other_units(ctx
         assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL, (sv, sx)
 
 
-def test_helfand_matrix_cores_on_a_pure_trend(ctx):
+@pytest.mark.parametrize("form", [1, 2])
+def test_helfand_matrix_cores_on_a_pure_trend(ctx, form):
     """The case the plain expansion S1 - 2 S2 loses (3.6e-9 on the reference's own
     step trajectory): v = t, x = t^2 / 2, so P = m t^3 / 2 grows by nine orders of magnitude while
-    the lag-1 differences stay small.  Every lag against the vector kernel (difference first)."""
+    the lag-1 differences stay small.  Every lag against the vector kernel (difference first); both
+    matrix-core forms ("direct_mfma" 1 / 2)."""
     T = 3000
     v, x = step(T)
     m = np.array([1.0, 2.0])
     v = np.repeat(v[:, :1], 2, axis=1) * np.array([1.0, 0.5])[None, :, None]
     x = np.repeat(x[:, :1], 2, axis=1)
+    ctx.set_option("direct_mfma", form)
     ts_m, _ = run_helfand(ctx, v, x, m, 1.0, False)
     ctx.set_option("direct_mfma", 0)
     try:
@@ -1615,7 +1622,15 @@ def test_helfand_matrix_cores_do_not_depend_on_the_unit(ctx):
     try:
         for sv, sx in ((1e-6, 1e-6), (1e4, 1e4), (1e-3, 1.0)):
             got, _ = run_helfand(ctx, v * sv, x * sx, m, 1.0, False)
+            assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_bp_helf"]
+            assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL, (sv, sx)
+        ctx.set_option("direct_mfma", 2)  # the column-packed form
+        base2, _ = run_helfand(ctx, v, x, m, 1.0, False)
+        assert scale_rel_err(base2, base) < 1e-12
+        for sv, sx in ((1e-6, 1e-6), (1e4, 1e4), (1e-3, 1.0)):
+            got, _ = run_helfand(ctx, v * sv, x * sx, m, 1.0, False)
             assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_lags"]
             assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL, (sv, sx)
     finally:
+        ctx.set_option("direct_mfma", 1)
         ctx.set_option("timeline", 0)

@@ -52,7 +52,7 @@ static void launch_h(int nwg, const double* pm, long pitch, int T, long A, doubl
     static unsigned long long* counter = nullptr;
     if (!counter) CK(hipMalloc(&counter, 8));
     CK(hipMemsetAsync(counter, 0, 8, 0));
-    hipLaunchKernelGGL((k_band_bp_helf<D, BP_NW>), dim3(nwg), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A, 1.0, out, ld, counter);
+    hipLaunchKernelGGL((k_band_bp_helf<D, BP_NW, false>), dim3(nwg), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A, 1.0, out, ld, counter, 1, (double*)nullptr);
 }
 static void launch_hd(int D, int nwg, const double* pm, long pitch, int T, long A, double* out, long ld) {
     if (D == 1) launch_h<1>(nwg, pm, pitch, T, A, out, ld);
@@ -184,6 +184,38 @@ int main(int argc, char** argv) {
         for (int kind : {1, 2, 3}) bad += hcheck_one(1000, 5, 3, 256, kind) + hcheck_one(4100, 2, 3, 256, kind) + hcheck_one(700, 3, 2, 3, kind);
         printf(bad ? "FAILED %d\n" : "all ok\n", bad);
         return bad ? 1 : 0;
+    }
+    if (!strcmp(mode, "hltime")) {  // lag sums alone through the same kernel (per_unit particles per unit)
+        const int T = argc > 2 ? atoi(argv[2]) : 20000;
+        const long A = argc > 3 ? atol(argv[3]) : 25000;
+        const int per = argc > 4 ? atoi(argv[4]) : 16;
+        const long n_cols = 3 * A, n_pairs = (n_cols + 1) / 2, pitch = (T + 7) / 8 * 8;
+        const int n_groups = ((T + 15) / 16 + 15) / 16;
+        const long n_pb = (A + per - 1) / per;
+        double *pm, *partial, *lagsum;
+        unsigned long long* counter;
+        CK(hipMalloc(&pm, (size_t)n_pairs * pitch * 16));
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, pm, (size_t)n_pairs * pitch * 2);
+        CK(hipMalloc(&partial, 8 * (size_t)n_pb * n_groups * kBandPartial));
+        CK(hipMalloc(&lagsum, 8 * (size_t)T));
+        CK(hipMalloc(&counter, 8));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        for (int r = 0; r < 3; ++r) {
+            CK(hipEventRecord(e0, 0));
+            CK(hipMemsetAsync(counter, 0, 8, 0));
+            hipLaunchKernelGGL((k_band_bp_helf<3, BP_NW, true>), dim3(prop.multiProcessorCount), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A, 1.0,
+                               (double*)nullptr, 0L, counter, per, partial);
+            hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 255) / 256), dim3(256), 0, 0, partial, n_pb, n_groups, T, 1.0, lagsum);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r) printf("  Helfand lag sums (FP64 matrix cores, %d particles per unit) %d x %ld x 3: %.3f ms  %.1f TFLOP/s (2 flop per term)\n", per, T, A,
+                          ms, 2.0 * (double)T * (T - 1) / 2 * n_cols / (ms * 1e-3) / 1e12);
+        }
+        return 0;
     }
     const bool helf = !strcmp(mode, "htime");
     const int T = argc > 2 ? atoi(argv[2]) : 5000;

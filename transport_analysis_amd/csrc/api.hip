@@ -285,14 +285,28 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         return TA_OK;
     }
     if (band_ok && mode == MODE_HELFAND) {
-        // the product slab P = (m v) x first (T*A*D*8 bytes more; without them: the vector kernel)
+        // the product slab P = (m v) x first (T*A*D*8 bytes more; without them: the vector kernel); then the kernel of the
+        // by-particle form with the particles of a unit summed in its accumulators (k-slots from the time axis: all four do
+        // arithmetic, where the column-packed k_band_lags<true> gives two of its eight to the norms: 445 against 646 ms per
+        // configs[4] share).  "direct_mfma" 2 selects the column-packed form.
         const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2;
         const int n_parts = (int)std::min<int64_t>(1024, n_pairs);
+        const bool time_packed = ctx->opt_direct_mfma != 2;
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)) == TA_OK &&
-            ensure(ctx, ctx->helf_small, sizeof(double) * (size_t)n_parts * T) == TA_OK) {
+            ensure(ctx, ctx->helf_small, sizeof(double) * (size_t)n_parts * T) == TA_OK &&
+            (!time_packed || (ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
+                              ensure(ctx, ctx->unit_counter, 8) == TA_OK))) {
             tl_mark(ctx, "k_helfand_product", st);
             TA_HIP_TRY(ctx, launch_helfand_product((const double*)d_vel, (const double*)d_pos, d_masses, pitch, T, n_cols, D,
                                                    (double*)ctx->helf_p.p, (double*)ctx->helf_small.p, n_parts, st));
+            if (time_packed) {
+                tl_mark(ctx, "k_band_bp_helf", st);
+                TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+                TA_HIP_TRY(ctx, launch_band_bp_helf_lags(ctx->n_cu, (const double*)ctx->helf_p.p, pitch, (int)T, A, D, scale / (double)D,
+                                                         (double*)ctx->bp_scratch.p, (unsigned long long*)ctx->unit_counter.p, d_lagsum, st));
+                TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+                return TA_OK;
+            }
             tl_mark(ctx, "k_band_lags", st);
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
             TA_HIP_TRY(ctx, launch_band_lags(&ctx->band, ctx->n_cu, true, (const double*)ctx->helf_p.p, pitch, (int)T, n_cols,

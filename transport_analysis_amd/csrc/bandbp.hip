@@ -32,10 +32,41 @@ hipError_t launch_band_bp_helf(int n_cu, const double* P, long pitch, int T, lon
     if (e == hipSuccess) e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
     const dim3 grid(std::max(1, n_cu)), block(64 * kWaves);
-    if (D == 1) hipLaunchKernelGGL((k_band_bp_helf<1, kWaves>), grid, block, 0, st, P, pitch, T, n_atoms, factor, bp_am, ld_am, next_unit);
-    else if (D == 2) hipLaunchKernelGGL((k_band_bp_helf<2, kWaves>), grid, block, 0, st, P, pitch, T, n_atoms, factor, bp_am, ld_am, next_unit);
-    else if (D == 3) hipLaunchKernelGGL((k_band_bp_helf<3, kWaves>), grid, block, 0, st, P, pitch, T, n_atoms, factor, bp_am, ld_am, next_unit);
+    double* none = nullptr;
+    if (D == 1) hipLaunchKernelGGL((k_band_bp_helf<1, kWaves, false>), grid, block, 0, st, P, pitch, T, n_atoms, factor, bp_am, ld_am, next_unit, 1, none);
+    else if (D == 2) hipLaunchKernelGGL((k_band_bp_helf<2, kWaves, false>), grid, block, 0, st, P, pitch, T, n_atoms, factor, bp_am, ld_am, next_unit, 1, none);
+    else if (D == 3) hipLaunchKernelGGL((k_band_bp_helf<3, kWaves, false>), grid, block, 0, st, P, pitch, T, n_atoms, factor, bp_am, ld_am, next_unit, 1, none);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ... and its lag sums alone (by_particle=False): lagsum[k] = factor * sum over particles, columns and origins of (dP)^2 / (n_frames - k),
+// lagsum[0] = 0.  A unit = one group of 16 block lags of band_bp_helf_block() consecutive particles.
+// partial: band_bp_helf_partial_doubles() doubles of scratch.
+int band_bp_helf_block(int n_cu, int T, long n_atoms) {
+    // short enough for the last units not to leave the chip idle (a unit of 16 particles: ~2 ms at 20000 frames), long enough to
+    // amortise the epilogue; fewer when there are not ~8 units per wave otherwise
+    const long n_groups = ((T + 15) / 16 + 15) / 16, want = 8L * 8 * std::max(1, n_cu);
+    return (int)std::max<long>(1, std::min<long>(16, n_atoms * n_groups / want));
+}
+size_t band_bp_helf_partial_doubles(int n_cu, int T, long n_atoms) {
+    const long per = band_bp_helf_block(n_cu, T, n_atoms), n_pb = (n_atoms + per - 1) / per, n_groups = ((T + 15) / 16 + 15) / 16;
+    return (size_t)n_pb * n_groups * kBandPartial;
+}
+hipError_t launch_band_bp_helf_lags(int n_cu, const double* P, long pitch, int T, long n_atoms, int D, double factor, double* partial,
+                                    unsigned long long* next_unit, double* lagsum, hipStream_t st) {
+    constexpr int kWaves = 8;
+    const int per = band_bp_helf_block(n_cu, T, n_atoms), n_groups = ((T + 15) / 16 + 15) / 16;
+    const long n_pb = (n_atoms + per - 1) / per;
+    hipError_t e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    const dim3 grid(std::max(1, n_cu)), block(64 * kWaves);
+    double* none = nullptr;
+    if (D == 1) hipLaunchKernelGGL((k_band_bp_helf<1, kWaves, true>), grid, block, 0, st, P, pitch, T, n_atoms, factor, none, 0L, next_unit, per, partial);
+    else if (D == 2) hipLaunchKernelGGL((k_band_bp_helf<2, kWaves, true>), grid, block, 0, st, P, pitch, T, n_atoms, factor, none, 0L, next_unit, per, partial);
+    else if (D == 3) hipLaunchKernelGGL((k_band_bp_helf<3, kWaves, true>), grid, block, 0, st, P, pitch, T, n_atoms, factor, none, 0L, next_unit, per, partial);
+    else return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 255) / 256), dim3(256), 0, st, partial, n_pb, n_groups, T, factor, lagsum);
     return hipGetLastError();
 }
 

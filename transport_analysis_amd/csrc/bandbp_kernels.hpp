@@ -178,19 +178,22 @@ __device__ __forceinline__ double band_first_lane(double x) {
                                               (unsigned)__builtin_amdgcn_readfirstlane((int)w.y)});
 }
 
-// P: pair-major float64 product slab of n_atoms * D columns.  bp_am[particle * ld_am + lag] = factor * H-sum / (T - lag),
-// lag 0 exactly 0; bp_am and *next_unit must be ZERO on entry.  grid: any number of workgroups of 64 NW threads.
-template <int D, int NW>
+// P: pair-major float64 product slab of n_atoms * D columns.  grid: any number of workgroups of 64 NW threads.
+// !LAGS: bp_am[particle * ld_am + lag] = factor * H-sum / (T - lag), lag 0 exactly 0; bp_am and *next_unit must be ZERO on entry.
+// LAGS (lag sums alone, results.visc_by_particle not asked for): a unit is a block lag group of `per_unit` consecutive
+// particles, whose sums stay in the same accumulators; it writes partial[(g * n_pb + block) * kBandPartial + q] = the sum for
+// lag 256 g - 15 + q over its particles (every element written; k_bandbp_gather adds them in a fixed order).
+template <int D, int NW, bool LAGS>
 __global__ void __launch_bounds__(64 * NW)
     k_band_bp_helf(const double* __restrict__ P, long pitch, int T, long n_atoms, double factor, double* __restrict__ bp_am,
-                   long ld_am, unsigned long long* __restrict__ next_unit) {
+                   long ld_am, unsigned long long* __restrict__ next_unit, int per_unit, double* __restrict__ partial) {
     static_assert(D >= 1 && D <= 3, "a particle's columns lie in at most two column pairs");
     constexpr int NR = D + 1;  // rings: the centred columns and the rows' squared norms
     static_assert(NR * kBpRingFrames >= 2 * 16 * 32 + 16, "the epilogue's scratch reuses the ring");
     __shared__ double ringB[NW][NR][kBpRingFrames];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nblk = (T + 15) / 16, n_groups = (nblk + 15) / 16;
-    const long n_units = n_atoms * n_groups;
+    const long n_pb = LAGS ? (n_atoms + per_unit - 1) / per_unit : n_atoms, n_units = n_pb * n_groups;
     double(*rB)[kBpRingFrames] = ringB[wave];
     for (;;) {
         unsigned long long taken = 0;
@@ -198,8 +201,15 @@ __global__ void __launch_bounds__(64 * NW)
         const long u = (long)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(taken >> 32)) << 32) |
                               (unsigned)__builtin_amdgcn_readfirstlane((int)taken));
         if (u >= n_units) break;
-        const long atom = __builtin_amdgcn_readfirstlane((int)(u / n_groups));
-        const int g = __builtin_amdgcn_readfirstlane((int)(u - atom * n_groups)), d0 = 16 * g;
+        const long pb = __builtin_amdgcn_readfirstlane((int)(u / n_groups));
+        const int g = __builtin_amdgcn_readfirstlane((int)(u - pb * n_groups)), d0 = 16 * g;
+        const int n_super = (nblk - d0 + 3) / 4, fB = 16 * d0;
+        band_d4 acc[16];
+        double nbacc[16], na = 0.0;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc[d] = band_d4{0.0, 0.0, 0.0, 0.0}, nbacc[d] = 0.0;
+        const long atom_lo = LAGS ? pb * per_unit : pb, atom_hi = LAGS ? (atom_lo + per_unit < n_atoms ? atom_lo + per_unit : n_atoms) : pb + 1;
+        for (long atom = atom_lo; atom < atom_hi; ++atom) {
         __amdgpu_buffer_rsrc_t rs[D];
 #pragma unroll
         for (int c = 0; c < D; ++c) {
@@ -210,11 +220,6 @@ __global__ void __launch_bounds__(64 * NW)
         auto load = [&](int c, int f0) -> double {  // frames f0 ... f0 + 63 of column c, one per lane; zeros behind the series
             return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs[c], (f0 + lane) * 16, 0, 0));
         };
-        const int n_super = (nblk - d0 + 3) / 4, fB = 16 * d0;
-        band_d4 acc[16];
-        double nbacc[16], na = 0.0;
-#pragma unroll
-        for (int d = 0; d < 16; ++d) acc[d] = band_d4{0.0, 0.0, 0.0, 0.0}, nbacc[d] = 0.0;
         double sa[D], sb[D], r[D];
         // raw rows of chunk `pos` (frames fbase ...) -> centred columns and their norms in the ring
         auto write_chunk = [&]<bool TAIL>(int pos, int fbase, const double(&raw)[D]) {
@@ -323,8 +328,9 @@ __global__ void __launch_bounds__(64 * NW)
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();  // (the next particle's rows overwrite the ring)
+        }
         // (a - b)^2 summed = NA[m] + NB_d[n] - 2 acc_d[m][n]; diagonals as above
-        __builtin_amdgcn_wave_barrier();
         double* blk = &rB[0][0];   // [16][32]
         double* dsum = blk + 512;  // [16][32]
         double* nas = dsum + 512;  // [16]
@@ -354,6 +360,23 @@ __global__ void __launch_bounds__(64 * NW)
             if (lane < 32) dsum[d * 32 + lane] = s;
             __builtin_amdgcn_wave_barrier();
         }
+        if constexpr (LAGS) {
+            double* out = partial + ((long)g * n_pb + pb) * kBandPartial;
+            for (int q = lane; q < kBandPartial; q += 64) {
+                // slot q is lag offset q - 15 = 16 d + e: (d, e >= 0) and (d + 1, e - 16)
+                const int off = q - 15;
+                const int d = off >= 0 ? off >> 4 : -1, e = off - 16 * d;  // e in [0, 15] (off < 0: 1..15)
+                double s = 0.0;
+                if (off <= 255) {
+                    if (d >= 0) s = dsum[d * 32 + e + 15];
+                    if (e >= 1 && d + 1 <= 15) s += dsum[(d + 1) * 32 + e - 16 + 15];
+                }
+                out[q] = s;
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        const long atom = pb;
         double* out = bp_am + atom * ld_am;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -376,6 +399,21 @@ __global__ void __launch_bounds__(64 * NW)
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// lagsum[k] = factor * (sum over the particle blocks of the halves that hold lag k) / (T - k), fixed order; lagsum[0] = 0
+static __global__ void __launch_bounds__(256)
+    k_bandbp_gather(const double* __restrict__ partial, long n_pb, int n_groups, int T, double factor, double* __restrict__ lagsum) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= T) return;
+    double s = 0.0;
+    for (int h = 0; h < 2; ++h) {  // group g holds lag offsets -15 ... 255 from 256 g
+        const int g = (k >> 8) + h, off = k - 256 * g;
+        if (g >= n_groups || off < -15) continue;
+        const double* p = partial + (long)g * n_pb * kBandPartial + off + 15;
+        for (long b = 0; b < n_pb; ++b) s += p[b * kBandPartial];
+    }
+    lagsum[k] = k == 0 ? 0.0 : factor * (s / (double)(T - k));
 }
 
 }  // namespace ta

@@ -74,6 +74,9 @@ hipError_t launch_band_bp_vacf(int n_cu, const double* pm, long pitch, int T, lo
                                unsigned long long* next_unit, hipStream_t st);
 hipError_t launch_band_bp_helf(int n_cu, const double* P, long pitch, int T, long n_atoms, int D, double factor, double* bp_am,
                                long ld_am, unsigned long long* next_unit, hipStream_t st);
+size_t band_bp_helf_partial_doubles(int n_cu, int T, long n_atoms);
+hipError_t launch_band_bp_helf_lags(int n_cu, const double* P, long pitch, int T, long n_atoms, int D, double factor, double* partial,
+                                    unsigned long long* next_unit, double* lagsum, hipStream_t st);
 hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,
                                hipStream_t st);
 // helfand_fft.hip: optional FFT evaluation of the Helfand lag sums
