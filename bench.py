@@ -318,14 +318,16 @@ class Case:
         if self.mode == "helfand" and self.helfand_fft:
             return False
         if self.bp is not None:  # by-particle arrays: the float32 Helfand form (dim = 3) and both float64 forms
-            return (self.mode == "helfand" and self.float32 and self.D == 3) or not self.float32
+            return self.mode == "helfand" or not self.float32
         return self.mode == "helfand" or (self.mode == "direct" and not self.float32)
 
     def kernel_name(self):
         if self.on_matrix_cores():
             if self.bp is not None:
-                return "k_band32_bp" if self.float32 else ("k_band_bp_vacf" if self.mode == "direct" else "k_band_bp_helf")
-            return "k_band32_lags" if self.float32 else "k_band_lags"
+                return "k_band32_tp" if self.float32 else ("k_band_bp_vacf" if self.mode == "direct" else "k_band_bp_helf")
+            if self.mode == "helfand":
+                return "k_band32_tp" if self.float32 else "k_band_bp_helf"
+            return "k_band_lags"
         if self.mode != "fft" and not (self.mode == "helfand" and self.helfand_fft):
             return "k_direct"
         if self.T > 163840:
@@ -403,13 +405,11 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
                "frac": tf / mpeak, "traffic": None, "kernel": case.kernel_name(), "kernel_ms": kernel_ms,
                "algorithmic_flops_per_launch": fl, "hbm_GBps_for_reference": gbps}
         if case.mode == "helfand":
-            # `achieved` / `frac` = what the matrix pipe ISSUES: 2 flop per term on 6 of its 8 column slots (the
-            # fourth lane group carries the norms).  The reference's own arithmetic (difference, square, add =
-            # 3 flop per term; what the vector kernel's line counts) is `reference_flops_*`:
-            # a larger number that says nothing about the pipe
-            # (by-particle form: 3 of 4 slots, and units of 16 block lags own 15: 16/15 of the MFMAs)
-            # (float64 by-particle form, k_band_bp_helf: k-slots from the time axis, all four used, no overlap of units)
-            slots = ((4.0 / 3.0) * (16.0 / 15.0) if float32 else 1.0) if case.bp is not None else 8.0 / 6.0
+            # `achieved` / `frac` = what the matrix pipe ISSUES: 2 flop per term (the time-packed kernels k_band_bp_helf /
+            # k_band32_tp use all four k-slots for products; the norms are vector adds).  The reference's own arithmetic
+            # (difference, square, add = 3 flop per term; what the vector kernel's line counts) is
+            # `reference_flops_*`: a larger number that says nothing about the pipe
+            slots = 1.0
             issued = 2.0 * slots * D * A * T * (T - 1) / 2 / (kernel_ms * 1e-3) / 1e12
             out.update({"achieved": issued, "frac": issued / mpeak,
                         "issued_flops_per_launch": 2.0 * slots * D * A * T * (T - 1) / 2,

@@ -225,7 +225,11 @@ def test_lag_sums_only_on_the_reference_kats(backend, step_vtraj, tdim, tdim_fac
 def test_helfand_float32_switch(backend, step_vtraj):
     """float32=True selects the library's float32 squared-difference path (configs[4])."""
     vh = VH(step_vtraj.atoms, dim_type="xy", float32=True).run(start=10, stop=1000, step=10)
-    assert_allclose(vh.results.timeseries, g("kat_helfand_poly_10_1000_10_D2.npy"), rtol=5e-6)
+    want = g("kat_helfand_poly_10_1000_10_D2.npy")
+    # the float32 path's bar: 2e-6 of the series' scale (P is rounded once to float32: on this pure trend that rounding,
+    # 6e-8 |P|, is what the shortest lags see; lag by lag they agree to a few 1e-6)
+    assert np.max(np.abs(vh.results.timeseries - want)) < 2e-6 * np.max(np.abs(want))
+    assert_allclose(vh.results.timeseries, want, rtol=5e-5)
     assert vh.results.timeseries[0] == 0.0
     if backend == "oracle-backed":
         assert vh._ctx.options["direct_f32"] == 1

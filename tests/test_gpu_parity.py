@@ -326,11 +326,13 @@ def test_helfand_matrix_cores_on_a_pure_trend(ctx, form):
 
 @pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 2, 3), (15, 3, 1), (16, 5, 3), (17, 2, 2), (241, 3, 3), (256, 3, 3),
                                    (257, 9, 1), (272, 4, 3), (273, 5, 2), (513, 11, 3), (1000, 37, 3), (2049, 8, 3),
-                                   (4100, 3, 3), (5000, 7, 3), (300, 2001, 1)])
-def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D):
-    """BASELINE configs[4]'s float32 path without the by-particle array: k_band32_lags (v_mfma_f32_16x16x4_f32,
-    band32_kernels.hpp) on the float32 product slab — rows fetched by LDS-DMA, float32 accumulators flushed
-    into float64 — against the oracle (viscosity.py:201-233) at the float32 path's bar, 2e-6 of the series'
+                                   (4100, 3, 3), (5000, 7, 3), (300, 2001, 1), (300, 2001, 3)])
+@pytest.mark.parametrize("form", [1, 2])
+def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
+    """BASELINE configs[4]'s float32 path without the by-particle array, both FP32 matrix-core forms: "direct_mfma" 1
+    (the default) k_band32_tp (band32tp_kernels.hpp: k-slots from the time axis, a unit's particles summed in its
+    accumulators), 2 the column-packed k_band32_lags (band32_kernels.hpp: rows fetched by LDS-DMA); float32
+    accumulators flushed into float64 — against the oracle (viscosity.py:201-233) at the float32 path's bar, 2e-6 of the series'
     scale, on the shapes of the float64 form's test: both sides of the 16-frame blocks and the 256-lag
     groups, ragged column counts (sextets with one and two pairs, an unpaired last column), P far from
     zero-mean.  Same bits every launch; and the float32 vector kernel ("direct_mfma" 0) agrees."""
@@ -342,9 +344,10 @@ def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D):
     want_ts = orc.helfand(v, x, m, vol, 300.0)[1]
     ctx.set_option("direct_f32", 1)
     ctx.set_option("timeline", 1)
+    ctx.set_option("direct_mfma", form)
     try:
         ts_m, _ = run_helfand(ctx, v, x, m, scale, False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_lags"]
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp" if form == 1 else "k_band32_lags"]
         ts_again, _ = ctx.helfand_msd(m, scale, by_particle=False)
         assert np.array_equal(ts_m, ts_again)  # fixed summation order
         ctx.set_option("direct_mfma", 0)
@@ -361,13 +364,15 @@ def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D):
         assert scale_rel_err(ts_m, want_ts) > 0.0  # really float32 arithmetic
 
 
-@pytest.mark.parametrize("T,A", [(1, 2), (2, 3), (16, 5), (17, 3), (239, 2), (240, 3), (241, 2), (257, 7), (481, 5), (1000, 9),
-                                 (2049, 3), (300, 300)])
-def test_helfand_float32_by_particle_on_the_matrix_cores(ctx, T, A):
-    """The float32 option WITH results.visc_by_particle (the class default output), dim = 3: k_band32_bp — a particle's
-    x, y, z in three of the MFMA's four k-slots, units of 16 block lags that own 240 lags each — against the
-    oracle at 2e-6 of the scale, frame counts on both sides of the 16-frame blocks and of the 240-lag units; the
-    timeseries is the mean of the by-particle array; dim < 3 stays on the vector kernel."""
+@pytest.mark.parametrize("T,A", [(1, 2), (2, 3), (16, 5), (17, 3), (63, 3), (65, 2), (239, 2), (240, 3), (241, 2), (257, 7), (449, 3),
+                                 (481, 5), (513, 2), (1000, 9), (2049, 3), (4100, 2), (300, 300)])
+@pytest.mark.parametrize("form", [1, 2])
+def test_helfand_float32_by_particle_on_the_matrix_cores(ctx, T, A, form):
+    """The float32 option WITH results.visc_by_particle (the class default output): "direct_mfma" 1 (the default)
+    k_band32_tp (k-slots from the time axis; any dim), 2 k_band32_bp (dim = 3: a particle's x, y, z in three of the
+    MFMA's four k-slots, units that own 240 lags; dim < 3 on the vector kernel) — against the oracle at 2e-6 of the
+    scale, frame counts on both sides of the 16-frame blocks, the 64-frame chunks and the 240- / 256-lag units; the
+    timeseries is the mean of the by-particle array."""
     from oracle import numpy_oracle as orc
 
     v, x, m, vol = orc.synthetic_helfand(T, A, 3, seed=2900 + T)
@@ -376,16 +381,21 @@ def test_helfand_float32_by_particle_on_the_matrix_cores(ctx, T, A):
     want_bp, want_ts = orc.helfand(v, x, m, vol, 300.0)
     ctx.set_option("direct_f32", 1)
     ctx.set_option("timeline", 1)
+    ctx.set_option("direct_mfma", form)
     try:
         ts, bp = run_helfand(ctx, v, x, m, scale, True)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_bp", "k_bp_transpose", "k_sum_partials"]
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp" if form == 1 else "k_band32_bp",
+                                                         "k_bp_transpose", "k_sum_partials"]
         ts2, bp2 = ctx.helfand_msd(m, scale, by_particle=True)
         assert np.array_equal(bp, bp2) and np.array_equal(ts, ts2)
         _, bp_d2 = run_helfand(ctx, v[:, :, :2], x[:, :, :2], m, scale, True)
-        assert "k_direct" in [n for n, _ in ctx.kernel_timeline()]
+        assert ("k_band32_tp" if form == 1 else "k_direct") in [n for n, _ in ctx.kernel_timeline()]
+        _, bp_d1 = run_helfand(ctx, v[:, :, 1:2], x[:, :, 1:2], m, scale, True)
     finally:
+        ctx.set_option("direct_mfma", 1)
         ctx.set_option("direct_f32", 0)
         ctx.set_option("timeline", 0)
+    assert scale_rel_err(bp_d1, orc.helfand(v[:, :, 1:2], x[:, :, 1:2], m, vol, 300.0)[0]) < TOL_F32
     assert np.all(bp[0] == 0.0) and ts[0] == 0.0
     assert scale_rel_err(bp, want_bp) < TOL_F32
     assert scale_rel_err(ts, want_ts) < TOL_F32
@@ -432,7 +442,7 @@ def test_helfand_float32_matrix_cores_trend_units_and_float32_slabs(ctx):
             ctx.stage_commit(0, T2)
             ctx.set_option("timeline", 1)
             got, _ = ctx.helfand_msd(m2, 1.0, by_particle=False)
-            assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_lags"]
+            assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp"]
         finally:
             ctx.set_option("timeline", 0)
             ctx.set_option("stage_device_f32", 0)
@@ -1474,8 +1484,12 @@ def test_kernel_timeline_sums_to_the_call(ctx):
         ts2, _ = ctx.vacf_direct(by_particle=False)
         assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_lags"]  # lag sums alone: matrix cores
         ctx.vacf_direct(by_particle=True)
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_bp_vacf", "k_bp_transpose", "k_sum_partials"]
+        ctx.set_option("direct_mfma", 0)
+        ctx.vacf_direct(by_particle=True)
         assert [n for n, _ in ctx.kernel_timeline()] == ["memset", "k_direct", "k_sum_partials", "k_bp_transpose"]
     finally:
+        ctx.set_option("direct_mfma", 1)
         ctx.set_option("timeline", 0)
     want_bp, want_ts = orc.vacf_fft_batched(v)
     assert scale_rel_err(ts, want_ts) < TOL and scale_rel_err(bp, want_bp) < TOL

@@ -195,34 +195,48 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
     // and run on the FP64 matrix cores (band_kernels.hpp).  The by-particle arrays and the float32
     // option stay on the vector kernels below.
     const bool band_ok = !d_bp && !f32 && !src_f32 && ctx->opt_direct_mfma && T < ((int64_t)1 << 24);
-    // ... and the float32 option's Helfand lag sums on the FP32 matrix cores (band32_kernels.hpp): P rounded once
-    // to float32 like the float32 vector kernel's staged values, float32 products, float64 accumulation
+    // ... and the float32 option's Helfand forms on the FP32 matrix cores: P rounded once to float32 like the float32 vector
+    // kernel's staged values, float32 products, float64 accumulation.  Default: the time-packed kernel
+    // (band32tp_kernels.hpp: all four k-slots do arithmetic; 259 ms per configs[4] share with or without the by-particle
+    // array); "direct_mfma" 2: the column-packed forms of band32_kernels.hpp (340 ms lag sums, 393 ms by particle at dim = 3).
+    const bool tp32 = ctx->opt_direct_mfma != 2;
     if (!d_bp && f32 && mode == MODE_HELFAND && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
         const int64_t n_cols = A * D;
-        if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK) {
+        if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK &&
+            (!tp32 || (ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
+                       ensure(ctx, ctx->unit_counter, 8) == TA_OK))) {
             tl_mark(ctx, "k_helfand_product32", st);
             TA_HIP_TRY(ctx, launch_helfand_product32(d_vel, d_pos, src_f32, d_masses, pitch, T, n_cols, D, (float*)ctx->helf_p.p, st));
-            tl_mark(ctx, "k_band32_lags", st);
+            tl_mark(ctx, tp32 ? "k_band32_tp" : "k_band32_lags", st);
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-            TA_HIP_TRY(ctx, launch_band32_lags(&ctx->band, ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, n_cols,
-                                               scale / (double)D, d_lagsum, st));
+            if (tp32)
+                TA_HIP_TRY(ctx, launch_band32_tp_lags(ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, A, D, scale / (double)D,
+                                                      (double*)ctx->bp_scratch.p, (unsigned long long*)ctx->unit_counter.p, d_lagsum, st));
+            else
+                TA_HIP_TRY(ctx, launch_band32_lags(&ctx->band, ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, n_cols,
+                                                   scale / (double)D, d_lagsum, st));
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
             return TA_OK;
         }
         (void)hipGetLastError();  // out of memory for the product slab: the vector kernel needs none
     }
-    // ... and with the by-particle array (dim = 3: a particle's x, y, z in three of the MFMA's four k-slots)
-    if (d_bp && f32 && mode == MODE_HELFAND && D == 3 && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
+    // ... and with the by-particle array (the column-packed form: dim = 3 only, a particle's x, y, z in three of the four k-slots)
+    if (d_bp && f32 && mode == MODE_HELFAND && (tp32 || D == 3) && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
         const int64_t n_cols = A * D, Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK &&
             ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
-            ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T) == TA_OK) {
+            ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T) == TA_OK &&
+            ensure(ctx, ctx->unit_counter, 8) == TA_OK) {
             tl_mark(ctx, "k_helfand_product32", st);
             TA_HIP_TRY(ctx, launch_helfand_product32(d_vel, d_pos, src_f32, d_masses, pitch, T, n_cols, D, (float*)ctx->helf_p.p, st));
-            tl_mark(ctx, "k_band32_bp", st);
+            tl_mark(ctx, tp32 ? "k_band32_tp" : "k_band32_bp", st);
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-            TA_HIP_TRY(ctx, launch_band32_bp(ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, A, scale / (double)D,
-                                             (double*)ctx->bp_scratch.p, Tp, st));
+            if (tp32)
+                TA_HIP_TRY(ctx, launch_band32_tp_bp(ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, A, D, scale / (double)D,
+                                                    (double*)ctx->bp_scratch.p, Tp, (unsigned long long*)ctx->unit_counter.p, st));
+            else
+                TA_HIP_TRY(ctx, launch_band32_bp(ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, A, scale / (double)D,
+                                                 (double*)ctx->bp_scratch.p, Tp, st));
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
             tl_mark(ctx, "k_bp_transpose", st);
             TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp, (double*)ctx->ts_partial.p, st));

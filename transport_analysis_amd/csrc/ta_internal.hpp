@@ -74,7 +74,13 @@ hipError_t launch_band_bp_vacf(int n_cu, const double* pm, long pitch, int T, lo
                                unsigned long long* next_unit, hipStream_t st);
 hipError_t launch_band_bp_helf(int n_cu, const double* P, long pitch, int T, long n_atoms, int D, double factor, double* bp_am,
                                long ld_am, unsigned long long* next_unit, hipStream_t st);
+int band_bp_helf_block(int n_cu, int T, long n_atoms);
 size_t band_bp_helf_partial_doubles(int n_cu, int T, long n_atoms);
+// band32tp.hip: the float32 option's Helfand forms, k-slots from the time axis
+hipError_t launch_band32_tp_bp(int n_cu, const float* P32, long pitch, int T, long n_atoms, int D, double factor, double* bp_am, long ld_am,
+                               unsigned long long* next_unit, hipStream_t st);
+hipError_t launch_band32_tp_lags(int n_cu, const float* P32, long pitch, int T, long n_atoms, int D, double factor, double* partial,
+                                 unsigned long long* next_unit, double* lagsum, hipStream_t st);
 hipError_t launch_band_bp_helf_lags(int n_cu, const double* P, long pitch, int T, long n_atoms, int D, double factor, double* partial,
                                     unsigned long long* next_unit, double* lagsum, hipStream_t st);
 hipError_t launch_sum_partials(const double* partial, int n_parts, long n, double* out,
