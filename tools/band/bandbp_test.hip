@@ -213,6 +213,23 @@ static int tcheck_one(int T, long A, int D, int nwg, int kind, int per) {  // pe
             if (!(e <= worst)) worst = e, wk = k;
         }
     }
+    if (getenv("TP_DEBUG") && !per) {
+        const long a = wa < 0 ? 0 : wa;
+        std::vector<double> ref(T, 0.0);
+        for (int k = 1; k < T; ++k) {
+            double acc = 0;
+            for (int d = 0; d < D; ++d) {
+                const long c = D * a + d;
+                const float* col = h.data() + (c >> 1) * pitch * 2 + (c & 1);
+                for (int i = 0; i + k < T; ++i) { const double df = (double)col[2 * i] - (double)col[2 * (i + k)]; acc += df * df; }
+            }
+            ref[k] = acc / (T - k);
+        }
+        for (int k = 0; k < T; ++k) {
+            const double e = (got[a * pitch + k] - ref[k]) * (T - k);
+            if (std::fabs(e) > 1e-3 * std::fabs(ref[k] * (T - k))) printf("   lag %4d (off %3d): got-ref (unnormalised) %.6g  ref %.6g\n", k, k & 255, e, ref[k] * (T - k));
+        }
+    }
     const bool ok = worst < 2e-6;
     printf("float32 %s kind %d T=%6d A=%5ld D=%d nwg=%3d : worst %.2e of the scale (particle %ld lag %d) %s\n", per ? "lag sums   " : "by particle", kind, T, A, D,
            nwg, worst, wa, wk, ok ? "ok" : "FAIL");
@@ -287,6 +304,7 @@ int main(int argc, char** argv) {
         printf(bad ? "FAILED %d\n" : "all ok\n", bad);
         return bad ? 1 : 0;
     }
+    if (!strcmp(mode, "tdebug")) return tcheck_one(argc > 2 ? atoi(argv[2]) : 1000, argc > 3 ? atol(argv[3]) : 1, argc > 4 ? atoi(argv[4]) : 1, 7, 0, 0);
     if (!strcmp(mode, "tcheck")) {
         int bad = 0;
         const int shapes[][2] = {{1, 2}, {2, 3}, {15, 4}, {16, 5}, {17, 3}, {63, 2}, {64, 3}, {65, 2}, {239, 2}, {240, 3}, {241, 2}, {255, 3},

@@ -25,6 +25,15 @@ namespace ta {
 #ifndef TA_BAND32TP_FLUSH
 #define TA_BAND32TP_FLUSH 64
 #endif
+#ifndef TA_BAND32TP_ABL  // timing ablations (wrong results), bit mask: 1 no norm-column adds, 2 no re-centring, 4 no flush in the loop,
+#define TA_BAND32TP_ABL 0  // 8 no MFMAs, 16 no window reads (operands = the A registers)
+#endif
+#ifndef TA_BAND32TP_ORDER  // 0: batches of 16 windows per column, read ahead of their MFMAs; 2: block lag by block lag
+#define TA_BAND32TP_ORDER 2
+#endif
+#ifndef TA_BAND32TP_SB
+#define TA_BAND32TP_SB __builtin_amdgcn_sched_barrier(0)
+#endif
 constexpr int kBand32tpFlush = TA_BAND32TP_FLUSH;  // super-steps between flushes (a multiple of 8)
 
 __device__ __forceinline__ float band32_first_lane(float x) {
@@ -72,7 +81,7 @@ __global__ void __launch_bounds__(64 * NW)
         auto flush = [&]() __attribute__((always_inline)) {
             const float tot = band32_sum_rows(na);  // every lane: NA[lane & 15]
             if (lane < 16) nas[lane] = tot;
-            __builtin_amdgcn_wave_barrier();
+            TA_LDS_ORDER();
             const band_f4 na_m = *reinterpret_cast<const band_f4*>(nas + 4 * (lane >> 4));  // rows m = 4 (lane >> 4) + r
             float nbd[16];
 #pragma unroll
@@ -123,14 +132,20 @@ __global__ void __launch_bounds__(64 * NW)
             }
 #pragma unroll
             for (int c = 0; c < D; ++c) sb[0][c] = load(c, fB + 64 * 5), sb[1][c] = load(c, fB + 64 * 6);
+            TA_LDS_ORDER();
             int S = 0;
             // one super-step; a == S % 8 (a constant once unrolled)
             auto body = [&]<bool TAIL, int a>() __attribute__((always_inline)) {
-                if (a == 0 && ++since == kBand32tpFlush / kBpChunks) {
+                if (a == 0 && !(TA_BAND32TP_ABL & 4) && ++since == kBand32tpFlush / kBpChunks) {
                     flush();
                     since = 0;
                 }
-                if (a % 4 == 0 && S != 0) {  // a new pass: a new reference row, which the ring's live chunks follow
+                // The ring is written chunk by chunk and read window by window: a lane reads what OTHER lanes wrote.  The compiler
+                // sees each thread's own addresses only (a write at 64 q + lane and a read at 16 x + lane never alias for it) and
+                // would move reads across the writes: wave_barrier() pins its order on both sides of the writes (no instruction:
+                // LDS operations of one wave complete in order).
+                TA_LDS_ORDER();
+                if (a % 4 == 0 && S != 0 && !(TA_BAND32TP_ABL & 2)) {  // a new pass: a new reference row, which the ring's live chunks follow
                     float delta[D];
 #pragma unroll
                     for (int c = 0; c < D; ++c) {
@@ -154,6 +169,17 @@ __global__ void __launch_bounds__(64 * NW)
                         rB[D][64 * q + lane] = nb;
                     }
                 }
+                write_chunk.template operator()<TAIL>((a + 5) % kBpChunks, fB + 64 * (S + 5), sb[a & 1]);  // chunk S + 5
+                TA_LDS_ORDER();
+                // the 16 windows of ring row `row` for this super-step: a batch of LDS reads that is in flight while the MFMAs of
+                // the batch before it run (left to itself the compiler reads two windows, waits, issues two MFMAs, ...: an LDS
+                // round trip per 64 matrix cycles)
+                float Bf[2][16];
+                auto read_batch = [&](int buf, int row) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) Bf[buf][d] = rB[row][(64 * a + 16 * d) % (64 * kBpChunks) + lane];
+                };
+                if constexpr (!TAIL && !(TA_BAND32TP_ABL & 16) && TA_BAND32TP_ORDER == 0) read_batch(0, 0);
                 float A[D], asq = 0.0f;
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
@@ -161,7 +187,6 @@ __global__ void __launch_bounds__(64 * NW)
                     if (TAIL && !(64 * S + lane < T)) A[c] = 0.0f;
                     asq = __builtin_fmaf(A[c], A[c], asq);
                 }
-                write_chunk.template operator()<TAIL>((a + 5) % kBpChunks, fB + 64 * (S + 5), sb[a & 1]);  // chunk S + 5
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
                     sb[a & 1][c] = load(c, fB + 64 * (S + 7));
@@ -170,13 +195,29 @@ __global__ void __launch_bounds__(64 * NW)
                 __builtin_amdgcn_sched_barrier(0);  // the requests stay here, two super-steps ahead of their use
                 if constexpr (!TAIL) {
                     na += asq;
+#if TA_BAND32TP_ORDER == 0
 #pragma unroll
-                    for (int c = 0; c < D; ++c)
+                    for (int c = 0; c < D; ++c) {
+                        if (!(TA_BAND32TP_ABL & 16)) read_batch((c + 1) & 1, c + 1);  // the next column's windows (after the last column: the norms')
+                        TA_BAND32TP_SB;
+                        if (!(TA_BAND32TP_ABL & 8)) {
 #pragma unroll
-                        for (int d = 0; d < 16; ++d)
-                            acc[d] = TA_BAND32_MFMA(A[c], rB[c][(64 * a + 16 * d) % (64 * kBpChunks) + lane], acc[d]);
+                            for (int d = 0; d < 16; ++d) acc[d] = TA_BAND32_MFMA(A[c], (TA_BAND32TP_ABL & 16) ? A[(c + d) % D] : Bf[c & 1][d], acc[d]);
+                        }
+                        TA_BAND32TP_SB;
+                    }
 #pragma unroll
-                    for (int d = 0; d < 16; ++d) nbacc[d] += rB[D][(64 * a + 16 * d) % (64 * kBpChunks) + lane];
+                    for (int d = 0; d < 16; ++d)
+                        if (!(TA_BAND32TP_ABL & 17)) nbacc[d] += Bf[D & 1][d];
+#else  // block lag by block lag: a window of every column and of the norms, their MFMAs, the norm add
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) {
+                        const int w = (64 * a + 16 * d) % (64 * kBpChunks) + lane;
+#pragma unroll
+                        for (int c = 0; c < D; ++c) acc[d] = TA_BAND32_MFMA(A[c], rB[c][w], acc[d]);
+                        nbacc[d] += rB[D][w];
+                    }
+#endif
                 } else {
                     const float Ah = -0.5f * asq;
 #pragma unroll
@@ -203,7 +244,7 @@ __global__ void __launch_bounds__(64 * NW)
             if (S < n_super)
                 while (pass_tail(std::make_integer_sequence<int, kBpChunks>{})) {
                 }
-            __builtin_amdgcn_wave_barrier();  // (the next particle's rows overwrite the ring)
+            TA_LDS_ORDER();  // (the next particle's rows overwrite the ring)
         }
         flush();
         // sums.s[k]: lag slot q = lane + 64 k, lag 256 g - 15 + q: diagonal e >= 0 of block lag d plus e - 16 of d + 1

@@ -27,6 +27,19 @@
 
 namespace ta {
 
+// Lanes of a wave exchange data through the LDS here (ring: written chunk by chunk, read window by window; epilogues).  The
+// hardware completes one wave's LDS operations in order; the COMPILER orders only what may alias within a thread (a write at
+// 64 q + lane and a read at 16 x + lane never do) — fences for its IR passes, wave_barrier for its schedulers; no instruction.
+#define TA_LDS_ORDER()                                              \
+    do {                                                            \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
+        __builtin_amdgcn_wave_barrier();                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
+    } while (0)
+
+#ifndef TA_BANDBP_ORDER
+#define TA_BANDBP_ORDER 2
+#endif
 constexpr int kBpChunks = 8;                        // ring: chunks of 64 frames (super-step S reads chunks S ... S + 4)
 constexpr int kBpRingFrames = 64 * (kBpChunks + 1);  // + the copy of ring position 0 behind position 7
 
@@ -83,16 +96,23 @@ __global__ void __launch_bounds__(64 * NW)
             sb[c] = load(c, fB + 64 * 5);
             sa[c] = load(c, 0);  // the A operand IS the load: lane = frame
         }
+        TA_LDS_ORDER();
         int S = 0;
         for (bool more = true; more;) {
 #pragma unroll
             for (int a = 0; a < kBpChunks; ++a) {  // S % 8 == a: ring positions are immediates
                 const int pos = (a + 5) % kBpChunks;
+                // The ring is written chunk by chunk and read window by window: a lane reads what OTHER lanes wrote.  The compiler
+                // sees each thread's own addresses only (a write at 64 q + lane and a read at 16 x + lane never alias for it) and
+                // may move reads across the writes: wave_barrier() pins its order on both sides of the writes (no instruction:
+                // LDS operations of one wave complete in order).
+                TA_LDS_ORDER();
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
                     rB[c][64 * pos + lane] = sb[c];  // chunk S + 5 (first read by super-step S + 1)
                     if (pos == 0) rB[c][64 * kBpChunks + lane] = sb[c];
                 }
+                TA_LDS_ORDER();
                 double A[D];
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
@@ -101,11 +121,19 @@ __global__ void __launch_bounds__(64 * NW)
                     sa[c] = load(c, 64 * (S + 1));
                 }
                 __builtin_amdgcn_sched_barrier(0);  // the requests stay here, a super-step ahead of their use
+#if TA_BANDBP_ORDER == 2  // block lag by block lag
+#pragma unroll
+                for (int d = 0; d < 16; ++d)
+#pragma unroll
+                    for (int c = 0; c < D; ++c)
+                        acc[d] = TA_BAND_MFMA(A[c], rB[c][(64 * a + 16 * d) % (64 * kBpChunks) + lane], acc[d]);
+#else
 #pragma unroll
                 for (int c = 0; c < D; ++c)
 #pragma unroll
                     for (int d = 0; d < 16; ++d)
                         acc[d] = TA_BAND_MFMA(A[c], rB[c][(64 * a + 16 * d) % (64 * kBpChunks) + lane], acc[d]);
+#endif
                 if (++S == n_super) {
                     more = false;
                     break;
@@ -115,24 +143,24 @@ __global__ void __launch_bounds__(64 * NW)
         // diagonals: acc[d] register r of lane l is C_d[m = 4 r + (l >> 4)][n = l & 15], lag 16 (d0 + d) + n - m.
         // A block goes to the LDS skewed — row m, column n - m + 15 — so that a diagonal is a column: its sum is 16
         // reads without a bound (the cells no row writes stay zero), eight per half wave.
-        __builtin_amdgcn_wave_barrier();
+        TA_LDS_ORDER();
         double* blk = &rB[0][0];   // [16][32]
         double* dsum = blk + 512;  // [16][32]: the 31 diagonal sums of every block lag
 #pragma unroll
         for (int q = 0; q < 8; ++q) blk[64 * q + lane] = 0.0;
-        __builtin_amdgcn_wave_barrier();
+        TA_LDS_ORDER();
         const int skew = (lane & 15) - (lane >> 4) + 15, half = lane >> 5, col = lane & 31;
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) blk[(4 * r + (lane >> 4)) * 32 + skew - 4 * r] = acc[d][r];
-            __builtin_amdgcn_wave_barrier();
+            TA_LDS_ORDER();
             double s = 0.0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += blk[(8 * half + j) * 32 + col];
             s = band_sum_halves(s);
             if (lane < 32) dsum[d * 32 + lane] = s;
-            __builtin_amdgcn_wave_barrier();
+            TA_LDS_ORDER();
         }
         double* out = bp_am + atom * ld_am;
 #pragma unroll
@@ -154,7 +182,7 @@ __global__ void __launch_bounds__(64 * NW)
             const long lag = 256L * g - 16 + lane;
             if (lag < T) unsafeAtomicAdd(out + lag, dsum[lane - 16 + 15] / (double)(T - lag));
         }
-        __builtin_amdgcn_wave_barrier();
+        TA_LDS_ORDER();
     }
 }
 
@@ -246,9 +274,11 @@ __global__ void __launch_bounds__(64 * NW)
         }
 #pragma unroll
         for (int c = 0; c < D; ++c) sb[c] = load(c, fB + 64 * 5);
+        TA_LDS_ORDER();
         int S = 0;
         // one super-step; a == S % 8 (a constant once unrolled)
         auto body = [&]<bool TAIL>(int a) {
+            TA_LDS_ORDER();  // (ring writes below, window reads above and further down: see k_band_bp_vacf)
             if (a % 4 == 0 && S != 0) {  // a new pass: a new reference row, which the ring's contents follow
                 double delta[D];
 #pragma unroll
@@ -279,6 +309,7 @@ __global__ void __launch_bounds__(64 * NW)
                 asq = __builtin_fma(A[c], A[c], asq);
             }
             write_chunk.template operator()<TAIL>((a + 5) % kBpChunks, fB + 64 * (S + 5), sb);  // chunk S + 5 (first read by super-step S + 1)
+            TA_LDS_ORDER();
 #pragma unroll
             for (int c = 0; c < D; ++c) {
                 sb[c] = load(c, fB + 64 * (S + 6));
@@ -287,6 +318,7 @@ __global__ void __launch_bounds__(64 * NW)
             __builtin_amdgcn_sched_barrier(0);  // the requests stay here, a super-step ahead of their use
             if constexpr (!TAIL) {
                 na += asq;
+#if TA_BANDBP_ORDER == 0
 #pragma unroll
                 for (int c = 0; c < D; ++c)
 #pragma unroll
@@ -294,6 +326,29 @@ __global__ void __launch_bounds__(64 * NW)
                         acc[d] = TA_BAND_MFMA(A[c], rB[c][(64 * a + 16 * d) % (64 * kBpChunks) + lane], acc[d]);
 #pragma unroll
                 for (int d = 0; d < 16; ++d) nbacc[d] += rB[D][(64 * a + 16 * d) % (64 * kBpChunks) + lane];
+#elif TA_BANDBP_ORDER == 1  // the norm column's windows first: their adds then stand among the MFMAs, not behind the last one
+                double nbw[16];
+#pragma unroll
+                for (int d = 0; d < 16; ++d) nbw[d] = rB[D][(64 * a + 16 * d) % (64 * kBpChunks) + lane];
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+#pragma unroll
+                    for (int d = 0; d < 16; ++d)
+                        acc[d] = TA_BAND_MFMA(A[c], rB[c][(64 * a + 16 * d) % (64 * kBpChunks) + lane], acc[d]);
+                    if (c == 0) {
+#pragma unroll
+                        for (int d = 0; d < 16; ++d) nbacc[d] += nbw[d];
+                    }
+                }
+#else  // block lag by block lag
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const int w = (64 * a + 16 * d) % (64 * kBpChunks) + lane;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) acc[d] = TA_BAND_MFMA(A[c], rB[c][w], acc[d]);
+                    nbacc[d] += rB[D][w];
+                }
+#endif
             } else {
                 const double Ah = -0.5 * asq;
 #pragma unroll
@@ -328,7 +383,7 @@ __global__ void __launch_bounds__(64 * NW)
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();  // (the next particle's rows overwrite the ring)
+        TA_LDS_ORDER();  // (the next particle's rows overwrite the ring)
         }
         // (a - b)^2 summed = NA[m] + NB_d[n] - 2 acc_d[m][n]; diagonals as above
         double* blk = &rB[0][0];   // [16][32]
@@ -338,13 +393,13 @@ __global__ void __launch_bounds__(64 * NW)
         {
             const double tot = band_sum_rows(na);  // every lane: NA[lane & 15]
             if (lane < 16) nas[lane] = tot;
-            __builtin_amdgcn_wave_barrier();
+            TA_LDS_ORDER();
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) na_m[r4] = nas[4 * r4 + (lane >> 4)];
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) blk[64 * q + lane] = 0.0;
-        __builtin_amdgcn_wave_barrier();
+        TA_LDS_ORDER();
         const int skew = (lane & 15) - (lane >> 4) + 15, half = lane >> 5, col = lane & 31;
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
@@ -352,13 +407,13 @@ __global__ void __launch_bounds__(64 * NW)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4)
                 blk[(4 * r4 + (lane >> 4)) * 32 + skew - 4 * r4] = __builtin_fma(-2.0, acc[d][r4], na_m[r4] + nbd);
-            __builtin_amdgcn_wave_barrier();
+            TA_LDS_ORDER();
             double s = 0.0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += blk[(8 * half + j) * 32 + col];
             s = band_sum_halves(s);
             if (lane < 32) dsum[d * 32 + lane] = s;
-            __builtin_amdgcn_wave_barrier();
+            TA_LDS_ORDER();
         }
         if constexpr (LAGS) {
             double* out = partial + ((long)g * n_pb + pb) * kBandPartial;
@@ -373,7 +428,7 @@ __global__ void __launch_bounds__(64 * NW)
                 }
                 out[q] = s;
             }
-            __builtin_amdgcn_wave_barrier();
+            TA_LDS_ORDER();
             continue;
         }
         const long atom = pb;
@@ -397,7 +452,7 @@ __global__ void __launch_bounds__(64 * NW)
             const long lag = 256L * g - 16 + lane;
             if (lag < T) unsafeAtomicAdd(out + lag, factor * dsum[lane - 16 + 15] / (double)(T - lag));
         }
-        __builtin_amdgcn_wave_barrier();
+        TA_LDS_ORDER();
     }
 }
 
