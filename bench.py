@@ -895,8 +895,9 @@ def other_configs(torch, dist, _lib, ctx, dev):
         ("configs[2] shape with vacf_by_particle: FFT VACF 10000 x 100000 x 3", "fft", 10000, 100000, True, False, False, 3, 1),
         ("configs[3]: windowed (direct) VACF 5000 x 50000 x 3", "direct", 5000, 50000, False, False, False, 3, 1),
         ("configs[3] shape with vacf_by_particle (the class default output; FP64 matrix cores, k-slots from the time axis): windowed VACF 5000 x 50000 x 3", "direct", 5000, 50000, True, False, False, 2, 1),
-        ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float64 (matrix cores)", "helfand", 20000, 25000, False, False, False, 2, 1),
-        ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float32 path (FP32 matrix cores)", "helfand", 20000, 25000, False, True, False, 2, 1),
+        ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float64 (FP64 matrix cores, k-slots from the time axis)", "helfand", 20000, 25000, False, False, False, 2, 1),
+        ("configs[4] per-GPU share, float64 with visc_by_particle (the class default output; FP64 matrix cores): 20000 x 25000 x 3", "helfand", 20000, 25000, True, False, False, 2, 1),
+        ("configs[4] per-GPU share: Helfand MSD 20000 x 25000 x 3, float32 path (FP32 matrix cores, k-slots from the time axis)", "helfand", 20000, 25000, False, True, False, 2, 1),
         ("configs[4] per-GPU share, float32 path with visc_by_particle (the class default output; FP32 matrix cores): 20000 x 25000 x 3", "helfand", 20000, 25000, True, True, False, 2, 1),
         ("configs[4] per-GPU share, helfand_fft option (float64): 20000 x 25000 x 3", "helfand", 20000, 25000, False, False, True, 3, 1),
         ("long trajectory: FFT VACF timeseries 20000 x 25000 x 3", "fft", 20000, 25000, False, False, False, 5, 1),

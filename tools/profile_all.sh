@@ -3,8 +3,8 @@
 #   1. headline (configs[2] tensor, lag sums): --kernel-trace --stats over >= 10 timed calls after
 #      >= 3 warm-ups, next to the hipEvent medians of the SAME run; FETCH/WRITE/TCC passes
 #   2. HBM-traffic passes (FETCH_SIZE, WRITE_SIZE in separate runs) of the other workloads:
-#      by-particle, direct configs[3] (matrix-core lag sums; vector kernel with the by-particle array), Helfand
-#      float64 (FP64 matrix cores) and float32 (FP32 matrix cores) share, helfand_fft, 20000-frame path
+#      by-particle, direct configs[3] (matrix cores, with and without the by-particle array), Helfand float64 and float32
+#      shares (time-packed matrix-core kernels, with and without the by-particle array), helfand_fft, 20000-frame path
 # Everything lands in gpurun_out/prof_<tag>*/; hbm_traffic.json accumulates the entries, keyed by
 # the library's hash.  usage: profile_all.sh TAG [quick]
 set -u
@@ -24,9 +24,11 @@ run c3 fft_10000x100000x3 k_wsplit_accum 13 --steps 10 --warmup 3
 [ "$QUICK" = quick ] && exit 0
 run c3bp fft_10000x100000x3_bp k_wsplit_accum+k_winverse+k_bp_transpose+k_sum_partials 3 --steps 2 --warmup 1 --by-particle
 run direct direct_5000x50000x3 k_band_lags 3 --steps 2 --warmup 1 --mode direct --frames 5000 --atoms 50000
-run directbp direct_5000x50000x3_bp k_direct+k_sum_partials+k_bp_transpose 3 --steps 2 --warmup 1 --mode direct --frames 5000 --atoms 50000 --by-particle
-run helf64 helfand_20000x25000x3 k_helfand_product+k_band_lags+k_band_gather 2 --steps 1 --warmup 1 --mode helfand --frames 20000 --atoms 25000
-run helf32 helfand_20000x25000x3_f32 k_helfand_product32+k_band32_lags+k_band_gather 2 --steps 1 --warmup 1 --mode helfand --float32 --frames 20000 --atoms 25000
+run directbp direct_5000x50000x3_bp k_band_bp_vacf+k_bp_transpose+k_sum_partials 3 --steps 2 --warmup 1 --mode direct --frames 5000 --atoms 50000 --by-particle
+run helf64 helfand_20000x25000x3 k_helfand_product+k_band_bp_helf+k_bandbp_gather 2 --steps 1 --warmup 1 --mode helfand --frames 20000 --atoms 25000
+run helf64bp helfand_20000x25000x3_bp k_helfand_product+k_band_bp_helf+k_bp_transpose+k_sum_partials 2 --steps 1 --warmup 1 --mode helfand --frames 20000 --atoms 25000 --by-particle
+run helf32 helfand_20000x25000x3_f32 k_helfand_product32+k_band32_tp+k_bandbp_gather 2 --steps 1 --warmup 1 --mode helfand --float32 --frames 20000 --atoms 25000
+run helf32bp helfand_20000x25000x3_bp_f32 k_helfand_product32+k_band32_tp+k_bp_transpose+k_sum_partials 2 --steps 1 --warmup 1 --mode helfand --float32 --frames 20000 --atoms 25000 --by-particle
 run hfft helfand_20000x25000x3_hfft k_helfand_product+k_wsplit_accum+k_sum_partials+k_winverse+k_helfand_combine 3 --steps 2 --warmup 1 --mode helfand --helfand-fft --frames 20000 --atoms 25000
 run long fft_20000x25000x3 k_wsplit_accum 4 --steps 3 --warmup 1 --frames 20000 --atoms 25000
 run longbp fft_20000x25000x3_bp k_wsplit_accum+k_winverse+k_bp_transpose+k_sum_partials 3 --steps 2 --warmup 1 --frames 20000 --atoms 25000 --by-particle

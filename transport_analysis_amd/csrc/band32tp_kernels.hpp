@@ -28,12 +28,6 @@ namespace ta {
 #ifndef TA_BAND32TP_ABL  // timing ablations (wrong results), bit mask: 1 no norm-column adds, 2 no re-centring, 4 no flush in the loop,
 #define TA_BAND32TP_ABL 0  // 8 no MFMAs, 16 no window reads (operands = the A registers)
 #endif
-#ifndef TA_BAND32TP_ORDER  // 0: batches of 16 windows per column, read ahead of their MFMAs; 2: block lag by block lag
-#define TA_BAND32TP_ORDER 2
-#endif
-#ifndef TA_BAND32TP_SB
-#define TA_BAND32TP_SB __builtin_amdgcn_sched_barrier(0)
-#endif
 constexpr int kBand32tpFlush = TA_BAND32TP_FLUSH;  // super-steps between flushes (a multiple of 8)
 
 __device__ __forceinline__ float band32_first_lane(float x) {
@@ -171,15 +165,6 @@ __global__ void __launch_bounds__(64 * NW)
                 }
                 write_chunk.template operator()<TAIL>((a + 5) % kBpChunks, fB + 64 * (S + 5), sb[a & 1]);  // chunk S + 5
                 TA_LDS_ORDER();
-                // the 16 windows of ring row `row` for this super-step: a batch of LDS reads that is in flight while the MFMAs of
-                // the batch before it run (left to itself the compiler reads two windows, waits, issues two MFMAs, ...: an LDS
-                // round trip per 64 matrix cycles)
-                float Bf[2][16];
-                auto read_batch = [&](int buf, int row) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int d = 0; d < 16; ++d) Bf[buf][d] = rB[row][(64 * a + 16 * d) % (64 * kBpChunks) + lane];
-                };
-                if constexpr (!TAIL && !(TA_BAND32TP_ABL & 16) && TA_BAND32TP_ORDER == 0) read_batch(0, 0);
                 float A[D], asq = 0.0f;
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
@@ -195,29 +180,19 @@ __global__ void __launch_bounds__(64 * NW)
                 __builtin_amdgcn_sched_barrier(0);  // the requests stay here, two super-steps ahead of their use
                 if constexpr (!TAIL) {
                     na += asq;
-#if TA_BAND32TP_ORDER == 0
-#pragma unroll
-                    for (int c = 0; c < D; ++c) {
-                        if (!(TA_BAND32TP_ABL & 16)) read_batch((c + 1) & 1, c + 1);  // the next column's windows (after the last column: the norms')
-                        TA_BAND32TP_SB;
-                        if (!(TA_BAND32TP_ABL & 8)) {
-#pragma unroll
-                            for (int d = 0; d < 16; ++d) acc[d] = TA_BAND32_MFMA(A[c], (TA_BAND32TP_ABL & 16) ? A[(c + d) % D] : Bf[c & 1][d], acc[d]);
-                        }
-                        TA_BAND32TP_SB;
-                    }
-#pragma unroll
-                    for (int d = 0; d < 16; ++d)
-                        if (!(TA_BAND32TP_ABL & 17)) nbacc[d] += Bf[D & 1][d];
-#else  // block lag by block lag: a window of every column and of the norms, their MFMAs, the norm add
+                    // block lag by block lag: a window of every column and of the norms, their MFMAs, the norm add.  (Measured at
+                    // 20000 x 25000 x 3, profiles/r05_band32tp_ablation.txt: reading a column's 16 windows as one batch ahead of its
+                    // MFMAs 258 ms, this order 256; requesting block lag d + 1's windows before the MFMAs of d with the scheduler
+                    // fenced per block lag 309; three waves per SIMD 320 - 490, the loop then spills.)
 #pragma unroll
                     for (int d = 0; d < 16; ++d) {
                         const int w = (64 * a + 16 * d) % (64 * kBpChunks) + lane;
+                        if (!(TA_BAND32TP_ABL & 8)) {
 #pragma unroll
-                        for (int c = 0; c < D; ++c) acc[d] = TA_BAND32_MFMA(A[c], rB[c][w], acc[d]);
-                        nbacc[d] += rB[D][w];
+                            for (int c = 0; c < D; ++c) acc[d] = TA_BAND32_MFMA(A[c], (TA_BAND32TP_ABL & 16) ? A[(c + d) % D] : rB[c][w], acc[d]);
+                        }
+                        if (!(TA_BAND32TP_ABL & 17)) nbacc[d] += rB[D][w];
                     }
-#endif
                 } else {
                     const float Ah = -0.5f * asq;
 #pragma unroll

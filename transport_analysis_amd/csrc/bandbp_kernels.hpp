@@ -37,9 +37,6 @@ namespace ta {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
     } while (0)
 
-#ifndef TA_BANDBP_ORDER
-#define TA_BANDBP_ORDER 2
-#endif
 constexpr int kBpChunks = 8;                        // ring: chunks of 64 frames (super-step S reads chunks S ... S + 4)
 constexpr int kBpRingFrames = 64 * (kBpChunks + 1);  // + the copy of ring position 0 behind position 7
 
@@ -98,42 +95,51 @@ __global__ void __launch_bounds__(64 * NW)
         }
         TA_LDS_ORDER();
         int S = 0;
-        for (bool more = true; more;) {
+        // one super-step; a == S % 8 (a constant once unrolled: ring positions are immediates).  TAIL: the last super-steps of
+        // a unit skip the block lags whose whole window lies behind the series (the band's triangular end)
+        auto body = [&]<bool TAIL>(int a) __attribute__((always_inline)) {
+            const int pos = (a + 5) % kBpChunks;
+            // The ring is written chunk by chunk and read window by window: a lane reads what OTHER lanes wrote.  The compiler
+            // sees each thread's own addresses only (a write at 64 q + lane and a read at 16 x + lane never alias for it) and
+            // may move reads across the writes: TA_LDS_ORDER() pins its order on both sides of the writes (no instruction:
+            // LDS operations of one wave complete in order).
+            TA_LDS_ORDER();
 #pragma unroll
-            for (int a = 0; a < kBpChunks; ++a) {  // S % 8 == a: ring positions are immediates
-                const int pos = (a + 5) % kBpChunks;
-                // The ring is written chunk by chunk and read window by window: a lane reads what OTHER lanes wrote.  The compiler
-                // sees each thread's own addresses only (a write at 64 q + lane and a read at 16 x + lane never alias for it) and
-                // may move reads across the writes: wave_barrier() pins its order on both sides of the writes (no instruction:
-                // LDS operations of one wave complete in order).
-                TA_LDS_ORDER();
+            for (int c = 0; c < D; ++c) {
+                rB[c][64 * pos + lane] = sb[c];  // chunk S + 5 (first read by super-step S + 1)
+                if (pos == 0) rB[c][64 * kBpChunks + lane] = sb[c];
+            }
+            TA_LDS_ORDER();
+            double A[D];
 #pragma unroll
-                for (int c = 0; c < D; ++c) {
-                    rB[c][64 * pos + lane] = sb[c];  // chunk S + 5 (first read by super-step S + 1)
-                    if (pos == 0) rB[c][64 * kBpChunks + lane] = sb[c];
-                }
-                TA_LDS_ORDER();
-                double A[D];
+            for (int c = 0; c < D; ++c) {
+                A[c] = sa[c];
+                sb[c] = load(c, fB + 64 * (S + 6));
+                sa[c] = load(c, 64 * (S + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the requests stay here, a super-step ahead of their use
 #pragma unroll
-                for (int c = 0; c < D; ++c) {
-                    A[c] = sa[c];
-                    sb[c] = load(c, fB + 64 * (S + 6));
-                    sa[c] = load(c, 64 * (S + 1));
-                }
-                __builtin_amdgcn_sched_barrier(0);  // the requests stay here, a super-step ahead of their use
-#if TA_BANDBP_ORDER == 2  // block lag by block lag
-#pragma unroll
-                for (int d = 0; d < 16; ++d)
-#pragma unroll
-                    for (int c = 0; c < D; ++c)
-                        acc[d] = TA_BAND_MFMA(A[c], rB[c][(64 * a + 16 * d) % (64 * kBpChunks) + lane], acc[d]);
-#else
+            for (int d = 0; d < 16; ++d) {  // block lag by block lag
+                if (TAIL && 64 * S + 16 * (d0 + d) >= T) continue;  // (wave-uniform)
 #pragma unroll
                 for (int c = 0; c < D; ++c)
+                    acc[d] = TA_BAND_MFMA(A[c], rB[c][(64 * a + 16 * d) % (64 * kBpChunks) + lane], acc[d]);
+            }
+        };
+        // whole passes of 8 super-steps in which every block lag's window still starts inside the series
+        const int n_ok = (T - fB - 240 + 63) / 64;  // super-steps S with 64 S + 16 (d0 + 15) < T
+        const int S_bulk = (n_ok < n_super ? (n_ok > 0 ? n_ok : 0) : n_super) / kBpChunks * kBpChunks;
+        while (S < S_bulk) {
 #pragma unroll
-                    for (int d = 0; d < 16; ++d)
-                        acc[d] = TA_BAND_MFMA(A[c], rB[c][(64 * a + 16 * d) % (64 * kBpChunks) + lane], acc[d]);
-#endif
+            for (int a = 0; a < kBpChunks; ++a) {
+                body.template operator()<false>(a);
+                ++S;
+            }
+        }
+        for (bool more = S < n_super; more;) {
+#pragma unroll
+            for (int a = 0; a < kBpChunks; ++a) {
+                body.template operator()<true>(a);
                 if (++S == n_super) {
                     more = false;
                     break;
@@ -288,8 +294,10 @@ __global__ void __launch_bounds__(64 * NW)
                 }
 #pragma unroll
                 for (int q = 0; q <= kBpChunks; ++q) {
-                    const int k = ((q % kBpChunks) - a + kBpChunks) % kBpChunks;  // position q holds chunk S + k (k <= 4) or the dead S + k - 8
-                    const int fbase = fB + 64 * (S + (k <= 4 ? k : k - kBpChunks));
+                    const int k = ((q % kBpChunks) - a + kBpChunks) % kBpChunks;  // position q holds chunk S + k
+                    if (k > 4) continue;                     // (k = 5 ... 7: chunks behind the window, about to be overwritten)
+                    if (q == kBpChunks && k == 0) continue;  // the copy of position 0 serves windows that start in position 7: chunk S + k - 1
+                    const int fbase = fB + 64 * (S + k);
                     double nb = 0.0;
 #pragma unroll
                     for (int c = 0; c < D; ++c) {
@@ -318,29 +326,9 @@ __global__ void __launch_bounds__(64 * NW)
             __builtin_amdgcn_sched_barrier(0);  // the requests stay here, a super-step ahead of their use
             if constexpr (!TAIL) {
                 na += asq;
-#if TA_BANDBP_ORDER == 0
-#pragma unroll
-                for (int c = 0; c < D; ++c)
-#pragma unroll
-                    for (int d = 0; d < 16; ++d)
-                        acc[d] = TA_BAND_MFMA(A[c], rB[c][(64 * a + 16 * d) % (64 * kBpChunks) + lane], acc[d]);
-#pragma unroll
-                for (int d = 0; d < 16; ++d) nbacc[d] += rB[D][(64 * a + 16 * d) % (64 * kBpChunks) + lane];
-#elif TA_BANDBP_ORDER == 1  // the norm column's windows first: their adds then stand among the MFMAs, not behind the last one
-                double nbw[16];
-#pragma unroll
-                for (int d = 0; d < 16; ++d) nbw[d] = rB[D][(64 * a + 16 * d) % (64 * kBpChunks) + lane];
-#pragma unroll
-                for (int c = 0; c < D; ++c) {
-#pragma unroll
-                    for (int d = 0; d < 16; ++d)
-                        acc[d] = TA_BAND_MFMA(A[c], rB[c][(64 * a + 16 * d) % (64 * kBpChunks) + lane], acc[d]);
-                    if (c == 0) {
-#pragma unroll
-                        for (int d = 0; d < 16; ++d) nbacc[d] += nbw[d];
-                    }
-                }
-#else  // block lag by block lag
+                // block lag by block lag: the windows of every column and of the norms, their MFMAs, the norm add (column by column
+                // with the norm adds behind the last MFMA: 490 ms at 20000 x 25000 x 3; the norm adds after the first column: 476;
+                // this order: 462)
 #pragma unroll
                 for (int d = 0; d < 16; ++d) {
                     const int w = (64 * a + 16 * d) % (64 * kBpChunks) + lane;
@@ -348,7 +336,6 @@ __global__ void __launch_bounds__(64 * NW)
                     for (int c = 0; c < D; ++c) acc[d] = TA_BAND_MFMA(A[c], rB[c][w], acc[d]);
                     nbacc[d] += rB[D][w];
                 }
-#endif
             } else {
                 const double Ah = -0.5 * asq;
 #pragma unroll
