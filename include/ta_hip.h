@@ -292,20 +292,22 @@ int ta_band_plan_info(int64_t n_frames, int n_cu, int *n_pieces, int *octets_in_
  *   "direct_f32" 0|1 : direct correlators (ta_vacf_direct*, ta_helfand_msd*) round the staged values (Helfand:
  *                      P = (m v) x, formed in float64) ONCE to float32, form products / squared differences
  *                      in float32 and accumulate in float64 (BASELINE configs[4]'s float32 path; within 2e-6
- *                      of the series' scale).  Helfand runs on the FP32 matrix cores (band32_kernels.hpp:
- *                      v_mfma_f32_16x16x4_f32 on a float32 product slab, T*A*D*4 bytes more): the lag sums
- *                      alone 1.7x faster than the float32 vector kernel, with the by-particle array (dim = 3)
- *                      1.4x; the windowed VACF and dim < 3 stay on the vector kernels.  Default 0 = float64.
- *   "direct_mfma" 1|0: ta_vacf_direct* and ta_helfand_msd* WITHOUT a by-particle array (lag sums only,
- *                      float64) run on the FP64 matrix cores (band_kernels.hpp): the windowed VACF's
- *                      lag sums are the diagonal sums of the frames' Gram matrix
- *                      (velocityautocorr.py:217-238 summed over particles; 1.4x the vector kernel); the
- *                      Helfand squared differences (viscosity.py:201-233) are formed from products of
- *                      rows centred on a nearby frame (1.5x; every lag within 1e-10 of the
- *                      difference-first vector kernel even for a pure trend; needs T*A*D*8 bytes for
- *                      the product slab, else the vector kernel runs).  0 = the vector kernels, also for
- *                      "direct_f32".  In float64 the by-particle arrays come from the vector kernels whatever
- *                      this says.
+ *                      of the series' scale).  Helfand runs on the FP32 matrix cores (band32tp_kernels.hpp:
+ *                      v_mfma_f32_16x16x4_f32 on a float32 product slab, T*A*D*4 bytes more), with or without
+ *                      the by-particle array, any dim: 2.2x the float32 vector kernel; the windowed VACF stays on
+ *                      the vector kernel.  Default 0 = float64.
+ *   "direct_mfma" 1|0|2: ta_vacf_direct* and ta_helfand_msd* run on the matrix cores (float64: FP64,
+ *                      v_mfma_f64_16x16x4_f64).  Windowed VACF (velocityautocorr.py:217-238): lag sums alone =
+ *                      the diagonal sums of the frames' Gram matrix (band_kernels.hpp, 1.4x the vector
+ *                      kernel); with the by-particle array the instruction's k-slots are filled from the time
+ *                      axis (bandbp_kernels.hpp, 1.45x).  Helfand squared differences (viscosity.py:201-233):
+ *                      products of rows centred on a nearby frame, k-slots from the time axis, with or without
+ *                      the by-particle array (2.1x / 1.4x the forms before it; every lag and particle within 1e-9
+ *                      of the difference-first vector kernel, pure trend included; needs T*A*D*8 bytes for the
+ *                      product slab, else the vector kernel runs).  0 = the vector kernels everywhere, also
+ *                      under "direct_f32".  2 = the column-packed Helfand forms of round 4 / early round 5
+ *                      (band_kernels.hpp's k_band_lags<true>; band32_kernels.hpp's k_band32_lags, and
+ *                      k_band32_bp at dim = 3), kept as a second implementation the tests run.
  *   "helfand_fft" 0|1: ta_helfand_msd* evaluate the mean squared differences in O(T log T)
  *                      (n_frames <= 163840, else as default): sum (P[i]-P[i+k])^2 = S1(k) - 2 S2(k), S2 by the FFT
  *                      lag sums of the product slab P = (m v) x, S1 by prefix sums.  An

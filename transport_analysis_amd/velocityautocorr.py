@@ -35,11 +35,13 @@ class VelocityAutocorr(AnalysisBase):
         ``False``: direct "windowed" algorithm.  Both give the same quantity.
     by_particle : bool, keyword-only, default True
         ``True`` materialises ``results.vacf_by_particle`` (n_frames, n_atoms)
-        as the reference does.  ``False`` is the fast path: only
-        ``results.timeseries`` is computed (``fft=True``: power spectra are summed
-        over atoms on the GPU before the single inverse transform; ``fft=False``:
-        the lag sums are the diagonal sums of the frames' Gram matrix, on the FP64
-        matrix cores) and ``results.vacf_by_particle`` is ``None``.
+        as the reference does (``fft=False``: on the FP64 matrix cores, a particle's
+        column in a per-wave LDS ring).  ``False`` computes only
+        ``results.timeseries`` (``fft=True``: power spectra are summed
+        over atoms on the GPU before the single inverse transform, 2.4x faster;
+        ``fft=False``: the lag sums are the diagonal sums of the frames' Gram matrix,
+        on the FP64 matrix cores, no faster than with the array) and
+        ``results.vacf_by_particle`` is ``None``.
     device : int, keyword-only
         GPU index (default: ``$TA_AMD_DEVICE`` or 0; with ``distributed=True``:
         ``$TA_AMD_DEVICE``, else ``$LOCAL_RANK``, else torch's current device).

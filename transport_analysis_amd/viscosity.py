@@ -27,8 +27,8 @@ class ViscosityHelfand(AnalysisBase):
     dim_type : {'xyz', 'xy', 'yz', 'xz', 'x', 'y', 'z'}
     linear_fit_window : (int, int) or None — lag-index window for the slope fit.
     by_particle : bool, keyword-only, default True — materialise
-        ``results.visc_by_particle``; ``False`` computes the timeseries only (float64: on the
-        FP64 matrix cores, 1.5x the vector kernel, every lag to rounding).
+        ``results.visc_by_particle``; ``False`` computes the timeseries only.  Both run on the
+        matrix cores (FP64; ``float32=True``: FP32), every lag to the path's accuracy.
     device : int, keyword-only — GPU index (default ``$TA_AMD_DEVICE`` or 0).
     distributed : bool, keyword-only, default False — one process per GPU under
         ``torch.distributed``: each rank handles its contiguous block of atoms, one all-reduce of
@@ -36,8 +36,8 @@ class ViscosityHelfand(AnalysisBase):
         holds this rank's atoms only (``results.particle_range``).
     float32 : bool, keyword-only, default False — form the mass-weighted
         velocity-position products in float64, then evaluate the squared differences and
-        their block sums in float32 (accumulated into float64): ~1e-6 relative accuracy
-        instead of 1e-10, about twice the throughput.
+        their block sums in float32 (accumulated into float64): 2e-6 of the series' scale
+        instead of 1e-10 relative, 1.8x the throughput.
 
     fft : bool, keyword-only, default False — an extension (the reference has only the
         O(n_frames^2) loop): evaluate the mean squared differences in
