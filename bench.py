@@ -225,7 +225,7 @@ def single_process(args):
                    "library_sha16": so_sha16(), "launcher": "single process"},
         "roofline": {"bound": "hbm", "achieved": slowest["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": slowest["GBps"] / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "k_wsplit_accum" if args.mode == "fft" else "k_band_lags",
+                     "kernel": "k_wsplit_accum" if args.mode == "fft" else "k_band_bp_vacf",
                      "kernel_ms": slowest["kernel_ms"], "algorithmic_bytes_per_launch": slowest["bytes"],
                      "what": "the slowest member's dominant kernel (hipEvents on its own stream, median over the timed calls); "
                              "`per_member` has all of them, `reduce_and_host_ms` what the call adds to the slowest member "
@@ -327,7 +327,7 @@ class Case:
                 return "k_band32_tp" if self.float32 else ("k_band_bp_vacf" if self.mode == "direct" else "k_band_bp_helf")
             if self.mode == "helfand":
                 return "k_band32_tp" if self.float32 else "k_band_bp_helf"
-            return "k_band_lags"
+            return "k_band_bp_vacf"
         if self.mode != "fft" and not (self.mode == "helfand" and self.helfand_fft):
             return "k_direct"
         if self.T > 163840:

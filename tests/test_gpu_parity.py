@@ -142,21 +142,24 @@ def test_vacf_direct_vs_oracle_shapes(ctx, T, A, D):
 @pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 1, 1), (15, 3, 1), (16, 5, 3), (17, 2, 2), (240, 4, 3), (241, 3, 3),
                                    (255, 7, 3), (256, 3, 3), (257, 9, 1), (271, 4, 3), (272, 4, 3), (273, 5, 2),
                                    (511, 6, 3), (513, 11, 3), (1000, 37, 3), (2049, 8, 3), (4100, 3, 3),
-                                   (5000, 21, 3), (9000, 3, 1), (300, 2001, 1)])
-def test_vacf_direct_lag_sums_on_the_matrix_cores(ctx, T, A, D):
-    """Windowed VACF without the by-particle array = diagonal sums of the frames' Gram matrix:
-    k_band_lags (v_mfma_f64_16x16x4_f64, band_kernels.hpp) against the oracle and against the
-    vector kernel it replaces ("direct_mfma" 0); frame counts on both sides of the 16-frame blocks
-    and the 256-lag groups, odd column counts (the unpaired column's zero partner), few and many
-    columns."""
+                                   (5000, 21, 3), (9000, 3, 1), (300, 2001, 1), (300, 2003, 3)])
+@pytest.mark.parametrize("form", [1, 2])
+def test_vacf_direct_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
+    """Windowed VACF without the by-particle array = diagonal sums of the frames' Gram matrix, both
+    matrix-core forms: "direct_mfma" 1 (the default) k_band_bp_vacf with a unit's particles summed in its
+    accumulators (k-slots from the time axis, bandbp_kernels.hpp), 2 the column-packed k_band_lags
+    (band_kernels.hpp) — against the oracle and against the vector kernel ("direct_mfma" 0); frame counts on
+    both sides of the 16-frame blocks and the 256-lag groups, odd column counts (the unpaired column's zero
+    partner), few and many columns."""
     from oracle import numpy_oracle as orc
 
     v = orc.synthetic_velocities(T, A, D, seed=2600 + T)
     want_ts = orc.vacf_windowed(v)[1] if T <= 1000 else orc.vacf_fft_batched(v)[1]
     ctx.set_option("timeline", 1)
+    ctx.set_option("direct_mfma", form)
     try:
         ts_m, _ = run_vacf(ctx, v, False, False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_lags"]
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_bp_vacf" if form == 1 else "k_band_lags"]
         ts_again, _ = ctx.vacf_direct(by_particle=False)
         assert np.array_equal(ts_m, ts_again)  # fixed summation order: the same bits every launch
         ctx.set_option("direct_mfma", 0)
@@ -633,10 +636,10 @@ def test_vacf_fft_long_trajectory(ctx, T, A, D):
 
 
 def test_vacf_beyond_the_fft_plans(ctx):
-    """n_frames > 163840: ta_vacf_fft computes the same quantity with the O(T^2) correlators — the lag sums
-    on the matrix cores (10241 block lags, 641 groups: more groups than wave slots, so every wave runs
-    several whole groups), the by-particle array on the vector kernel with the column staged in global
-    memory — against the FFT oracle."""
+    """n_frames > 163840: ta_vacf_fft computes the same quantity with the O(T^2) correlators on the matrix
+    cores — 10241 block lags, 641 groups of 16: the time-packed kernel's 641 units of one particle (lag sums and
+    by particle), and under "direct_mfma" 2 the column-packed kernel (more groups than wave slots, so every wave
+    runs several whole groups) — against the FFT oracle."""
     from oracle import numpy_oracle as orc
 
     T, A, D = 163841, 1, 2
@@ -645,10 +648,14 @@ def test_vacf_beyond_the_fft_plans(ctx):
     ctx.set_option("timeline", 1)
     try:
         ts, bp = run_vacf(ctx, v, True, False)
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_bp_vacf"]
+        ctx.set_option("direct_mfma", 2)
+        ts2, _ = ctx.vacf_fft(by_particle=False)
         assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_lags"]
     finally:
+        ctx.set_option("direct_mfma", 1)
         ctx.set_option("timeline", 0)
-    assert scale_rel_err(ts, want_ts) < TOL
+    assert scale_rel_err(ts, want_ts) < TOL and scale_rel_err(ts2, want_ts) < TOL
     ts, bp = ctx.vacf_fft(by_particle=True)
     assert scale_rel_err(bp, want_bp) < TOL and scale_rel_err(ts, want_ts) < TOL
 
@@ -1482,7 +1489,7 @@ def test_kernel_timeline_sums_to_the_call(ctx):
         # the marks sit inside the call's own start / end events
         assert 0.5 * total < sum(ms for _, ms in tl) <= 1.02 * total
         ts2, _ = ctx.vacf_direct(by_particle=False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_lags"]  # lag sums alone: matrix cores
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_bp_vacf"]  # lag sums alone: matrix cores
         ctx.vacf_direct(by_particle=True)
         assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_bp_vacf", "k_bp_transpose", "k_sum_partials"]
         ctx.set_option("direct_mfma", 0)

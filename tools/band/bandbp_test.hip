@@ -50,7 +50,7 @@ static void launch(int nwg, const double* pm, long pitch, int T, long A, double*
     static unsigned long long* counter = nullptr;
     if (!counter) CK(hipMalloc(&counter, 8));
     CK(hipMemsetAsync(counter, 0, 8, 0));
-    hipLaunchKernelGGL((k_band_bp_vacf<D, BP_NW>), dim3(nwg), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A, out, ld, counter);
+    hipLaunchKernelGGL((k_band_bp_vacf<D, BP_NW, false>), dim3(nwg), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A, out, ld, counter, 1, (double*)nullptr);
 }
 static void launch_d(int D, int nwg, const double* pm, long pitch, int T, long A, double* out, long ld) {
     if (D == 1) launch<1>(nwg, pm, pitch, T, A, out, ld);
@@ -168,7 +168,7 @@ static int tcheck_one(int T, long A, int D, int nwg, int kind, int per) {  // pe
         if (D == 1) launch_t<1, true>(nwg, pm, pitch, T, A, nullptr, 0, per, partial);
         else if (D == 2) launch_t<2, true>(nwg, pm, pitch, T, A, nullptr, 0, per, partial);
         else launch_t<3, true>(nwg, pm, pitch, T, A, nullptr, 0, per, partial);
-        hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 255) / 256), dim3(256), 0, 0, partial, n_pb, n_groups, T, 1.0, lagsum);
+        hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 15) / 16), dim3(256), 0, 0, partial, n_pb, n_groups, T, 1.0, 1, lagsum);
     } else {
         if (D == 1) launch_t<1, false>(nwg, pm, pitch, T, A, out, pitch, 1, nullptr);
         else if (D == 2) launch_t<2, false>(nwg, pm, pitch, T, A, out, pitch, 1, nullptr);
@@ -336,7 +336,7 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(e0, 0));
             if (per) {
                 launch_t<3, true>(prop.multiProcessorCount, pm, pitch, T, A, nullptr, 0, per, partial);
-                hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 255) / 256), dim3(256), 0, 0, partial, n_pb, n_groups, T, 1.0, lagsum);
+                hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 15) / 16), dim3(256), 0, 0, partial, n_pb, n_groups, T, 1.0, 1, lagsum);
             } else {
                 CK(hipMemsetAsync(out, 0, 8 * (size_t)A * pitch, 0));
                 launch_t<3, false>(prop.multiProcessorCount, pm, pitch, T, A, out, pitch, 1, nullptr);
@@ -347,6 +347,38 @@ int main(int argc, char** argv) {
             CK(hipEventElapsedTime(&ms, e0, e1));
             if (r) printf("  Helfand float32 time-packed (%s, %d waves per workgroup) %d x %ld x 3: %.3f ms  %.1f TFLOP/s (2 flop per term)\n",
                           per ? "lag sums" : "by particle", TP_NW, T, A, ms, 2.0 * (double)T * (T - 1) / 2 * n_cols / (ms * 1e-3) / 1e12);
+        }
+        return 0;
+    }
+    if (!strcmp(mode, "ltime")) {  // windowed VACF lag sums alone (per_unit particles per unit)
+        const int T = argc > 2 ? atoi(argv[2]) : 5000;
+        const long A = argc > 3 ? atol(argv[3]) : 50000;
+        const int per = argc > 4 ? atoi(argv[4]) : 16;
+        const long n_cols = 3 * A, n_pairs = (n_cols + 1) / 2, pitch = (T + 7) / 8 * 8;
+        const int n_groups = ((T + 15) / 16 + 15) / 16;
+        const long n_pb = (A + per - 1) / per;
+        double *pm, *partial, *lagsum;
+        unsigned long long* counter;
+        CK(hipMalloc(&pm, (size_t)n_pairs * pitch * 16));
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, pm, (size_t)n_pairs * pitch * 2);
+        CK(hipMalloc(&partial, 8 * (size_t)n_pb * n_groups * kBandPartial));
+        CK(hipMalloc(&lagsum, 8 * (size_t)T));
+        CK(hipMalloc(&counter, 8));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        for (int r = 0; r < 3; ++r) {
+            CK(hipEventRecord(e0, 0));
+            CK(hipMemsetAsync(counter, 0, 8, 0));
+            hipLaunchKernelGGL((k_band_bp_vacf<3, BP_NW, true>), dim3(prop.multiProcessorCount), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A,
+                               (double*)nullptr, 0L, counter, per, partial);
+            hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 15) / 16), dim3(256), 0, 0, partial, n_pb, n_groups, T, 1.0, 0, lagsum);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r) printf("  windowed VACF lag sums (FP64 matrix cores, %d particles per unit) %d x %ld x 3: %.3f ms  %.1f TFLOP/s\n", per, T, A, ms,
+                          2.0 * (double)T * (T + 1) / 2 * n_cols / (ms * 1e-3) / 1e12);
         }
         return 0;
     }
@@ -372,7 +404,7 @@ int main(int argc, char** argv) {
             CK(hipMemsetAsync(counter, 0, 8, 0));
             hipLaunchKernelGGL((k_band_bp_helf<3, BP_NW, true>), dim3(prop.multiProcessorCount), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A, 1.0,
                                (double*)nullptr, 0L, counter, per, partial);
-            hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 255) / 256), dim3(256), 0, 0, partial, n_pb, n_groups, T, 1.0, lagsum);
+            hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 15) / 16), dim3(256), 0, 0, partial, n_pb, n_groups, T, 1.0, 1, lagsum);
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float ms;

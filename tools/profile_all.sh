@@ -23,7 +23,7 @@ run() {  # name key kernels steps_total args...
 run c3 fft_10000x100000x3 k_wsplit_accum 13 --steps 10 --warmup 3
 [ "$QUICK" = quick ] && exit 0
 run c3bp fft_10000x100000x3_bp k_wsplit_accum+k_winverse+k_bp_transpose+k_sum_partials 3 --steps 2 --warmup 1 --by-particle
-run direct direct_5000x50000x3 k_band_lags 3 --steps 2 --warmup 1 --mode direct --frames 5000 --atoms 50000
+run direct direct_5000x50000x3 k_band_bp_vacf+k_bandbp_gather 3 --steps 2 --warmup 1 --mode direct --frames 5000 --atoms 50000
 run directbp direct_5000x50000x3_bp k_band_bp_vacf+k_bp_transpose+k_sum_partials 3 --steps 2 --warmup 1 --mode direct --frames 5000 --atoms 50000 --by-particle
 run helf64 helfand_20000x25000x3 k_helfand_product+k_band_bp_helf+k_bandbp_gather 2 --steps 1 --warmup 1 --mode helfand --frames 20000 --atoms 25000
 run helf64bp helfand_20000x25000x3_bp k_helfand_product+k_band_bp_helf+k_bp_transpose+k_sum_partials 2 --steps 1 --warmup 1 --mode helfand --frames 20000 --atoms 25000 --by-particle

@@ -41,7 +41,7 @@ hipError_t launch_band32_tp_lags(int n_cu, const float* P32, long pitch, int T, 
     if (e != hipSuccess) return e;
     e = launch_tp<true>(n_cu, P32, pitch, T, n_atoms, D, factor, nullptr, 0, next_unit, per, partial, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 255) / 256), dim3(256), 0, st, partial, n_pb, n_groups, T, factor, lagsum);
+    hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 15) / 16), dim3(256), 0, st, partial, n_pb, n_groups, T, factor, 1, lagsum);
     return hipGetLastError();
 }
 

@@ -42,17 +42,19 @@ constexpr int kBpRingFrames = 64 * (kBpChunks + 1);  // + the copy of ring posit
 
 // pm: pair-major float64 slab of n_atoms * D columns.  bp_am[particle * ld_am + lag] = S[lag] / (T - lag), every lag
 // < T written or added to: bp_am and *next_unit must be ZERO on entry.  grid: any number of workgroups of 64 NW threads.
-template <int D, int NW>
+// LAGS (lag sums alone): a unit is a block lag group of `per_unit` consecutive particles summed in the same accumulators;
+// it writes partial[(g * n_pb + block) * kBandPartial + q] = the sum for lag 256 g - 15 + q (k_bandbp_gather adds them up).
+template <int D, int NW, bool LAGS>
 __global__ void __launch_bounds__(64 * NW)
     k_band_bp_vacf(const double* __restrict__ pm, long pitch, int T, long n_atoms, double* __restrict__ bp_am, long ld_am,
-                   unsigned long long* __restrict__ next_unit) {
+                   unsigned long long* __restrict__ next_unit, int per_unit, double* __restrict__ partial) {
     static_assert(D >= 1 && D <= 3, "a particle's columns lie in at most two column pairs");
     constexpr int DR = D < 2 ? 2 : D;  // (one column's ring is smaller than the epilogue's scratch)
     static_assert(DR * kBpRingFrames >= 2 * 16 * 32, "the epilogue's scratch reuses the ring");
     __shared__ double ringB[NW][DR][kBpRingFrames];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nblk = (T + 15) / 16, n_groups = (nblk + 15) / 16;
-    const long n_units = n_atoms * n_groups;
+    const long n_pb = LAGS ? (n_atoms + per_unit - 1) / per_unit : n_atoms, n_units = n_pb * n_groups;
     double(*rB)[kBpRingFrames] = ringB[wave];
     for (;;) {
         // units differ in length (the band of block lag 16 g is nblk - 16 g blocks long): a wave takes the next one when it
@@ -62,8 +64,16 @@ __global__ void __launch_bounds__(64 * NW)
         const long u = (long)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(taken >> 32)) << 32) |
                               (unsigned)__builtin_amdgcn_readfirstlane((int)taken));
         if (u >= n_units) break;
-        const long atom = __builtin_amdgcn_readfirstlane((int)(u / n_groups));
-        const int g = __builtin_amdgcn_readfirstlane((int)(u - atom * n_groups)), d0 = 16 * g;
+        // a particle's (a block of particles') units one after the other: they run at about the same time, on the same rows.
+        // (Longest units first — all blocks at block lag group 0, then group 1, ... — loses that and is 2 - 5 % slower.)
+        const long pb = __builtin_amdgcn_readfirstlane((int)(u / n_groups));
+        const int g = __builtin_amdgcn_readfirstlane((int)(u - pb * n_groups)), d0 = 16 * g;
+        const int n_super = (nblk - d0 + 3) / 4, fB = 16 * d0;
+        band_d4 acc[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) acc[d] = band_d4{0.0, 0.0, 0.0, 0.0};
+        const long atom_lo = LAGS ? pb * per_unit : pb, atom_hi = LAGS ? (atom_lo + per_unit < n_atoms ? atom_lo + per_unit : n_atoms) : pb + 1;
+        for (long atom = atom_lo; atom < atom_hi; ++atom) {
         // one buffer resource per column, cut off behind frame T - 1: frames past the end of the series read as zeros
         // (the rows behind them belong to the padding or to the next pair) and every column takes the same offsets
         __amdgpu_buffer_rsrc_t rs[D];
@@ -76,10 +86,6 @@ __global__ void __launch_bounds__(64 * NW)
         auto load = [&](int c, int f0) -> double {  // frames f0 ... f0 + 63 of column c, one per lane
             return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs[c], (f0 + lane) * 16, 0, 0));
         };
-        const int n_super = (nblk - d0 + 3) / 4, fB = 16 * d0;
-        band_d4 acc[16];
-#pragma unroll
-        for (int d = 0; d < 16; ++d) acc[d] = band_d4{0.0, 0.0, 0.0, 0.0};
         // the ring's first five chunks; chunk 5 and the first A chunk wait in registers
         double sb[D], sa[D];
 #pragma unroll
@@ -146,6 +152,8 @@ __global__ void __launch_bounds__(64 * NW)
                 }
             }
         }
+        TA_LDS_ORDER();  // (the next particle's rows overwrite the ring)
+        }
         // diagonals: acc[d] register r of lane l is C_d[m = 4 r + (l >> 4)][n = l & 15], lag 16 (d0 + d) + n - m.
         // A block goes to the LDS skewed — row m, column n - m + 15 — so that a diagonal is a column: its sum is 16
         // reads without a bound (the cells no row writes stay zero), eight per half wave.
@@ -168,7 +176,23 @@ __global__ void __launch_bounds__(64 * NW)
             if (lane < 32) dsum[d * 32 + lane] = s;
             TA_LDS_ORDER();
         }
-        double* out = bp_am + atom * ld_am;
+        if constexpr (LAGS) {
+            double* out = partial + ((long)g * n_pb + pb) * kBandPartial;
+            for (int q = lane; q < kBandPartial; q += 64) {
+                // slot q is lag offset q - 15 = 16 d + e: (d, e >= 0) and (d + 1, e - 16)
+                const int off = q - 15;
+                const int d = off >= 0 ? off >> 4 : -1, e = off - 16 * d;  // e in [0, 15] (off < 0: 1..15)
+                double s = 0.0;
+                if (off <= 255) {
+                    if (d >= 0) s = dsum[d * 32 + e + 15];
+                    if (e >= 1 && d + 1 <= 15) s += dsum[(d + 1) * 32 + e - 16 + 15];
+                }
+                out[q] = s;
+            }
+            TA_LDS_ORDER();
+            continue;
+        }
+        double* out = bp_am + pb * ld_am;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int off = lane + 64 * k;  // lag 256 g + off = 16 (d0 + d) + e: block lag d with e >= 0, d + 1 with e - 16
@@ -235,6 +259,8 @@ __global__ void __launch_bounds__(64 * NW)
         const long u = (long)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(taken >> 32)) << 32) |
                               (unsigned)__builtin_amdgcn_readfirstlane((int)taken));
         if (u >= n_units) break;
+        // a particle's (a block of particles') units one after the other: they run at about the same time, on the same rows.
+        // (Longest units first — all blocks at block lag group 0, then group 1, ... — loses that and is 2 - 5 % slower.)
         const long pb = __builtin_amdgcn_readfirstlane((int)(u / n_groups));
         const int g = __builtin_amdgcn_readfirstlane((int)(u - pb * n_groups)), d0 = 16 * g;
         const int n_super = (nblk - d0 + 3) / 4, fB = 16 * d0;
@@ -443,19 +469,30 @@ __global__ void __launch_bounds__(64 * NW)
     }
 }
 
-// lagsum[k] = factor * (sum over the particle blocks of the halves that hold lag k) / (T - k), fixed order; lagsum[0] = 0
+// lagsum[k] = factor * (sum over the particle blocks of the halves that hold lag k) / (T - k), in a fixed order: a block
+// takes 16 lags, its 16 slices of threads each every 16th particle block, their sums are added slice by slice.
+// zero_lag0: lagsum[0] = 0 exactly (viscosity.py:205-233 leaves row 0 at 0).  grid: ceil(T / 16) blocks of 256.
 static __global__ void __launch_bounds__(256)
-    k_bandbp_gather(const double* __restrict__ partial, long n_pb, int n_groups, int T, double factor, double* __restrict__ lagsum) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= T) return;
+    k_bandbp_gather(const double* __restrict__ partial, long n_pb, int n_groups, int T, double factor, int zero_lag0,
+                    double* __restrict__ lagsum) {
+    __shared__ double red[16][17];
+    const int kk = threadIdx.x & 15, sl = threadIdx.x >> 4, k = blockIdx.x * 16 + kk;
     double s = 0.0;
-    for (int h = 0; h < 2; ++h) {  // group g holds lag offsets -15 ... 255 from 256 g
-        const int g = (k >> 8) + h, off = k - 256 * g;
-        if (g >= n_groups || off < -15) continue;
-        const double* p = partial + (long)g * n_pb * kBandPartial + off + 15;
-        for (long b = 0; b < n_pb; ++b) s += p[b * kBandPartial];
+    if (k < T)
+        for (int h = 0; h < 2; ++h) {  // group g holds lag offsets -15 ... 255 from 256 g
+            const int g = (k >> 8) + h, off = k - 256 * g;
+            if (g >= n_groups || off < -15) continue;
+            const double* p = partial + (long)g * n_pb * kBandPartial + off + 15;
+            for (long b = sl; b < n_pb; b += 16) s += p[b * kBandPartial];
+        }
+    red[sl][kk] = s;
+    __syncthreads();
+    if (sl == 0 && k < T) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][kk];
+        lagsum[k] = (zero_lag0 && k == 0) ? 0.0 : factor * (t / (double)(T - k));
     }
-    lagsum[k] = k == 0 ? 0.0 : factor * (s / (double)(T - k));
 }
 
 }  // namespace ta

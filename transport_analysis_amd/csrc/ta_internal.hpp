@@ -72,6 +72,8 @@ hipError_t launch_row_sums(const double* bp, long n_rows, long n_cols, long ld, 
 // bandbp.hip: the windowed VACF with its by-particle array on the FP64 matrix cores (atom-major scratch, zeroed inside)
 hipError_t launch_band_bp_vacf(int n_cu, const double* pm, long pitch, int T, long n_atoms, int D, double* bp_am, long ld_am,
                                unsigned long long* next_unit, hipStream_t st);
+hipError_t launch_band_bp_vacf_lags(int n_cu, const double* pm, long pitch, int T, long n_atoms, int D, double* partial,
+                                    unsigned long long* next_unit, double* lagsum, hipStream_t st);
 hipError_t launch_band_bp_helf(int n_cu, const double* P, long pitch, int T, long n_atoms, int D, double factor, double* bp_am,
                                long ld_am, unsigned long long* next_unit, hipStream_t st);
 int band_bp_helf_block(int n_cu, int T, long n_atoms);
