@@ -48,8 +48,8 @@ __global__ void k_fill32(float* p, size_t n) {
 template <int D>
 static void launch(int nwg, const double* pm, long pitch, int T, long A, double* out, long ld) {
     static unsigned long long* counter = nullptr;
-    if (!counter) CK(hipMalloc(&counter, 8));
-    CK(hipMemsetAsync(counter, 0, 8, 0));
+    if (!counter) CK(hipMalloc(&counter, 64));
+    CK(hipMemsetAsync(counter, 0, 64, 0));
     hipLaunchKernelGGL((k_band_bp_vacf<D, BP_NW, false>), dim3(nwg), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A, out, ld, counter, 1, (double*)nullptr);
 }
 static void launch_d(int D, int nwg, const double* pm, long pitch, int T, long A, double* out, long ld) {
@@ -61,8 +61,8 @@ static void launch_d(int D, int nwg, const double* pm, long pitch, int T, long A
 template <int D>
 static void launch_h(int nwg, const double* pm, long pitch, int T, long A, double* out, long ld) {
     static unsigned long long* counter = nullptr;
-    if (!counter) CK(hipMalloc(&counter, 8));
-    CK(hipMemsetAsync(counter, 0, 8, 0));
+    if (!counter) CK(hipMalloc(&counter, 64));
+    CK(hipMemsetAsync(counter, 0, 64, 0));
     hipLaunchKernelGGL((k_band_bp_helf<D, BP_NW, false>), dim3(nwg), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A, 1.0, out, ld, counter, 1, (double*)nullptr);
 }
 static void launch_hd(int D, int nwg, const double* pm, long pitch, int T, long A, double* out, long ld) {
@@ -136,8 +136,8 @@ static int hcheck_one(int T, long A, int D, int nwg, int kind) {
 template <int D, bool LAGS>
 static void launch_t(int nwg, const float* pm, long pitch, int T, long A, double* out, long ld, int per, double* partial) {
     static unsigned long long* counter = nullptr;
-    if (!counter) CK(hipMalloc(&counter, 8));
-    CK(hipMemsetAsync(counter, 0, 8, 0));
+    if (!counter) CK(hipMalloc(&counter, 64));
+    CK(hipMemsetAsync(counter, 0, 64, 0));
     hipLaunchKernelGGL((k_band32_tp<D, TP_NW, LAGS>), dim3(nwg), dim3(64 * TP_NW), 0, 0, pm, pitch, T, A, 1.0, out, ld, counter, per, partial);
 }
 static int tcheck_one(int T, long A, int D, int nwg, int kind, int per) {  // per = 0: by particle; > 0: lag sums with `per` particles per unit
@@ -363,13 +363,13 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, pm, (size_t)n_pairs * pitch * 2);
         CK(hipMalloc(&partial, 8 * (size_t)n_pb * n_groups * kBandPartial));
         CK(hipMalloc(&lagsum, 8 * (size_t)T));
-        CK(hipMalloc(&counter, 8));
+        CK(hipMalloc(&counter, 64));
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
         for (int r = 0; r < 3; ++r) {
             CK(hipEventRecord(e0, 0));
-            CK(hipMemsetAsync(counter, 0, 8, 0));
+            CK(hipMemsetAsync(counter, 0, 64, 0));
             hipLaunchKernelGGL((k_band_bp_vacf<3, BP_NW, true>), dim3(prop.multiProcessorCount), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A,
                                (double*)nullptr, 0L, counter, per, partial);
             hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 15) / 16), dim3(256), 0, 0, partial, n_pb, n_groups, T, 1.0, 0, lagsum);
@@ -395,13 +395,13 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, pm, (size_t)n_pairs * pitch * 2);
         CK(hipMalloc(&partial, 8 * (size_t)n_pb * n_groups * kBandPartial));
         CK(hipMalloc(&lagsum, 8 * (size_t)T));
-        CK(hipMalloc(&counter, 8));
+        CK(hipMalloc(&counter, 64));
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
         for (int r = 0; r < 3; ++r) {
             CK(hipEventRecord(e0, 0));
-            CK(hipMemsetAsync(counter, 0, 8, 0));
+            CK(hipMemsetAsync(counter, 0, 64, 0));
             hipLaunchKernelGGL((k_band_bp_helf<3, BP_NW, true>), dim3(prop.multiProcessorCount), dim3(64 * BP_NW), 0, 0, pm, pitch, T, A, 1.0,
                                (double*)nullptr, 0L, counter, per, partial);
             hipLaunchKernelGGL(k_bandbp_gather, dim3((T + 15) / 16), dim3(256), 0, 0, partial, n_pb, n_groups, T, 1.0, 1, lagsum);

@@ -204,7 +204,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         const int64_t n_cols = A * D;
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK &&
             (!tp32 || (ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
-                       ensure(ctx, ctx->unit_counter, 8) == TA_OK))) {
+                       ensure(ctx, ctx->unit_counter, 64) == TA_OK))) {
             tl_mark(ctx, "k_helfand_product32", st);
             TA_HIP_TRY(ctx, launch_helfand_product32(d_vel, d_pos, src_f32, d_masses, pitch, T, n_cols, D, (float*)ctx->helf_p.p, st));
             tl_mark(ctx, tp32 ? "k_band32_tp" : "k_band32_lags", st);
@@ -226,7 +226,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK &&
             ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
             ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T) == TA_OK &&
-            ensure(ctx, ctx->unit_counter, 8) == TA_OK) {
+            ensure(ctx, ctx->unit_counter, 64) == TA_OK) {
             tl_mark(ctx, "k_helfand_product32", st);
             TA_HIP_TRY(ctx, launch_helfand_product32(d_vel, d_pos, src_f32, d_masses, pitch, T, n_cols, D, (float*)ctx->helf_p.p, st));
             tl_mark(ctx, tp32 ? "k_band32_tp" : "k_band32_bp", st);
@@ -252,7 +252,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         const int64_t Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
         if (ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
             ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T) == TA_OK &&
-            ensure(ctx, ctx->unit_counter, 8) == TA_OK) {
+            ensure(ctx, ctx->unit_counter, 64) == TA_OK) {
             tl_mark(ctx, "k_band_bp_vacf", st);
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
             TA_HIP_TRY(ctx, launch_band_bp_vacf(ctx->n_cu, (const double*)d_vel, pitch, (int)T, A, D, (double*)ctx->bp_scratch.p, Tp,
@@ -274,7 +274,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
             ensure(ctx, ctx->helf_small, sizeof(double) * (size_t)n_parts * T) == TA_OK &&
             ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
             ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T) == TA_OK &&
-            ensure(ctx, ctx->unit_counter, 8) == TA_OK) {
+            ensure(ctx, ctx->unit_counter, 64) == TA_OK) {
             tl_mark(ctx, "k_helfand_product", st);
             TA_HIP_TRY(ctx, launch_helfand_product((const double*)d_vel, (const double*)d_pos, d_masses, pitch, T, n_cols, D,
                                                    (double*)ctx->helf_p.p, (double*)ctx->helf_small.p, n_parts, st));
@@ -295,7 +295,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
     // by a counter instead of a fixed cut: 52.3 against 54.2 ms at 5000 x 50000 x 3); "direct_mfma" 2: the column-packed k_band_lags
     if (band_ok && mode == MODE_VACF && ctx->opt_direct_mfma != 2 &&
         ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
-        ensure(ctx, ctx->unit_counter, 8) == TA_OK) {
+        ensure(ctx, ctx->unit_counter, 64) == TA_OK) {
         tl_mark(ctx, "k_band_bp_vacf", st);
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
         TA_HIP_TRY(ctx, launch_band_bp_vacf_lags(ctx->n_cu, (const double*)d_vel, pitch, (int)T, A, D, (double*)ctx->bp_scratch.p,
@@ -321,7 +321,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)) == TA_OK &&
             ensure(ctx, ctx->helf_small, sizeof(double) * (size_t)n_parts * T) == TA_OK &&
             (!time_packed || (ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
-                              ensure(ctx, ctx->unit_counter, 8) == TA_OK))) {
+                              ensure(ctx, ctx->unit_counter, 64) == TA_OK))) {
             tl_mark(ctx, "k_helfand_product", st);
             TA_HIP_TRY(ctx, launch_helfand_product((const double*)d_vel, (const double*)d_pos, d_masses, pitch, T, n_cols, D,
                                                    (double*)ctx->helf_p.p, (double*)ctx->helf_small.p, n_parts, st));

@@ -27,7 +27,7 @@ hipError_t launch_tp(int n_cu, const float* P32, long pitch, int T, long n_atoms
 hipError_t launch_band32_tp_bp(int n_cu, const float* P32, long pitch, int T, long n_atoms, int D, double factor, double* bp_am, long ld_am,
                                unsigned long long* next_unit, hipStream_t st) {
     hipError_t e = hipMemsetAsync(bp_am, 0, sizeof(double) * (size_t)n_atoms * (size_t)ld_am, st);
-    if (e == hipSuccess) e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long), st);
+    if (e == hipSuccess) e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long) * kBpCounters, st);
     if (e != hipSuccess) return e;
     return launch_tp<false>(n_cu, P32, pitch, T, n_atoms, D, factor, bp_am, ld_am, next_unit, 1, nullptr, st);
 }
@@ -37,7 +37,7 @@ hipError_t launch_band32_tp_lags(int n_cu, const float* P32, long pitch, int T, 
                                  unsigned long long* next_unit, double* lagsum, hipStream_t st) {
     const int per = band_bp_helf_block(n_cu, T, n_atoms), n_groups = ((T + 15) / 16 + 15) / 16;
     const long n_pb = (n_atoms + per - 1) / per;
-    hipError_t e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long), st);
+    hipError_t e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long) * kBpCounters, st);
     if (e != hipSuccess) return e;
     e = launch_tp<true>(n_cu, P32, pitch, T, n_atoms, D, factor, nullptr, 0, next_unit, per, partial, st);
     if (e != hipSuccess) return e;

@@ -35,7 +35,7 @@ __device__ __forceinline__ float band32_first_lane(float x) {
 }
 
 // P32: pair-major float32 product slab (8-byte rows) of n_atoms * D columns.  grid: any number of workgroups of 64 NW threads.
-// !LAGS: bp_am[particle * ld_am + lag] = factor * sum_i sum_d (dP)^2 / (T - lag), lag 0 exactly 0; bp_am and *next_unit
+// !LAGS: bp_am[particle * ld_am + lag] = factor * sum_i sum_d (dP)^2 / (T - lag), lag 0 exactly 0; bp_am and next_unit[0 .. 7]
 // must be ZERO on entry (two units add their halves of the lags at a unit boundary).
 // LAGS: partial[(g * n_pb + block) * kBandPartial + q] = the sum for lag 256 g - 15 + q over the unit's `per_unit`
 // particles (every element written; k_bandbp_gather adds them in a fixed order).
@@ -50,21 +50,16 @@ __global__ void __launch_bounds__(64 * NW)
     __shared__ __attribute__((aligned(16))) float diag[NW][32 * 17 + 16 * 32 + 16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nblk = (T + 15) / 16, n_groups = (nblk + 15) / 16;
-    const long n_pb = LAGS ? (n_atoms + per_unit - 1) / per_unit : n_atoms, n_units = n_pb * n_groups;
+    const long n_pb = LAGS ? (n_atoms + per_unit - 1) / per_unit : n_atoms;
     float(*rB)[kBpRingFrames] = ringB[wave];
     Band32Diag sums;
     sums.init(diag[wave], lane);
     float* nas = diag[wave] + 32 * 17 + 16 * 32;  // NA[16] of a flush
     for (;;) {
-        unsigned long long taken = 0;
-        if (lane == 0) taken = atomicAdd(next_unit, 1ull);
-        const long u = (long)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(taken >> 32)) << 32) |
-                              (unsigned)__builtin_amdgcn_readfirstlane((int)taken));
-        if (u >= n_units) break;
-        // a particle's (a block of particles') units one after the other: they run at about the same time, on the same rows.
-        // (Longest units first — all blocks at block lag group 0, then group 1, ... — loses that and is 2 - 5 % slower.)
-        const long pb = __builtin_amdgcn_readfirstlane((int)(u / n_groups));
-        const int g = __builtin_amdgcn_readfirstlane((int)(u - pb * n_groups)), d0 = 16 * g;
+        long pb;
+        int g;
+        if (!band_take_unit(next_unit, lane, n_groups, n_pb, &pb, &g)) break;
+        const int d0 = 16 * g;
         const int n_super = (nblk - d0 + 3) / 4, fB = 16 * d0;
         band_f4 acc[16];
         float nbacc[16], na = 0.0f;

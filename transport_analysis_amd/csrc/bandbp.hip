@@ -11,12 +11,12 @@ namespace ta {
 int band_bp_helf_block(int n_cu, int T, long n_atoms);
 
 // bp_am[particle * ld_am + lag] = sum_{i, d} v[i, particle, d] v[i + lag, particle, d] / (n_frames - lag) (atom-major scratch of
-// n_atoms * ld_am doubles, zeroed here: two units add their halves of some lags); next_unit: 8 bytes of device memory
+// n_atoms * ld_am doubles, zeroed here: two units add their halves of some lags); next_unit: 64 bytes of device memory (one counter per XCD)
 hipError_t launch_band_bp_vacf(int n_cu, const double* pm, long pitch, int T, long n_atoms, int D, double* bp_am, long ld_am,
                                unsigned long long* next_unit, hipStream_t st) {
     constexpr int kWaves = 8;  // two per SIMD (194 registers; the rings of 8 waves take 111 KiB of the CU's LDS)
     hipError_t e = hipMemsetAsync(bp_am, 0, sizeof(double) * (size_t)n_atoms * (size_t)ld_am, st);
-    if (e == hipSuccess) e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long), st);
+    if (e == hipSuccess) e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long) * kBpCounters, st);
     if (e != hipSuccess) return e;
     const dim3 grid(std::max(1, n_cu)), block(64 * kWaves);
     double* none = nullptr;
@@ -34,7 +34,7 @@ hipError_t launch_band_bp_vacf_lags(int n_cu, const double* pm, long pitch, int 
     constexpr int kWaves = 8;
     const int per = band_bp_helf_block(n_cu, T, n_atoms), n_groups = ((T + 15) / 16 + 15) / 16;
     const long n_pb = (n_atoms + per - 1) / per;
-    hipError_t e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long), st);
+    hipError_t e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long) * kBpCounters, st);
     if (e != hipSuccess) return e;
     const dim3 grid(std::max(1, n_cu)), block(64 * kWaves);
     double* none = nullptr;
@@ -51,7 +51,7 @@ hipError_t launch_band_bp_helf(int n_cu, const double* P, long pitch, int T, lon
                                long ld_am, unsigned long long* next_unit, hipStream_t st) {
     constexpr int kWaves = 8;  // two per SIMD; four rings per wave (three centred columns and their norms): 147 KiB of LDS
     hipError_t e = hipMemsetAsync(bp_am, 0, sizeof(double) * (size_t)n_atoms * (size_t)ld_am, st);
-    if (e == hipSuccess) e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long), st);
+    if (e == hipSuccess) e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long) * kBpCounters, st);
     if (e != hipSuccess) return e;
     const dim3 grid(std::max(1, n_cu)), block(64 * kWaves);
     double* none = nullptr;
@@ -81,7 +81,7 @@ hipError_t launch_band_bp_helf_lags(int n_cu, const double* P, long pitch, int T
     constexpr int kWaves = 8;
     const int per = band_bp_helf_block(n_cu, T, n_atoms), n_groups = ((T + 15) / 16 + 15) / 16;
     const long n_pb = (n_atoms + per - 1) / per;
-    hipError_t e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long), st);
+    hipError_t e = hipMemsetAsync(next_unit, 0, sizeof(unsigned long long) * kBpCounters, st);
     if (e != hipSuccess) return e;
     const dim3 grid(std::max(1, n_cu)), block(64 * kWaves);
     double* none = nullptr;

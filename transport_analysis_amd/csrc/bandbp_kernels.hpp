@@ -37,11 +37,33 @@ namespace ta {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
     } while (0)
 
+// Work distribution of the time-packed kernels: a unit = (block of particles pb, block lag group g).  Units differ in length
+// (the band of group g is nblk - 16 g blocks long), so waves TAKE them: one counter per XCD (next_unit[0 .. 7]; workgroups are
+// dealt round-robin to the XCDs, blockIdx % 8), and XCD x takes the particle blocks x, x + 8, ...: the ~nblk/16 units of a
+// particle, which read the same rows, run at about the same time behind ONE L2.  The counters only grow: every wave leaves.
+// (Longest units first — all blocks at group 0, then group 1, ... — loses the shared rows and is 2 - 5 % slower.)
+#ifndef TA_BANDBP_XCD
+#define TA_BANDBP_XCD 1
+#endif
+constexpr int kBpCounters = 8;
+__device__ __forceinline__ bool band_take_unit(unsigned long long* next_unit, int lane, int n_groups, long n_pb, long* pb, int* g) {
+    const int n_lab = TA_BANDBP_XCD ? ((int)gridDim.x < kBpCounters ? (int)gridDim.x : kBpCounters) : 1;
+    const int x = (int)(blockIdx.x % (unsigned)n_lab);
+    unsigned long long taken = 0;
+    if (lane == 0) taken = atomicAdd(next_unit + x, 1ull);
+    const long v = (long)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(taken >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)taken));
+    const long pbl = v / n_groups;
+    *pb = x + (long)n_lab * pbl;
+    *g = (int)(v - pbl * n_groups);
+    return *pb < n_pb;
+}
+
 constexpr int kBpChunks = 8;                        // ring: chunks of 64 frames (super-step S reads chunks S ... S + 4)
 constexpr int kBpRingFrames = 64 * (kBpChunks + 1);  // + the copy of ring position 0 behind position 7
 
 // pm: pair-major float64 slab of n_atoms * D columns.  bp_am[particle * ld_am + lag] = S[lag] / (T - lag), every lag
-// < T written or added to: bp_am and *next_unit must be ZERO on entry.  grid: any number of workgroups of 64 NW threads.
+// < T written or added to: bp_am and next_unit[0 .. 7] must be ZERO on entry.  grid: any number of workgroups of 64 NW threads.
 // LAGS (lag sums alone): a unit is a block lag group of `per_unit` consecutive particles summed in the same accumulators;
 // it writes partial[(g * n_pb + block) * kBandPartial + q] = the sum for lag 256 g - 15 + q (k_bandbp_gather adds them up).
 template <int D, int NW, bool LAGS>
@@ -54,20 +76,13 @@ __global__ void __launch_bounds__(64 * NW)
     __shared__ double ringB[NW][DR][kBpRingFrames];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nblk = (T + 15) / 16, n_groups = (nblk + 15) / 16;
-    const long n_pb = LAGS ? (n_atoms + per_unit - 1) / per_unit : n_atoms, n_units = n_pb * n_groups;
+    const long n_pb = LAGS ? (n_atoms + per_unit - 1) / per_unit : n_atoms;
     double(*rB)[kBpRingFrames] = ringB[wave];
     for (;;) {
-        // units differ in length (the band of block lag 16 g is nblk - 16 g blocks long): a wave takes the next one when it
-        // is done with its own (the counter only grows: every wave leaves the loop)
-        unsigned long long taken = 0;
-        if (lane == 0) taken = atomicAdd(next_unit, 1ull);
-        const long u = (long)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(taken >> 32)) << 32) |
-                              (unsigned)__builtin_amdgcn_readfirstlane((int)taken));
-        if (u >= n_units) break;
-        // a particle's (a block of particles') units one after the other: they run at about the same time, on the same rows.
-        // (Longest units first — all blocks at block lag group 0, then group 1, ... — loses that and is 2 - 5 % slower.)
-        const long pb = __builtin_amdgcn_readfirstlane((int)(u / n_groups));
-        const int g = __builtin_amdgcn_readfirstlane((int)(u - pb * n_groups)), d0 = 16 * g;
+        long pb;
+        int g;
+        if (!band_take_unit(next_unit, lane, n_groups, n_pb, &pb, &g)) break;
+        const int d0 = 16 * g;
         const int n_super = (nblk - d0 + 3) / 4, fB = 16 * d0;
         band_d4 acc[16];
 #pragma unroll
@@ -237,7 +252,7 @@ __device__ __forceinline__ double band_first_lane(double x) {
 }
 
 // P: pair-major float64 product slab of n_atoms * D columns.  grid: any number of workgroups of 64 NW threads.
-// !LAGS: bp_am[particle * ld_am + lag] = factor * H-sum / (T - lag), lag 0 exactly 0; bp_am and *next_unit must be ZERO on entry.
+// !LAGS: bp_am[particle * ld_am + lag] = factor * H-sum / (T - lag), lag 0 exactly 0; bp_am and next_unit[0 .. 7] must be ZERO on entry.
 // LAGS (lag sums alone, results.visc_by_particle not asked for): a unit is a block lag group of `per_unit` consecutive
 // particles, whose sums stay in the same accumulators; it writes partial[(g * n_pb + block) * kBandPartial + q] = the sum for
 // lag 256 g - 15 + q over its particles (every element written; k_bandbp_gather adds them in a fixed order).
@@ -251,18 +266,13 @@ __global__ void __launch_bounds__(64 * NW)
     __shared__ double ringB[NW][NR][kBpRingFrames];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nblk = (T + 15) / 16, n_groups = (nblk + 15) / 16;
-    const long n_pb = LAGS ? (n_atoms + per_unit - 1) / per_unit : n_atoms, n_units = n_pb * n_groups;
+    const long n_pb = LAGS ? (n_atoms + per_unit - 1) / per_unit : n_atoms;
     double(*rB)[kBpRingFrames] = ringB[wave];
     for (;;) {
-        unsigned long long taken = 0;
-        if (lane == 0) taken = atomicAdd(next_unit, 1ull);
-        const long u = (long)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(taken >> 32)) << 32) |
-                              (unsigned)__builtin_amdgcn_readfirstlane((int)taken));
-        if (u >= n_units) break;
-        // a particle's (a block of particles') units one after the other: they run at about the same time, on the same rows.
-        // (Longest units first — all blocks at block lag group 0, then group 1, ... — loses that and is 2 - 5 % slower.)
-        const long pb = __builtin_amdgcn_readfirstlane((int)(u / n_groups));
-        const int g = __builtin_amdgcn_readfirstlane((int)(u - pb * n_groups)), d0 = 16 * g;
+        long pb;
+        int g;
+        if (!band_take_unit(next_unit, lane, n_groups, n_pb, &pb, &g)) break;
+        const int d0 = 16 * g;
         const int n_super = (nblk - d0 + 3) / 4, fB = 16 * d0;
         band_d4 acc[16];
         double nbacc[16], na = 0.0;
