@@ -8,7 +8,7 @@ OUT=/tmp/pmc32tp; rm -rf $OUT; mkdir -p $OUT
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32" "GRBM_GUI_ACTIVE GRBM_COUNT" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/s$i -- $BIN ttime 20000 25000 16 > $OUT/log$i.txt 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/s$i -- $BIN ttime 20000 25000 4 > $OUT/log$i.txt 2>&1
 done
 python3 - <<PY
 import csv,glob,collections
