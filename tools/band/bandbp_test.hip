@@ -131,7 +131,7 @@ static int hcheck_one(int T, long A, int D, int nwg, int kind) {
 
 // ---- float32, time-packed (band32tp_kernels.hpp) ----
 #ifndef TP_NW
-#define TP_NW 8
+#define TP_NW 12
 #endif
 template <int D, bool LAGS>
 static void launch_t(int nwg, const float* pm, long pitch, int T, long A, double* out, long ld, int per, double* partial) {

@@ -4,5 +4,5 @@
 cd "$(dirname "$0")"
 SUF=""
 if [ $# -gt 0 ] && [ "${1#-}" = "$1" ]; then SUF="_$1"; shift; fi
-/opt/rocm/bin/hipcc -O3 -std=c++20 --offload-arch=gfx950 -ffp-contract=fast -Wall -Wno-unused-function \
+/opt/rocm/bin/hipcc -O3 -std=c++20 --offload-arch=gfx950 -ffp-contract=fast -fno-slp-vectorize -Wall -Wno-unused-function \
   -Rpass-analysis=kernel-resource-usage "$@" bandbp_test.hip -o bandbp_test$SUF 2>&1 | python3 ../wfft/kres.py

@@ -9,7 +9,7 @@
 namespace ta {
 
 namespace {
-constexpr int kWaves32tp = 8;
+constexpr int kWaves32tp = 12;  // three per SIMD (168 registers: 8 / 12 waves 245 / 238 ms; the rings and flush images of 12 waves take 158 KiB of LDS)
 
 template <bool LAGS>
 hipError_t launch_tp(int n_cu, const float* P32, long pitch, int T, long n_atoms, int D, double factor, double* bp_am, long ld_am,

@@ -180,7 +180,9 @@ __global__ void __launch_bounds__(64 * NW)
                     // block lag by block lag: a window of every column and of the norms, their MFMAs, the norm add.  (Measured at
                     // 20000 x 25000 x 3, profiles/r05_band32tp_ablation.txt: reading a column's 16 windows as one batch ahead of its
                     // MFMAs 258 ms, this order 256; requesting block lag d + 1's windows before the MFMAs of d with the scheduler
-                    // fenced per block lag 309; three waves per SIMD 320 - 490, the loop then spills.)
+                    // fenced per block lag 309.  The SLP vectoriser is off for this file (csrc/Makefile): it packed the norm adds into
+                    // v_pk_add_f32 through register moves and kept their operands alive across super-steps — 256 registers and
+                    // spills; without it 215 - 223 and 245 ms, and three waves per SIMD fit without a spill in the loop: 238.)
 #pragma unroll
                     for (int d = 0; d < 16; ++d) {
                         const int w = (64 * a + 16 * d) % (64 * kBpChunks) + lane;
