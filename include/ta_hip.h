@@ -296,18 +296,20 @@ int ta_band_plan_info(int64_t n_frames, int n_cu, int *n_pieces, int *octets_in_
  *                      v_mfma_f32_16x16x4_f32 on a float32 product slab, T*A*D*4 bytes more), with or without
  *                      the by-particle array, any dim: 2.2x the float32 vector kernel; the windowed VACF stays on
  *                      the vector kernel.  Default 0 = float64.
- *   "direct_mfma" 1|0|2: ta_vacf_direct* and ta_helfand_msd* run on the matrix cores (float64: FP64,
- *                      v_mfma_f64_16x16x4_f64).  Windowed VACF (velocityautocorr.py:217-238): lag sums alone =
- *                      the diagonal sums of the frames' Gram matrix (band_kernels.hpp, 1.4x the vector
- *                      kernel); with the by-particle array the instruction's k-slots are filled from the time
- *                      axis (bandbp_kernels.hpp, 1.45x).  Helfand squared differences (viscosity.py:201-233):
- *                      products of rows centred on a nearby frame, k-slots from the time axis, with or without
- *                      the by-particle array (2.1x / 1.4x the forms before it; every lag and particle within 1e-9
- *                      of the difference-first vector kernel, pure trend included; needs T*A*D*8 bytes for the
- *                      product slab, else the vector kernel runs).  0 = the vector kernels everywhere, also
- *                      under "direct_f32".  2 = the column-packed Helfand forms of round 4 / early round 5
- *                      (band_kernels.hpp's k_band_lags<true>; band32_kernels.hpp's k_band32_lags, and
- *                      k_band32_bp at dim = 3), kept as a second implementation the tests run.
+ *   "direct_mfma" 1|0|2|3: ta_vacf_direct* and ta_helfand_msd* on the matrix cores (float64: FP64,
+ *                      v_mfma_f64_16x16x4_f64; under "direct_f32": FP32 for Helfand).  Two families exist.
+ *                      Time-packed (bandbp_kernels.hpp, band32tp_kernels.hpp): the instruction's k-slots are filled
+ *                      from the time axis, a particle's columns live in a per-wave LDS ring; with or without the
+ *                      by-particle arrays; Helfand from products of rows centred on a nearby frame (every lag and
+ *                      particle within 1e-9 of the difference-first vector kernel, pure trend included; needs
+ *                      T*A*D*8 bytes for the product slab, else the vector kernel runs).  Column-packed
+ *                      (band_kernels.hpp, band32_kernels.hpp): lag sums as diagonal sums of the frames' Gram matrix
+ *                      over column groups, no per-particle cost; by particle only k_band32_bp (float32, dim = 3).
+ *                      1 (default) = by n_frames, what is faster (the time-packed kernels fill a ring and run an
+ *                      epilogue per particle and lag group): windowed VACF lag sums time-packed from 1536 frames, by
+ *                      particle from 144 (below: vector kernel); Helfand float64 lag sums from 896, by particle always;
+ *                      float32 lag sums from 1408, by particle from 224 (below: k_band32_bp at dim = 3).
+ *                      0 = the vector kernels everywhere; 2 = column-packed wherever it exists; 3 = time-packed always.
  *   "helfand_fft" 0|1: ta_helfand_msd* evaluate the mean squared differences in O(T log T)
  *                      (n_frames <= 163840, else as default): sum (P[i]-P[i+k])^2 = S1(k) - 2 S2(k), S2 by the FFT
  *                      lag sums of the product slab P = (m v) x, S1 by prefix sums.  An

@@ -143,10 +143,10 @@ def test_vacf_direct_vs_oracle_shapes(ctx, T, A, D):
                                    (255, 7, 3), (256, 3, 3), (257, 9, 1), (271, 4, 3), (272, 4, 3), (273, 5, 2),
                                    (511, 6, 3), (513, 11, 3), (1000, 37, 3), (2049, 8, 3), (4100, 3, 3),
                                    (5000, 21, 3), (9000, 3, 1), (300, 2001, 1), (300, 2003, 3)])
-@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("form", [3, 2])
 def test_vacf_direct_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
     """Windowed VACF without the by-particle array = diagonal sums of the frames' Gram matrix, both
-    matrix-core forms: "direct_mfma" 1 (the default) k_band_bp_vacf with a unit's particles summed in its
+    matrix-core forms: "direct_mfma" 3 (the default from 1536 frames) k_band_bp_vacf with a unit's particles summed in its
     accumulators (k-slots from the time axis, bandbp_kernels.hpp), 2 the column-packed k_band_lags
     (band_kernels.hpp) — against the oracle and against the vector kernel ("direct_mfma" 0); frame counts on
     both sides of the 16-frame blocks and the 256-lag groups, odd column counts (the unpaired column's zero
@@ -159,7 +159,7 @@ def test_vacf_direct_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
     ctx.set_option("direct_mfma", form)
     try:
         ts_m, _ = run_vacf(ctx, v, False, False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_bp_vacf" if form == 1 else "k_band_lags"]
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_bp_vacf" if form == 3 else "k_band_lags"]
         ts_again, _ = ctx.vacf_direct(by_particle=False)
         assert np.array_equal(ts_m, ts_again)  # fixed summation order: the same bits every launch
         ctx.set_option("direct_mfma", 0)
@@ -187,6 +187,7 @@ def test_vacf_direct_by_particle_on_the_matrix_cores(ctx, T, A, D):
     v = orc.synthetic_velocities(T, A, D, seed=2800 + T)
     want_bp, want_ts = orc.vacf_windowed(v) if T <= 1000 else orc.vacf_fft_batched(v)
     ctx.set_option("timeline", 1)
+    ctx.set_option("direct_mfma", 3)  # (the default, 1, takes the vector kernel below 144 frames)
     try:
         ts_m, bp_m = run_vacf(ctx, v, False, True)
         assert "k_band_bp_vacf" in [n for n, _ in ctx.kernel_timeline()]
@@ -209,10 +210,10 @@ def test_vacf_direct_by_particle_on_the_matrix_cores(ctx, T, A, D):
 @pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 2, 3), (15, 3, 1), (16, 5, 3), (17, 2, 2), (241, 3, 3), (256, 3, 3),
                                    (257, 9, 1), (272, 4, 3), (273, 5, 2), (513, 11, 3), (1000, 37, 3), (2049, 8, 3),
                                    (4100, 3, 3), (5000, 7, 3), (300, 2001, 1), (300, 2001, 3)])
-@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("form", [3, 2])
 def test_helfand_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
     """Einstein-Helfand mean squared differences without the by-particle array, both matrix-core forms:
-    "direct_mfma" 1 (the default) k_band_bp_helf with a unit's particles summed in its accumulators (k-slots from
+    "direct_mfma" 3 (the default from 896 frames) k_band_bp_helf with a unit's particles summed in its accumulators (k-slots from
     the time axis), 2 the column-packed k_band_lags<helfand> (norms carried in the fourth lane group); both on
     the product slab with rows centred on a nearby frame, against the oracle (viscosity.py:201-233: difference
     first) and against the vector kernel ("direct_mfma" 0); positions with a large offset and a drift, so that P
@@ -227,7 +228,7 @@ def test_helfand_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
     ctx.set_option("direct_mfma", form)
     try:
         ts_m, _ = run_helfand(ctx, v, x, m, scale, False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_bp_helf" if form == 1 else "k_band_lags"]
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_bp_helf" if form == 3 else "k_band_lags"]
         ts_again, _ = ctx.helfand_msd(m, scale, by_particle=False)
         assert np.array_equal(ts_m, ts_again)
         ctx.set_option("direct_mfma", 0)
@@ -305,7 +306,7 @@ def test_helfand_by_particle_matrix_cores_on_a_pure_trend_and_in_other_units(ctx
         assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL, (sv, sx)
 
 
-@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("form", [3, 2])
 def test_helfand_matrix_cores_on_a_pure_trend(ctx, form):
     """The case the plain expansion S1 - 2 S2 loses (3.6e-9 on the reference's own
     step trajectory): v = t, x = t^2 / 2, so P = m t^3 / 2 grows by nine orders of magnitude while
@@ -330,10 +331,10 @@ def test_helfand_matrix_cores_on_a_pure_trend(ctx, form):
 @pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 2, 3), (15, 3, 1), (16, 5, 3), (17, 2, 2), (241, 3, 3), (256, 3, 3),
                                    (257, 9, 1), (272, 4, 3), (273, 5, 2), (513, 11, 3), (1000, 37, 3), (2049, 8, 3),
                                    (4100, 3, 3), (5000, 7, 3), (300, 2001, 1), (300, 2001, 3)])
-@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("form", [3, 2])
 def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
-    """BASELINE configs[4]'s float32 path without the by-particle array, both FP32 matrix-core forms: "direct_mfma" 1
-    (the default) k_band32_tp (band32tp_kernels.hpp: k-slots from the time axis, a unit's particles summed in its
+    """BASELINE configs[4]'s float32 path without the by-particle array, both FP32 matrix-core forms: "direct_mfma" 3
+    (the default from 1408 frames) k_band32_tp (band32tp_kernels.hpp: k-slots from the time axis, a unit's particles summed in its
     accumulators), 2 the column-packed k_band32_lags (band32_kernels.hpp: rows fetched by LDS-DMA); float32
     accumulators flushed into float64 — against the oracle (viscosity.py:201-233) at the float32 path's bar, 2e-6 of the series'
     scale, on the shapes of the float64 form's test: both sides of the 16-frame blocks and the 256-lag
@@ -350,7 +351,7 @@ def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
     ctx.set_option("direct_mfma", form)
     try:
         ts_m, _ = run_helfand(ctx, v, x, m, scale, False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp" if form == 1 else "k_band32_lags"]
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp" if form == 3 else "k_band32_lags"]
         ts_again, _ = ctx.helfand_msd(m, scale, by_particle=False)
         assert np.array_equal(ts_m, ts_again)  # fixed summation order
         ctx.set_option("direct_mfma", 0)
@@ -369,9 +370,9 @@ def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
 
 @pytest.mark.parametrize("T,A", [(1, 2), (2, 3), (16, 5), (17, 3), (63, 3), (65, 2), (239, 2), (240, 3), (241, 2), (257, 7), (449, 3),
                                  (481, 5), (513, 2), (1000, 9), (2049, 3), (4100, 2), (300, 300)])
-@pytest.mark.parametrize("form", [1, 2])
+@pytest.mark.parametrize("form", [3, 2])
 def test_helfand_float32_by_particle_on_the_matrix_cores(ctx, T, A, form):
-    """The float32 option WITH results.visc_by_particle (the class default output): "direct_mfma" 1 (the default)
+    """The float32 option WITH results.visc_by_particle (the class default output): "direct_mfma" 3 (the default from 224 frames)
     k_band32_tp (k-slots from the time axis; any dim), 2 k_band32_bp (dim = 3: a particle's x, y, z in three of the
     MFMA's four k-slots, units that own 240 lags; dim < 3 on the vector kernel) — against the oracle at 2e-6 of the
     scale, frame counts on both sides of the 16-frame blocks, the 64-frame chunks and the 240- / 256-lag units; the
@@ -387,12 +388,12 @@ def test_helfand_float32_by_particle_on_the_matrix_cores(ctx, T, A, form):
     ctx.set_option("direct_mfma", form)
     try:
         ts, bp = run_helfand(ctx, v, x, m, scale, True)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp" if form == 1 else "k_band32_bp",
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp" if form == 3 else "k_band32_bp",
                                                          "k_bp_transpose", "k_sum_partials"]
         ts2, bp2 = ctx.helfand_msd(m, scale, by_particle=True)
         assert np.array_equal(bp, bp2) and np.array_equal(ts, ts2)
         _, bp_d2 = run_helfand(ctx, v[:, :, :2], x[:, :, :2], m, scale, True)
-        assert ("k_band32_tp" if form == 1 else "k_direct") in [n for n, _ in ctx.kernel_timeline()]
+        assert ("k_band32_tp" if form == 3 else "k_direct") in [n for n, _ in ctx.kernel_timeline()]
         _, bp_d1 = run_helfand(ctx, v[:, :, 1:2], x[:, :, 1:2], m, scale, True)
     finally:
         ctx.set_option("direct_mfma", 1)
@@ -434,24 +435,27 @@ def test_helfand_float32_matrix_cores_trend_units_and_float32_slabs(ctx):
         for sv, sx in ((1e-6, 1.0), (1e5, 1e5), (1e-4, 1e-4)):
             got, _ = run_helfand(ctx, v2 * sv, x2 * sx, m2, 1.0, False)
             assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL_F32, (sv, sx)
-        # (c) float32 device slabs
+        # (c) float32 device slabs, both matrix-core forms
         v32, x32 = v2.astype(np.float32), x2.astype(np.float32)
-        want, _ = run_helfand(ctx, v32.astype(np.float64), x32.astype(np.float64), m2, 1.0, False)
-        ctx.set_option("stage_device_f32", 1)
-        try:
-            sv_, sx_ = ctx.stage_alloc(T2, A2, 3, n_slabs=2, dtype=np.float32)
-            sv_[...] = v32
-            sx_[...] = x32
-            ctx.stage_commit(0, T2)
-            ctx.set_option("timeline", 1)
-            got, _ = ctx.helfand_msd(m2, 1.0, by_particle=False)
-            assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp"]
-        finally:
-            ctx.set_option("timeline", 0)
-            ctx.set_option("stage_device_f32", 0)
-            ctx.stage_free()
-        assert np.array_equal(got, want)
+        for form, kernel in ((3, "k_band32_tp"), (2, "k_band32_lags")):
+            ctx.set_option("direct_mfma", form)
+            want, _ = run_helfand(ctx, v32.astype(np.float64), x32.astype(np.float64), m2, 1.0, False)
+            ctx.set_option("stage_device_f32", 1)
+            try:
+                sv_, sx_ = ctx.stage_alloc(T2, A2, 3, n_slabs=2, dtype=np.float32)
+                sv_[...] = v32
+                sx_[...] = x32
+                ctx.stage_commit(0, T2)
+                ctx.set_option("timeline", 1)
+                got, _ = ctx.helfand_msd(m2, 1.0, by_particle=False)
+                assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", kernel]
+            finally:
+                ctx.set_option("timeline", 0)
+                ctx.set_option("stage_device_f32", 0)
+                ctx.stage_free()
+            assert np.array_equal(got, want)
     finally:
+        ctx.set_option("direct_mfma", 1)
         ctx.set_option("direct_f32", 0)
 
 
@@ -1502,6 +1506,56 @@ def test_kernel_timeline_sums_to_the_call(ctx):
     assert scale_rel_err(ts, want_ts) < TOL and scale_rel_err(bp, want_bp) < TOL
 
 
+def test_direct_forms_by_trajectory_length(ctx):
+    """"direct_mfma" 1 (the default) picks the form by n_frames: the time-packed matrix-core kernels pay a ring fill and an
+    epilogue per particle and lag group, so short trajectories run the column-packed forms (lag sums) or the vector
+    kernel (windowed VACF by particle) — thresholds from profiles/r05_direct_forms_sweep*.txt.  Whatever is picked
+    agrees with the forced forms."""
+    from oracle import numpy_oracle as orc
+
+    def names():
+        return [n for n, _ in ctx.kernel_timeline() if n.startswith(("k_band", "k_direct"))]
+
+    ctx.set_option("timeline", 1)
+    try:
+        for T, vacf_bp, vacf_ls, helf_ls, f32_bp, f32_ls in (
+                (100, "k_direct", "k_band_lags", "k_band_lags", "k_band32_bp", "k_band32_lags"),
+                (200, "k_band_bp_vacf", "k_band_lags", "k_band_lags", "k_band32_bp", "k_band32_lags"),
+                (900, "k_band_bp_vacf", "k_band_lags", "k_band_bp_helf", "k_band32_tp", "k_band32_lags"),
+                (1600, "k_band_bp_vacf", "k_band_bp_vacf", "k_band_bp_helf", "k_band32_tp", "k_band32_tp")):
+            v, x, m, vol = orc.synthetic_helfand(T, 5, 3, seed=41 + T)
+            ts_d, bp_d = run_vacf(ctx, v, False, True)
+            assert names() == [vacf_bp], (T, names())
+            ts_l, _ = ctx.vacf_direct(by_particle=False)
+            assert names() == [vacf_ls], (T, names())
+            hs_b, hb = run_helfand(ctx, v, x, m, 1.0, True)
+            assert names() == ["k_band_bp_helf"], (T, names())
+            hs_l, _ = ctx.helfand_msd(m, 1.0, by_particle=False)
+            assert names() == [helf_ls], (T, names())
+            ctx.set_option("direct_f32", 1)
+            fs_b, fb = ctx.helfand_msd(m, 1.0, by_particle=True)
+            assert names() == [f32_bp], (T, names())
+            fs_l, _ = ctx.helfand_msd(m, 1.0, by_particle=False)
+            assert names() == [f32_ls], (T, names())
+            ctx.set_option("direct_f32", 0)
+            for form in (3, 2, 0):
+                ctx.set_option("direct_mfma", form)
+                assert scale_rel_err(ctx.helfand_msd(m, 1.0, by_particle=False)[0], hs_l) < 1e-11
+                assert scale_rel_err(ctx.helfand_msd(m, 1.0, by_particle=True)[1], hb) < 1e-11
+                ctx.set_option("direct_f32", 1)
+                assert scale_rel_err(ctx.helfand_msd(m, 1.0, by_particle=False)[0], fs_l) < TOL_F32
+                ctx.set_option("direct_f32", 0)
+                run_vacf(ctx, v, False, False)
+                assert scale_rel_err(ctx.vacf_direct(by_particle=False)[0], ts_l) < 1e-12
+                assert scale_rel_err(ctx.vacf_direct(by_particle=True)[1], bp_d) < 1e-12
+                run_helfand(ctx, v, x, m, 1.0, False)  # (both slabs back for the next round)
+            ctx.set_option("direct_mfma", 1)
+    finally:
+        ctx.set_option("direct_mfma", 1)
+        ctx.set_option("direct_f32", 0)
+        ctx.set_option("timeline", 0)
+
+
 def test_pinned_result_home(ctx):
     """The by-particle array of a host-facing call lives in ta_host_alloc memory: written through
     a caller-provided `out`, outliving the context's slabs, freed with its last view."""
@@ -1641,6 +1695,9 @@ def test_helfand_matrix_cores_do_not_depend_on_the_unit(ctx):
     base, _ = run_helfand(ctx, v, x, m, 1.0, False)
     ctx.set_option("timeline", 1)
     try:
+        ctx.set_option("direct_mfma", 3)  # the time-packed form (the default from 896 frames)
+        base3, _ = run_helfand(ctx, v, x, m, 1.0, False)
+        assert scale_rel_err(base3, base) < 1e-12
         for sv, sx in ((1e-6, 1e-6), (1e4, 1e4), (1e-3, 1.0)):
             got, _ = run_helfand(ctx, v * sv, x * sx, m, 1.0, False)
             assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_bp_helf"]

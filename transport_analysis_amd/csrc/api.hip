@@ -199,7 +199,13 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
     // kernel's staged values, float32 products, float64 accumulation.  Default: the time-packed kernel
     // (band32tp_kernels.hpp: all four k-slots do arithmetic; 259 ms per configs[4] share with or without the by-particle
     // array); "direct_mfma" 2: the column-packed forms of band32_kernels.hpp (340 ms lag sums, 393 ms by particle at dim = 3).
-    const bool tp32 = ctx->opt_direct_mfma != 2;
+    // Which matrix-core form ("direct_mfma"): 1 = by trajectory length — the time-packed kernels pay a ring fill and an epilogue
+    // per particle (block) and lag group, the column-packed ones and the vector kernels do not: below a few hundred to 1500
+    // frames those win (profiles/r05_direct_forms_sweep*.txt: equal work, 64 ... 5000 frames); 2 = column-packed wherever it
+    // exists; 3 = time-packed always; 0 = vector kernels.
+    const int mf = (int)ctx->opt_direct_mfma;
+    auto time_packed = [&](int64_t from_frames) { return mf == 3 || (mf == 1 && T >= from_frames); };
+    const bool tp32 = d_bp ? (time_packed(224) || (mf == 1 && D != 3)) : time_packed(1408);
     if (!d_bp && f32 && mode == MODE_HELFAND && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
         const int64_t n_cols = A * D;
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK &&
@@ -248,7 +254,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
     }
     // ... and the windowed VACF with its by-particle array (the class default) on the FP64 matrix cores: the k-slots
     // are filled from the time axis (bandbp_kernels.hpp)
-    if (d_bp && !f32 && !src_f32 && mode == MODE_VACF && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
+    if (d_bp && !f32 && !src_f32 && mode == MODE_VACF && (mf == 2 || time_packed(144)) && T < ((int64_t)1 << 24)) {
         const int64_t Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
         if (ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
             ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T) == TA_OK &&
@@ -293,7 +299,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
     }
     // windowed VACF lag sums alone: the by-particle kernel with a unit's particles summed in its accumulators (work handed out
     // by a counter instead of a fixed cut: 52.3 against 54.2 ms at 5000 x 50000 x 3); "direct_mfma" 2: the column-packed k_band_lags
-    if (band_ok && mode == MODE_VACF && ctx->opt_direct_mfma != 2 &&
+    if (band_ok && mode == MODE_VACF && time_packed(1536) &&
         ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
         ensure(ctx, ctx->unit_counter, 64) == TA_OK) {
         tl_mark(ctx, "k_band_bp_vacf", st);
@@ -317,15 +323,15 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         // configs[4] share).  "direct_mfma" 2 selects the column-packed form.
         const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2;
         const int n_parts = (int)std::min<int64_t>(1024, n_pairs);
-        const bool time_packed = ctx->opt_direct_mfma != 2;
+        const bool tp64 = time_packed(896);
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)) == TA_OK &&
             ensure(ctx, ctx->helf_small, sizeof(double) * (size_t)n_parts * T) == TA_OK &&
-            (!time_packed || (ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
+            (!tp64 || (ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
                               ensure(ctx, ctx->unit_counter, 64) == TA_OK))) {
             tl_mark(ctx, "k_helfand_product", st);
             TA_HIP_TRY(ctx, launch_helfand_product((const double*)d_vel, (const double*)d_pos, d_masses, pitch, T, n_cols, D,
                                                    (double*)ctx->helf_p.p, (double*)ctx->helf_small.p, n_parts, st));
-            if (time_packed) {
+            if (tp64) {
                 tl_mark(ctx, "k_band_bp_helf", st);
                 TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
                 TA_HIP_TRY(ctx, launch_band_bp_helf_lags(ctx->n_cu, (const double*)ctx->helf_p.p, pitch, (int)T, A, D, scale / (double)D,
