@@ -391,7 +391,7 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
                 "algorithmic_bytes_per_launch": bytes_algo,
                 "valu": {"achieved_tflops": tf, "peak": FP64_PEAK_TFLOPS, "frac": tf / FP64_PEAK_TFLOPS,
                          "algorithmic_flops_per_launch": fl}}
-    # direct correlators: bound by the vector FP issue rate:
+    # direct correlators: vector kernels bound by the FP issue rate, matrix-core kernels by the MFMA pipe:
     # windowed VACF 2*D*A*T(T+1)/2 flop, Helfand 3*D*A*T(T-1)/2; HBM is touched once
     fl = (2.0 * D * A * T * (T + 1) / 2) if case.mode == "direct" else (3.0 * D * A * T * (T - 1) / 2)
     peak = FP32_PEAK_TFLOPS if float32 else FP64_PEAK_TFLOPS

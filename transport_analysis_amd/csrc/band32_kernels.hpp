@@ -210,7 +210,7 @@ struct Band32Diag {
 // (A block x, window block x + d0 + 15) is issued PF steps ahead into slot (x - i0) % NS and read into
 // registers one step ahead.  Every 16 steps the reference row moves to the A block's first frame and the 15
 // older window fragments follow it.
-// (Measured, DESIGN.md 4.3.2: v_mfma_f32_16x16x4_f32 and vector instructions do NOT overlap on gfx950 any more
+// (Measured, docs/HISTORY.md "Round 5: the column-packed float32 forms": v_mfma_f32_16x16x4_f32 and vector instructions do NOT overlap on gfx950 any more
 // than the FP64 form's do — making step x + 1's operands between step x's MFMAs, one MFMA : two vector
 // instructions, took 424 ms where this form took 389 (20000 x 25000 x 3, one wave per SIMD): a vector
 // instruction costs its time wherever it stands, and with one wave per SIMD that time is its latency (the

@@ -23,7 +23,7 @@
 // sweep the same octets in the same order, their waves covering the whole band between them, so
 // an octet (T x 64 bytes) is read by one XCD only.  (Nothing paces the waves, though: measured, 90 % of
 // the L2 requests miss and are served by the Infinity Cache / HBM — 2.2 TB/s, no time lost while
-// the matrix pipe is the limit; DESIGN.md 4.3.1.)
+// the matrix pipe is the limit; DESIGN.md 4.4.)
 //
 // Output: partial[label][piece][272] (lags 16 d0 - 15 ... 16 d0 + 255 of that piece), every element
 // written; k_band_gather adds them up in a fixed order: results do not depend on scheduling.
