@@ -235,19 +235,22 @@ int wfft_max_wg_per_cu(int R0) {
 // R0 = 1 (n_frames <= 512): independent waves, 4 per workgroup; accg [4 nwg][1024]
 hipError_t launch_w1_accum(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
                            const cd* tw, double* accg) {
-    static DevFlag done[kMaxDev];
-    hipError_t e = set_lds(k_w1_accum, W1::kLds, done);
+    // n_frames <= 256: pass A's 512 bins are pad enough, pass B is skipped (wfft.hpp, w1_two_passes)
+    static DevFlag done[kMaxDev], done1[kMaxDev];
+    hipError_t e = T <= 256 ? set_lds(k_w1_accum<true>, W1::kLds, done1) : set_lds(k_w1_accum<false>, W1::kLds, done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_w1_accum, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_pairs, tw, accg);
+    if (T <= 256) hipLaunchKernelGGL(k_w1_accum<true>, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_pairs, tw, accg);
+    else hipLaunchKernelGGL(k_w1_accum<false>, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_pairs, tw, accg);
     return hipGetLastError();
 }
 
 hipError_t launch_w1_bp(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_atoms, int D,
                         const cd* tw, double* out, long ld) {
-    static DevFlag done[kMaxDev];
-    hipError_t e = set_lds(k_w1_bp, W1::kLds, done);
+    static DevFlag done[kMaxDev], done1[kMaxDev];
+    hipError_t e = T <= 256 ? set_lds(k_w1_bp<true>, W1::kLds, done1) : set_lds(k_w1_bp<false>, W1::kLds, done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_w1_bp, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_atoms, D, tw, out, ld);
+    if (T <= 256) hipLaunchKernelGGL(k_w1_bp<true>, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_atoms, D, tw, out, ld);
+    else hipLaunchKernelGGL(k_w1_bp<false>, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_atoms, D, tw, out, ld);
     return hipGetLastError();
 }
 

@@ -1516,10 +1516,23 @@ struct W1 {
     static constexpr size_t kLds = (size_t)NWV * 2 * 512 * sizeof(cd);  // two regions per wave
 };
 
+// SINGLE (n_frames <= 256): the 512 bins of pass A alone are a long enough pad (512 >= 2 n_frames - 1).  With pass A's power
+// spectrum doubled and pass B's left at zero, everything downstream — the sum over workgroups, the inverse transform with its
+// 1 / 1024 — computes (1 / 512) sum_s P_A[s] W_512^{-s n}: the same lags from half the transforms.
+template <bool SINGLE>
 __device__ __forceinline__ void w1_two_passes(cd* __restrict__ regA, cd* __restrict__ regB, int lane,
                                               const cd (&twa)[7], const cd (&twb)[7], const cd (&v)[8],
                                               const cd (&tB)[8], double (&accA)[8], double (&accB)[8]) {
     const WfSubPost w(lane);
+    if constexpr (SINGLE) {
+        cd a[8];
+#pragma unroll
+        for (int n2 = 0; n2 < 8; ++n2) a[n2] = v[n2];
+        w.stage_a(regA, a, twa);
+        w.stage_b(regA, a, twb);
+        w.stage_c(a, accA);
+        return;
+    }
     cd a[8], b[8];
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) {
@@ -1535,6 +1548,7 @@ __device__ __forceinline__ void w1_two_passes(cd* __restrict__ regA, cd* __restr
 }
 
 // lag sums: accg [gridDim.x * 4][1024], natural bin order (bin 2 s + B), one row per wave
+template <bool SINGLE>
 __global__ void __launch_bounds__(W1::NT)
     k_w1_accum(const double* __restrict__ pm, long pitch, int T, long n_pairs,
                const cd* __restrict__ tw2, double* __restrict__ accg) {
@@ -1563,18 +1577,19 @@ __global__ void __launch_bounds__(W1::NT)
         cd v[8];
 #pragma unroll
         for (int n2 = 0; n2 < 8; ++n2) v[n2] = wf_load(rs, (unsigned)lane * 16u, (unsigned)(64 * n2) * 16u);
-        w1_two_passes(regA, regB, lane, twa, twb, v, tB, accA, accB);
+        w1_two_passes<SINGLE>(regA, regB, lane, twa, twb, v, tB, accA, accB);
     }
     double* out = accg + gw * 2 * W1::M;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int sb = (lane >> 3) + 8 * (lane & 7) + 64 * c;
-        out[2 * sb] = accA[c];
-        out[2 * sb + 1] = accB[c];
+        out[2 * sb] = SINGLE ? 2.0 * accA[c] : accA[c];
+        out[2 * sb + 1] = SINGLE ? 0.0 : accB[c];
     }
 }
 
 // by-particle: a wave takes whole atoms; out[atom * ld + lag] (atom-major, as k_wbp)
+template <bool SINGLE>
 __global__ void __launch_bounds__(W1::NT)
     k_w1_bp(const double* __restrict__ pm, long pitch, int T, long n_atoms, int D,
             const cd* __restrict__ tw2, double* __restrict__ out, long ld) {
@@ -1616,12 +1631,12 @@ __global__ void __launch_bounds__(W1::NT)
                 v[n2] = wf_load(rs, (unsigned)lane * 16u, (unsigned)(64 * n2) * 16u);
                 if (kind != 2) v[n2] = cd{kind ? v[n2].y : v[n2].x, 0.0};
             }
-            w1_two_passes(regA, regB, lane, twa, twb, v, tB, accA, accB);
+            w1_two_passes<SINGLE>(regA, regB, lane, twa, twb, v, tB, accA, accB);
         }
         // lag values: transposed transform of P_A + i P_B (R0 = 1: its output IS Q in natural order)
         cd v[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = cd{accA[c], accB[c]};
+        for (int c = 0; c < 8; ++c) v[c] = SINGLE ? cd{2.0 * accA[c], 0.0} : cd{accA[c], accB[c]};
         const WfSubT wt(lane);
         wt.run(regA, v, twa, twb);
         double* o = out + atom * ld;
