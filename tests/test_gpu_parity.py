@@ -106,7 +106,9 @@ SHAPES = [(1, 1, 1), (2, 3, 3), (5, 2, 2), (16, 7, 3), (17, 4, 1), (33, 9, 2), (
           (2049, 3, 3), (2561, 4, 2), (4097, 2, 3), (5121, 2, 1), (10000, 3, 3), (10240, 2, 2),
           (30, 5, 3), (64, 3, 2), (77, 4, 3), (200, 6, 1), (400, 5, 3), (2000, 3, 3),
           # first-stage radices 7, 9, 14, 18 (odd prime-power butterflies)
-          (3500, 5, 3), (4600, 3, 2), (7000, 4, 3), (9100, 3, 1)]
+          (3500, 5, 3), (4600, 3, 2), (7000, 4, 3), (9100, 3, 1),
+          # both sides of the one-pass limit (256 frames: 512 bins are pad enough) and of the wave-local transform (512)
+          (255, 4, 3), (256, 5, 3), (256, 3, 1), (512, 3, 3), (513, 2, 3)]
 
 
 @pytest.mark.parametrize("T,A,D", SHAPES)
