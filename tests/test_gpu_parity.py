@@ -111,6 +111,19 @@ SHAPES = [(1, 1, 1), (2, 3, 3), (5, 2, 2), (16, 7, 3), (17, 4, 1), (33, 9, 2), (
           (255, 4, 3), (256, 5, 3), (256, 3, 1), (512, 3, 3), (513, 2, 3)]
 
 
+def test_vacf_fft_short_series_share_a_transform(ctx):
+    """Lag sums of short trajectories: up to 256 frames one pass of the 512-point transform, up to 128 / 64 / 32 frames
+    2 / 4 / 8 column pairs in ONE transform (autocorrelations add; the series sit 512 / PACK rows apart and do not meet at
+    lags < n_frames) — every length on both sides of the limits, pair counts that do not fill the last transform."""
+    from oracle import numpy_oracle as orc
+
+    for T in (1, 2, 3, 16, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257):
+        for A, D in ((1, 1), (3, 3), (7, 2), (33, 3), (64, 1)):
+            v = orc.synthetic_velocities(T, A, D, seed=T * 7 + A)
+            ts, _ = run_vacf(ctx, v, True, False)
+            assert scale_rel_err(ts, orc.vacf_fft_batched(v)[1]) < TOL, (T, A, D)
+
+
 @pytest.mark.parametrize("T,A,D", SHAPES)
 def test_vacf_fft_vs_oracle_shapes(ctx, T, A, D):
     """Every FFT plan size incl. ragged/odd column counts, both output modes."""

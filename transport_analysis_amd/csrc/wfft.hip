@@ -235,13 +235,20 @@ int wfft_max_wg_per_cu(int R0) {
 // R0 = 1 (n_frames <= 512): independent waves, 4 per workgroup; accg [4 nwg][1024]
 hipError_t launch_w1_accum(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_pairs,
                            const cd* tw, double* accg) {
-    // n_frames <= 256: pass A's 512 bins are pad enough, pass B is skipped (wfft.hpp, w1_two_passes)
-    static DevFlag done[kMaxDev], done1[kMaxDev];
-    hipError_t e = T <= 256 ? set_lds(k_w1_accum<true>, W1::kLds, done1) : set_lds(k_w1_accum<false>, W1::kLds, done);
-    if (e != hipSuccess) return e;
-    if (T <= 256) hipLaunchKernelGGL(k_w1_accum<true>, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_pairs, tw, accg);
-    else hipLaunchKernelGGL(k_w1_accum<false>, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_pairs, tw, accg);
-    return hipGetLastError();
+    // n_frames <= 256: pass A's 512 bins are pad enough, pass B is skipped; <= 128 / 64 / 32: 2 / 4 / 8 pairs share a transform
+    // (wfft.hpp: w1_two_passes, k_w1_accum)
+    static DevFlag done[5][kMaxDev];
+    auto go = [&](auto kern, DevFlag* flag) {
+        hipError_t e = set_lds(kern, W1::kLds, flag);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(W1::NT), W1::kLds, st, pm, pitch, T, n_pairs, tw, accg);
+        return hipGetLastError();
+    };
+    if (T <= 32) return go(k_w1_accum<true, 8>, done[4]);
+    if (T <= 64) return go(k_w1_accum<true, 4>, done[3]);
+    if (T <= 128) return go(k_w1_accum<true, 2>, done[2]);
+    if (T <= 256) return go(k_w1_accum<true, 1>, done[1]);
+    return go(k_w1_accum<false, 1>, done[0]);
 }
 
 hipError_t launch_w1_bp(int nwg, hipStream_t st, const double* pm, long pitch, int T, long n_atoms, int D,

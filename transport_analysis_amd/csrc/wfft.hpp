@@ -1548,10 +1548,14 @@ __device__ __forceinline__ void w1_two_passes(cd* __restrict__ regA, cd* __restr
 }
 
 // lag sums: accg [gridDim.x * 4][1024], natural bin order (bin 2 s + B), one row per wave
-template <bool SINGLE>
+// PACK (lag sums of short series, SINGLE only): the autocorrelations of several series ADD, and series that sit 512 / PACK
+// rows apart in one transform do not meet at lags < n_frames as long as 512 / PACK >= 2 n_frames - 1: a wave transforms
+// PACK column pairs at once — pair PACK p + q in rows 512 q / PACK ... of the 512 — 2 / 4 / 8 up to 128 / 64 / 32 frames.
+template <bool SINGLE, int PACK>
 __global__ void __launch_bounds__(W1::NT)
     k_w1_accum(const double* __restrict__ pm, long pitch, int T, long n_pairs,
                const cd* __restrict__ tw2, double* __restrict__ accg) {
+    static_assert(PACK == 1 || (SINGLE && (PACK == 2 || PACK == 4 || PACK == 8)), "packing needs the one-pass form");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cd* lds = reinterpret_cast<cd*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1571,12 +1575,17 @@ __global__ void __launch_bounds__(W1::NT)
     double accA[8], accB[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) accA[c] = accB[c] = 0.0;
-    for (long p = gw; p < n_pairs; p += nw) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<double*>(pm + p * pitch * 2), 0, T * 16, 0x00020000);
+    constexpr int kPer = 8 / PACK;  // registers (blocks of 64 rows) per packed pair
+    for (long p = gw; p * PACK < n_pairs; p += nw) {
         cd v[8];
 #pragma unroll
-        for (int n2 = 0; n2 < 8; ++n2) v[n2] = wf_load(rs, (unsigned)lane * 16u, (unsigned)(64 * n2) * 16u);
+        for (int q = 0; q < PACK; ++q) {
+            const long pair = p * PACK + q;  // (a pair past the end: an empty resource, zeros)
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<double*>(pm + (pair < n_pairs ? pair : 0) * pitch * 2), 0, pair < n_pairs ? T * 16 : 0, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) v[q * kPer + j] = wf_load(rs, (unsigned)lane * 16u, (unsigned)(64 * j) * 16u);
+        }
         w1_two_passes<SINGLE>(regA, regB, lane, twa, twb, v, tB, accA, accB);
     }
     double* out = accg + gw * 2 * W1::M;
