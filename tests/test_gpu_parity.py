@@ -121,7 +121,11 @@ def test_vacf_fft_short_series_share_a_transform(ctx):
         for A, D in ((1, 1), (3, 3), (7, 2), (33, 3), (64, 1)):
             v = orc.synthetic_velocities(T, A, D, seed=T * 7 + A)
             ts, _ = run_vacf(ctx, v, True, False)
-            assert scale_rel_err(ts, orc.vacf_fft_batched(v)[1]) < TOL, (T, A, D)
+            want_bp, want_ts = orc.vacf_fft_batched(v)
+            assert scale_rel_err(ts, want_ts) < TOL, (T, A, D)
+            # by particle: up to 128 frames the two units of a dim = 3 particle share its transform
+            ts2, bp = ctx.vacf_fft(by_particle=True)
+            assert scale_rel_err(bp, want_bp) < TOL and scale_rel_err(ts2, want_ts) < TOL, (T, A, D)
 
 
 @pytest.mark.parametrize("T,A,D", SHAPES)

@@ -1623,15 +1623,37 @@ __global__ void __launch_bounds__(W1::NT)
         double accA[8], accB[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) accA[c] = accB[c] = 0.0;
-        for (int k = 0; k < n_units; ++k) {
-            // units as in k_wbp: the atom's aligned column pair (kind 2) and/or a single column
+        // units as in k_wbp: the atom's aligned column pair (kind 2) and/or a single column
+        auto unit_of = [&](int k, long* pair, int* kind) {
             const long c0 = atom * D;
+            if (D == 2) *pair = atom, *kind = 2;
+            else if (D == 1) *pair = c0 >> 1, *kind = (int)(c0 & 1);
+            else if ((c0 & 1) == 0) *pair = (c0 >> 1) + k, *kind = k == 0 ? 2 : 0;
+            else *pair = (c0 >> 1) + k, *kind = k == 0 ? 1 : 2;
+        };
+        if (SINGLE && n_units == 2 && T <= 128) {
+            // both units of the atom in ONE transform, 256 rows apart (their autocorrelations add: k_w1_accum's packing)
+            cd v[8];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                long pair;
+                int kind;
+                unit_of(k, &pair, &kind);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<double*>(pm + pair * pitch * 2), 0, T * 16, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cd x = wf_load(rs, (unsigned)lane * 16u, (unsigned)(64 * j) * 16u);
+                    if (kind != 2) x = cd{kind ? x.y : x.x, 0.0};
+                    v[4 * k + j] = x;
+                }
+            }
+            w1_two_passes<SINGLE>(regA, regB, lane, twa, twb, v, tB, accA, accB);
+        } else
+        for (int k = 0; k < n_units; ++k) {
             long pair;
             int kind;
-            if (D == 2) pair = atom, kind = 2;
-            else if (D == 1) pair = c0 >> 1, kind = (int)(c0 & 1);
-            else if ((c0 & 1) == 0) pair = (c0 >> 1) + k, kind = k == 0 ? 2 : 0;
-            else pair = (c0 >> 1) + k, kind = k == 0 ? 1 : 2;
+            unit_of(k, &pair, &kind);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<double*>(pm + pair * pitch * 2), 0, T * 16, 0x00020000);
             cd v[8];
