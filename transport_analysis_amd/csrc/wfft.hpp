@@ -1619,10 +1619,8 @@ __global__ void __launch_bounds__(W1::NT)
 #pragma unroll
     for (int n2 = 0; n2 < 8; ++n2) tB[n2] = wf_load(twr, (unsigned)lane * 16u, (unsigned)(64 * n2) * 16u);
     const int n_units = D == 3 ? 2 : 1;
-    for (long atom = gw; atom < n_atoms; atom += nw) {
-        double accA[8], accB[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) accA[c] = accB[c] = 0.0;
+    // the power spectrum of one particle (its units' spectra added) into acc
+    auto forward = [&](long atom, double (&accA)[8], double (&accB)[8]) __attribute__((always_inline)) {
         // units as in k_wbp: the atom's aligned column pair (kind 2) and/or a single column
         auto unit_of = [&](int k, long* pair, int* kind) {
             const long c0 = atom * D;
@@ -1649,7 +1647,8 @@ __global__ void __launch_bounds__(W1::NT)
                 }
             }
             w1_two_passes<SINGLE>(regA, regB, lane, twa, twb, v, tB, accA, accB);
-        } else
+            return;
+        }
         for (int k = 0; k < n_units; ++k) {
             long pair;
             int kind;
@@ -1664,23 +1663,77 @@ __global__ void __launch_bounds__(W1::NT)
             }
             w1_two_passes<SINGLE>(regA, regB, lane, twa, twb, v, tB, accA, accB);
         }
-        // lag values: transposed transform of P_A + i P_B (R0 = 1: its output IS Q in natural order)
-        cd v[8];
+    };
+    if constexpr (SINGLE) {
+        // One pass leaves the imaginary half of the inverse transform's input free: TWO particles share it (the transform of
+        // P_a + i P_b, real spectra: Re q_a[n] = (Q[n].re + Q[-n].re) / 2, Re q_b[n] = (Q[n].im + Q[-n].im) / 2).
+        for (long ap = gw; 2 * ap < n_atoms; ap += nw) {
+            const long a0 = 2 * ap, a1 = a0 + 1;
+            double acc0[8], acc1[8], unused[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = SINGLE ? cd{2.0 * accA[c], 0.0} : cd{accA[c], accB[c]};
-        const WfSubT wt(lane);
-        wt.run(regA, v, twa, twb);
-        double* o = out + atom * ld;
+            for (int c = 0; c < 8; ++c) acc0[c] = acc1[c] = unused[c] = 0.0;
+            forward(a0, acc0, unused);
+            if (a1 < n_atoms) forward(a1, acc1, unused);
+            cd v[8];
 #pragma unroll
-        for (int n2 = 0; n2 < 8; ++n2) {
-            const int n = 64 * n2 + lane;
-            const cd q = regA[n], qm = regA[(W1::M - n) % W1::M];
-            const cd w = tB[n2];  // W_1024^n = cos - i sin
-            const double ar = 0.5 * (q.x + qm.x), br = 0.5 * (q.y + qm.y), bi = -0.5 * (q.x - qm.x);
-            const double L = ar + (w.x * br - w.y * bi);
-            if (n < T) o[n] = L / (2.0 * (double)W1::M * (double)(T - n));
+            for (int c = 0; c < 8; ++c) v[c] = cd{2.0 * acc0[c], 2.0 * acc1[c]};  // (doubled: w1_two_passes)
+            const WfSubT wt(lane);
+            wt.run(regA, v, twa, twb);
+            double* o0 = out + a0 * ld;
+            double* o1 = out + a1 * ld;
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) {
+                const int n = 64 * n2 + lane;
+                const cd q = regA[n], qm = regA[(W1::M - n) % W1::M];
+                if (n < T) {
+                    const double norm = 1.0 / (2.0 * (double)W1::M * (double)(T - n));
+                    o0[n] = 0.5 * (q.x + qm.x) * norm;
+                    if (a1 < n_atoms) o1[n] = 0.5 * (q.y + qm.y) * norm;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
+    } else {
+        for (long atom = gw; atom < n_atoms; atom += nw) {
+            double accA[8], accB[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) accA[c] = accB[c] = 0.0;
+            for (int k = 0; k < n_units; ++k) {  // (spelled out, not `forward`: the compiler then stays at two waves per SIMD)
+                const long c0 = atom * D;
+                long pair;
+                int kind;
+                if (D == 2) pair = atom, kind = 2;
+                else if (D == 1) pair = c0 >> 1, kind = (int)(c0 & 1);
+                else if ((c0 & 1) == 0) pair = (c0 >> 1) + k, kind = k == 0 ? 2 : 0;
+                else pair = (c0 >> 1) + k, kind = k == 0 ? 1 : 2;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<double*>(pm + pair * pitch * 2), 0, T * 16, 0x00020000);
+                cd v[8];
+#pragma unroll
+                for (int n2 = 0; n2 < 8; ++n2) {
+                    v[n2] = wf_load(rs, (unsigned)lane * 16u, (unsigned)(64 * n2) * 16u);
+                    if (kind != 2) v[n2] = cd{kind ? v[n2].y : v[n2].x, 0.0};
+                }
+                w1_two_passes<false>(regA, regB, lane, twa, twb, v, tB, accA, accB);
+            }
+            // lag values: transposed transform of P_A + i P_B (R0 = 1: its output IS Q in natural order)
+            cd v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = cd{accA[c], accB[c]};
+            const WfSubT wt(lane);
+            wt.run(regA, v, twa, twb);
+            double* o = out + atom * ld;
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) {
+                const int n = 64 * n2 + lane;
+                const cd q = regA[n], qm = regA[(W1::M - n) % W1::M];
+                const cd w = tB[n2];  // W_1024^n = cos - i sin
+                const double ar = 0.5 * (q.x + qm.x), br = 0.5 * (q.y + qm.y), bi = -0.5 * (q.x - qm.x);
+                const double L = ar + (w.x * br - w.y * bi);
+                if (n < T) o[n] = L / (2.0 * (double)W1::M * (double)(T - n));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
