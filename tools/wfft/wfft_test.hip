@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../transport_analysis_amd/csrc/wfft.hpp"
+#include "wfused.hpp"
 
 using namespace ta;
 #define CK(x)                                                                       \
@@ -52,6 +53,18 @@ static void fft_rec(std::vector<cl>& a) {
     }
 }
 
+__global__ void k_fill32(float* p, size_t n, unsigned long long seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned long long z = (i + seed) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        p[i] = (float)(((double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5) * 3.4641016151377544);
+    }
+}
+
 __global__ void k_fill(double* p, size_t n, unsigned long long seed) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -64,8 +77,156 @@ __global__ void k_fill(double* p, size_t n, unsigned long long seed) {
     }
 }
 
+// ---- the fused by-particle kernel (csrc/wfused.hpp) --------------------------------------------------
+//   wfft_test fcheck [T] [f32]        : 7 atoms, dim = 1, 2, 3: every atom's lags against direct sums of products
+//   wfft_test ftime <n_atoms> [T] [reps] [D] [f32] [percu]
+template <int R0>
+static int run_fused(int argc, char** argv) {
+    if constexpr (R0 % 2 != 0 || R0 < 4) {
+        fprintf(stderr, "fused: even WF_R0 >= 4 only\n");
+        return 2;
+    } else {
+        using P = WPlan<R0>;
+        const int M2 = R0 * 512;  // padded half length: the series may have up to M2 frames
+        const bool check = !strcmp(argv[1], "fcheck");
+        const int T = check ? (argc > 2 && atoi(argv[2]) > 0 ? atoi(argv[2]) : (M2 == 10240 ? 10000 : M2 - 37)) : (argc > 3 ? atoi(argv[3]) : (M2 == 10240 ? 10000 : M2 - 37));
+        const bool f32 = check ? (argc > 3 && atoi(argv[3])) : (argc > 6 && atoi(argv[6]));
+        const long pitch = (T + 7) / 8 * 8, ld = pitch;
+        hipDeviceProp_t prop;
+        CK(hipGetDeviceProperties(&prop, 0));
+        std::vector<cd> tw(wf_table_elems(R0, 1));
+        wf_fill_table(R0, 1, tw.data());
+        cd* d_tw;
+        CK(hipMalloc(&d_tw, tw.size() * sizeof(cd)));
+        CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
+        std::vector<double> rn(T);
+        wfused_fill_rnorm(R0, T, rn.data());
+        double* d_rn;
+        CK(hipMalloc(&d_rn, rn.size() * 8));
+        CK(hipMemcpy(d_rn, rn.data(), rn.size() * 8, hipMemcpyHostToDevice));
+        auto launch = [&](const void* pm, long n_atoms, int D, double* d_out, int nwg) {
+            auto go = [&](auto kern) {
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)P::kLds));
+                hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, 0, (const double*)pm, pitch, T, n_atoms, D, d_tw,
+                                   d_rn, d_out, ld);
+                CK(hipGetLastError());
+            };
+            if (f32) go(k_wfused_bp<P, true>);
+            else go(k_wfused_bp<P, false>);
+        };
+        auto per_cu = [&]() {
+            int n = 1;
+            if (f32) {
+                auto kern = k_wfused_bp<P, true>;
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, P::NT, P::kLds) != hipSuccess || n < 1) n = 1;
+            } else {
+                auto kern = k_wfused_bp<P, false>;
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, P::NT, P::kLds) != hipSuccess || n < 1) n = 1;
+            }
+            return n;
+        };
+        if (check) {
+            int bad = 0;
+            for (int D = 1; D <= 3; ++D) {
+                const long A = 7, n_cols = A * D, n_pairs = (n_cols + 1) / 2;
+                const size_t n_el = (size_t)n_pairs * pitch * 2;
+                void* d_pm;
+                double* d_out;
+                CK(hipMalloc(&d_pm, n_el * (f32 ? 4 : 8)));
+                CK(hipMalloc(&d_out, (size_t)A * ld * 8));
+                CK(hipMemset(d_out, 0xff, (size_t)A * ld * 8));
+                if (f32) hipLaunchKernelGGL(k_fill32, dim3(256), dim3(256), 0, 0, (float*)d_pm, n_el, 4242ull + D);
+                else hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, 0, (double*)d_pm, n_el, 4242ull + D);
+                CK(hipDeviceSynchronize());
+                launch(d_pm, A, D, d_out, 3);  // three workgroups: grid-stride over the groups of atoms
+                CK(hipDeviceSynchronize());
+                std::vector<double> h(n_el), o((size_t)A * ld);
+                if (f32) {
+                    std::vector<float> hf(n_el);
+                    CK(hipMemcpy(hf.data(), d_pm, n_el * 4, hipMemcpyDeviceToHost));
+                    for (size_t i = 0; i < n_el; ++i) h[i] = hf[i];
+                } else CK(hipMemcpy(h.data(), d_pm, n_el * 8, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(o.data(), d_out, o.size() * 8, hipMemcpyDeviceToHost));
+                long double mx = 0, err = 0;
+                for (long a = 0; a < A; ++a)
+                    for (int n = 0; n < T; n += (n < 40 || n > T - 40) ? 1 : std::max(1, T / 61)) {
+                        long double sref = 0;
+                        for (int d = 0; d < D; ++d) {
+                            const long c = a * D + d, p = c / 2, hf = c & 1;
+                            for (int t = 0; t + n < T; ++t)
+                                sref += (long double)h[(p * pitch + t) * 2 + hf] * h[(p * pitch + t + n) * 2 + hf];
+                        }
+                        sref /= (long double)(T - n);
+                        mx = std::max(mx, fabsl(sref));
+                        const long double e = fabsl((long double)o[a * ld + n] - sref);
+                        if (!(e <= err)) err = e;  // (NaN propagates)
+                    }
+                const bool ok = err / mx < 1e-11L;
+                printf("fused R0=%d T=%d D=%d atoms=%ld %s  max|ref|=%Lg  max err=%Lg  rel=%Lg  %s\n", R0, T, D, A,
+                       f32 ? "f32" : "f64", mx, err, err / mx, ok ? "OK" : "FAIL");
+                bad += !ok;
+                CK(hipFree(d_pm));
+                CK(hipFree(d_out));
+            }
+            return bad ? 1 : 0;
+        }
+        const long A = atol(argv[2]);
+        const int reps = argc > 4 ? atoi(argv[4]) : 5;
+        const int D = argc > 5 ? atoi(argv[5]) : 3;
+        int pc = per_cu();
+        if (argc > 7 && atoi(argv[7]) > 0) pc = std::min(pc, atoi(argv[7]));
+        const long n_groups = D & 1 ? (A + 1) / 2 : A;
+        const int nwg = (int)std::min<long>((long)prop.multiProcessorCount * pc, n_groups);
+        const long n_pairs = (A * D + 1) / 2;
+        const size_t n_el = (size_t)n_pairs * pitch * 2;
+        void* d_pm;
+        double* d_out;
+        CK(hipMalloc(&d_pm, n_el * (f32 ? 4 : 8)));
+        CK(hipMalloc(&d_out, (size_t)A * ld * 8));
+        if (f32) hipLaunchKernelGGL(k_fill32, dim3(4096), dim3(256), 0, 0, (float*)d_pm, n_el, 12345ull);
+        else hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (double*)d_pm, n_el, 12345ull);
+        CK(hipDeviceSynchronize());
+        launch(d_pm, A, D, d_out, nwg);
+        CK(hipDeviceSynchronize());
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        float best = 1e30f, sum = 0;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0, 0));
+            launch(d_pm, A, D, d_out, nwg);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms);
+            sum += ms;
+        }
+#if WFU_STAMP
+        {
+            unsigned long long z[16];
+            CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(wfu_stamps), sizeof(z)));
+            const double per = (double)A * (reps + 1);
+            const char* nm[10] = {"S1", "S1 barrier", "S2 (+row requests)", "S2 barrier", "inv: acc -> LDS + barrier", "inv: reads, barrier, sub-series", "inv: barrier", "inv: radix + Q to LDS", "inv: barrier + untangle + stores", "inv: end barrier"};
+            double tot = 0;
+            for (int i = 0; i < 10; ++i) tot += (double)z[i];
+            for (int i = 0; i < 10; ++i) printf("  cycles per atom (wave 0): %-36s %9.0f  %5.1f %%\n", nm[i], z[i] / per, 100.0 * z[i] / tot);
+            printf("  total %.0f cycles per atom\n", tot / per);
+        }
+#endif
+        printf("fused R0=%d T=%d atoms=%ld D=%d %s nwg=%d (%d per CU): best %.3f ms  mean %.3f ms = %.2f us per atom and CU  (x100000 atoms: %.2f ms)\n",
+               R0, T, A, D, f32 ? "f32" : "f64", nwg, pc, best, sum / reps, best * 1e3 * prop.multiProcessorCount / A,
+               best * 100000.0 / A);
+        return 0;
+    }
+}
+
 template <int R0>
 static int run(int R, int argc, char** argv) {
+    if (argc > 1 && (!strcmp(argv[1], "fcheck") || !strcmp(argv[1], "ftime"))) return run_fused<R0>(argc, argv);
     using P = WPlan<R0>;
     const int M = P::M, L = 2 * R * M;
     if (argc > 1 && !strcmp(argv[1], "inv")) {
@@ -273,6 +434,9 @@ int main(int argc, char** argv) {
     const char* r = getenv("WF_R0");
     const int R0 = r ? atoi(r) : 20;
     const int R = getenv("WF_R") ? atoi(getenv("WF_R")) : 1;
+#ifdef WF_ONLY_R0  // quick builds: one plan
+    if (R0 == WF_ONLY_R0) return run<WF_ONLY_R0>(R, argc, argv);
+#else
     switch (R0) {
         case 20: return run<20>(R, argc, argv);
         case 18: return run<18>(R, argc, argv);
@@ -289,6 +453,7 @@ int main(int argc, char** argv) {
         case 3: return run<3>(R, argc, argv);
         case 2: return run<2>(R, argc, argv);
     }
+#endif
     fprintf(stderr, "unsupported WF_R0\n");
     return 2;
 }
