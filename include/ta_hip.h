@@ -11,6 +11,12 @@
  *   - every call returns int: 0 = TA_OK, negative = error (TA_E_*);
  *     ta_last_error() returns a human-readable message for the last failure
  *     on that context (or on the calling thread when ctx is NULL).
+ *   - no C++ exception crosses this boundary: every entry point's body runs inside a catch-all
+ *     (ta::guard, csrc/ta_internal.hpp); std::bad_alloc comes back as TA_E_NOMEM, any other
+ *     exception as TA_E_HIP, both with a message; work already queued on behalf of the call is
+ *     drained first, so the caller may free its arrays.  (Test hooks of ta_set_option:
+ *     "fail_alloc_after" / "fail_throw_after" n make the n-th call of the library's allocation
+ *     helper throw, tests/test_gpu_parity.py::test_exception_inside_the_library_becomes_a_status.)
  *   - HOST slabs (and the frame-major d_* inputs of the *_dev calls) are the reference's
  *     layout: (n_frames, n_atoms, dim) row-major (velocityautocorr.py:150-152,
  *     viscosity.py:128-134).  The library's own DEVICE slabs are "pair-major": the staging

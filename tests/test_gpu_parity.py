@@ -1731,3 +1731,65 @@ def test_helfand_matrix_cores_do_not_depend_on_the_unit(ctx):
     finally:
         ctx.set_option("direct_mfma", 1)
         ctx.set_option("timeline", 0)
+
+
+# ------------------------------------------------------------------ the C boundary and C++ exceptions
+@pytest.mark.parametrize("hook,code", [("fail_alloc_after", -2), ("fail_throw_after", -3)])  # TA_E_NOMEM, TA_E_HIP
+@pytest.mark.parametrize("entry", ["vacf_fft", "vacf_fft_bp", "vacf_direct", "helfand"])
+def test_exception_inside_the_library_becomes_a_status(hook, code, entry):
+    """SURVEY 8(b): every call returns an int status.  A std::bad_alloc / any other exception thrown inside a
+    compute call (the allocation helper throws on request: options fail_alloc_after / fail_throw_after) comes
+    back as TA_E_NOMEM / TA_E_HIP with a message, the interpreter lives, and the context works afterwards."""
+    from oracle import numpy_oracle as orc
+    from transport_analysis_amd import _lib
+
+    c = _lib.Context(0)
+    try:
+        T, A, D = 700, 9, 3
+        v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=11)
+        sv, sx = c.stage_alloc(T, A, D, n_slabs=2)
+        sv[...] = v
+        sx[...] = x
+        c.stage_commit(0, T)
+        calls = {
+            "vacf_fft": lambda: c.vacf_fft(by_particle=False),
+            "vacf_fft_bp": lambda: c.vacf_fft(by_particle=True),
+            "vacf_direct": lambda: c.vacf_direct(by_particle=True),
+            "helfand": lambda: c.helfand_msd(m, 1.0, by_particle=True),
+        }
+        want = calls[entry]()  # (also makes every later allocation a re-use: the hook counts calls, not bytes)
+        c.set_option(hook, 1)
+        with pytest.raises(_lib.TAError) as ei:
+            calls[entry]()
+        assert ei.value.code == code
+        assert ("bad_alloc" in str(ei.value)) if code == -2 else ("fail_throw_after" in str(ei.value))
+        got = calls[entry]()  # the hook has fired once; the context is intact
+        for a, b in zip(want, got):
+            if a is not None:
+                assert np.array_equal(a, b)
+    finally:
+        c.close()
+
+
+def test_exception_inside_a_group_call_becomes_a_status():
+    from oracle import numpy_oracle as orc
+    from transport_analysis_amd import _lib
+
+    g = _lib.Group([0, 0])
+    try:
+        T, A, D = 300, 10, 3
+        v = orc.synthetic_velocities(T, A, D, seed=5)
+        (views,) = g.stage_alloc(T, A, D, n_slabs=1)
+        for view, (lo, hi) in zip(views, g.shards):
+            if view is not None:
+                view[...] = v[:, lo:hi]
+        g.stage_commit(0, T)
+        want = g.vacf_fft(by_particle=True)
+        g.member_context(1).set_option("fail_alloc_after", 1)  # the second member's next allocation-helper call throws
+        with pytest.raises(_lib.TAError) as ei:
+            g.vacf_fft(by_particle=True)
+        assert ei.value.code == -2  # TA_E_NOMEM
+        got = g.vacf_fft(by_particle=True)
+        assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
+    finally:
+        g.close()

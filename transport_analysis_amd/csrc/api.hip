@@ -10,6 +10,8 @@
 #include <deque>
 #include <map>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -88,6 +90,7 @@ struct ta_ctx {
     int64_t opt_bp_spec_atoms = 0;
     int64_t opt_bp_prefetch = 2;
     int64_t opt_stage_device_f32 = 0;
+    int64_t opt_fail_alloc_after = 0, opt_fail_throw_after = 0;  // test hooks of ensure()
     // ta_stage_commit hands its frame range to a worker thread that makes the HIP calls (copies in pieces, the
     // transposition launches): the caller's frame loop never waits on the runtime — which it did, for as long
     // as another thread's hipHostMalloc of the by-particle result held the runtime's lock (0.17 s of a 0.6 s
@@ -108,9 +111,12 @@ static void commit_stop(ta_ctx* ctx);
 
 namespace {
 
-int fail(ta_ctx* ctx, int code, const std::string& msg) {
-    if (ctx) ctx->err = msg;
-    g_tls_error = msg;
+int fail(ta_ctx* ctx, int code, const std::string& msg) noexcept {
+    try {  // (a failing copy of the message must not turn an error return into an exception)
+        if (ctx) ctx->err = msg;
+        g_tls_error = msg;
+    } catch (...) {
+    }
     return code;
 }
 
@@ -123,6 +129,10 @@ int fail(ta_ctx* ctx, int code, const std::string& msg) {
     } while (0)
 
 int ensure(ta_ctx* ctx, DevBuf& b, size_t bytes) {
+    // test hooks ("fail_alloc_after" / "fail_throw_after" n): the n-th call from now throws what a failing host allocation /
+    // any other library exception would, so that the tests can see the C boundary turn it into a status
+    if (ctx->opt_fail_alloc_after > 0 && --ctx->opt_fail_alloc_after == 0) throw std::bad_alloc();
+    if (ctx->opt_fail_throw_after > 0 && --ctx->opt_fail_throw_after == 0) throw std::runtime_error("fail_throw_after");
     if (b.bytes >= bytes && b.p) return TA_OK;
     if (b.p) {
         hipFree(b.p);
@@ -697,6 +707,7 @@ int ta_device_count(void) {
 const char* ta_last_error(const ta_ctx* ctx) { return ctx ? ctx->err.c_str() : g_tls_error.c_str(); }
 
 int ta_ctx_create(int device, ta_ctx** out) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(nullptr, c_, m_); }, [&]() -> int {
     if (!out) return fail(nullptr, TA_E_INVALID, "out is NULL");
     *out = nullptr;
     int n = 0;
@@ -725,9 +736,11 @@ int ta_ctx_create(int device, ta_ctx** out) {
     ctx->n_cu = prop.multiProcessorCount;
     *out = ctx;
     return TA_OK;
+    });
 }
 
 int ta_stage_free(ta_ctx* ctx) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     (void)commit_flush(ctx);  // (an error of a commit into slabs that are going away is dropped with them)
     hipSetDevice(ctx->device);
@@ -745,9 +758,11 @@ int ta_stage_free(ta_ctx* ctx) {
     ctx->st_nslabs = 0;
     ctx->st_T = ctx->st_A = ctx->st_pitch = 0;
     return TA_OK;
+    });
 }
 
 int ta_ctx_destroy(ta_ctx* ctx) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return TA_OK;
     (void)commit_flush(ctx);
     commit_stop(ctx);
@@ -775,9 +790,11 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return TA_OK;
+    });
 }
 
 int ta_trim(ta_ctx* ctx) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     if (int rc = commit_flush(ctx)) return rc;
     hipSetDevice(ctx->device);
@@ -793,9 +810,11 @@ int ta_trim(ta_ctx* ctx) {
             b->bytes = 0;
         }
     return TA_OK;
+    });
 }
 
 int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx || !key) return fail(ctx, TA_E_INVALID, "null argument");
     if (!strcmp(key, "fft_nwg")) ctx->opt_fft_nwg = value;
     else if (!strcmp(key, "direct_nwg")) ctx->opt_direct_nwg = value;
@@ -806,6 +825,8 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "helfand_fft")) ctx->opt_helfand_fft = value;
     else if (!strcmp(key, "bp_block")) ctx->opt_bp_block = value;
     else if (!strcmp(key, "bp_spec_atoms")) ctx->opt_bp_spec_atoms = value;
+    else if (!strcmp(key, "fail_alloc_after")) ctx->opt_fail_alloc_after = value;
+    else if (!strcmp(key, "fail_throw_after")) ctx->opt_fail_throw_after = value;
     else if (!strcmp(key, "bp_prefetch")) ctx->opt_bp_prefetch = value;
     else if (!strcmp(key, "stage_device_f32")) ctx->opt_stage_device_f32 = value;
     else if (!strcmp(key, "timeline")) ctx->opt_timeline = value;
@@ -815,9 +836,11 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     }
     else return fail(ctx, TA_E_INVALID, std::string("unknown option ") + key);
     return TA_OK;
+    });
 }
 
 int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_stages) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(nullptr, c_, m_); }, [&]() -> int {
     int R0 = 0, R = 1;
     if (!wfft_choose((long)n_frames, &R0, &R))
         return fail(nullptr, TA_E_UNSUPPORTED, "n_frames exceeds the largest FFT plan");
@@ -827,6 +850,7 @@ int ta_fft_plan_info(int64_t n_frames, int64_t* m_out, int* n_threads, int* n_st
     if (n_threads) *n_threads = wfft_threads(R0);
     if (n_stages) *n_stages = (R0 == 1 ? 3 : 4) + (R > 1 ? 1 : 0);
     return TA_OK;
+    });
 }
 
 /* --------------------------------------------- pinned host memory for results */
@@ -842,6 +866,7 @@ std::map<void*, size_t> g_host_blocks;  // base -> mapped length
 extern "C" {
 
 int ta_host_alloc_on(int device, int64_t n_bytes, void** h_out) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(nullptr, c_, m_); }, [&]() -> int {
     if (!h_out || n_bytes < 0) return fail(nullptr, TA_E_INVALID, "bad argument");
     *h_out = nullptr;
     // the allocating thread may be a fresh helper thread whose current device is 0: bind it to the
@@ -872,11 +897,13 @@ int ta_host_alloc_on(int device, int64_t n_bytes, void** h_out) {
         return fail(nullptr, TA_E_NOMEM, std::string("pinned host allocation failed: ") + hipGetErrorString(e));
     *h_out = h;
     return TA_OK;
+    });
 }
 
 int ta_host_alloc(int64_t n_bytes, void** h_out) { return ta_host_alloc_on(-1, n_bytes, h_out); }
 
 int ta_host_free(void* h) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(nullptr, c_, m_); }, [&]() -> int {
     if (!h) return TA_OK;
     size_t len = 0;
     {
@@ -891,6 +918,7 @@ int ta_host_free(void* h) {
     }
     const hipError_t e = hipHostFree(h);
     return e == hipSuccess ? TA_OK : fail(nullptr, TA_E_HIP, std::string("hipHostFree: ") + hipGetErrorString(e));
+    });
 }
 
 /* ------------------------------------------------------------------ staging */
@@ -948,12 +976,16 @@ static int stage_alloc_common(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, in
 
 int ta_stage_alloc(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, int dim, int dtype, int n_slabs,
                    void** h_slabs) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!h_slabs) return fail(ctx, TA_E_INVALID, "h_slabs is NULL");
     return stage_alloc_common(ctx, n_frames, n_atoms, dim, dtype, n_slabs, h_slabs);
+    });
 }
 
 int ta_stage_alloc_device(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, int dim, int n_slabs) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     return stage_alloc_common(ctx, n_frames, n_atoms, dim, TA_F64, n_slabs, nullptr);
+    });
 }
 
 }  // extern "C"
@@ -1032,7 +1064,9 @@ static void commit_worker(ta_ctx* ctx) {
         ctx->cq.pop_front();
         ctx->cq_busy = true;
         lk.unlock();
-        const int rc = stage_commit_now(ctx, job.first, job.second);
+        // (an exception on this thread would end the process: it becomes the queued commit's error)
+        const int rc = ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); },
+                                 [&]() -> int { return stage_commit_now(ctx, job.first, job.second); });
         lk.lock();
         if (rc && ctx->cq_rc == TA_OK) ctx->cq_rc = rc, ctx->cq_err = ctx->err;  // the first failure is the one reported
         ctx->cq_busy = false;
@@ -1070,6 +1104,7 @@ static void commit_stop(ta_ctx* ctx) {
 extern "C" {
 
 int ta_stage_commit(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     if (ctx->st_nslabs == 0) return fail(ctx, TA_E_STATE, "ta_stage_alloc has not been called");
     if (frame_lo < 0 || frame_hi > ctx->st_T || frame_lo > frame_hi)
@@ -1087,10 +1122,12 @@ int ta_stage_commit(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
     }
     ctx->cq_cv.notify_all();
     return TA_OK;
+    });
 }
 
 int ta_stage_commit_dev(ta_ctx* ctx, int slab, const void* d_src, int dtype, int64_t ld_row,
                         int64_t frame_lo, int64_t frame_hi, void* stream) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx || !d_src) return fail(ctx, TA_E_INVALID, "null argument");
     if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
     if (dtype != TA_F32 && dtype != TA_F64) return fail(ctx, TA_E_INVALID, "bad dtype");
@@ -1103,10 +1140,12 @@ int ta_stage_commit_dev(ta_ctx* ctx, int slab, const void* d_src, int dtype, int
                                     ctx->d_slabs[slab], ctx->st_dev_f32, ctx->st_pitch, frame_lo,
                                     (hipStream_t)stream));
     return TA_OK;
+    });
 }
 
 int ta_stage_synth(ta_ctx* ctx, int slab, uint64_t seed, int64_t col_offset, int64_t n_cols_total,
                    void* stream) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
     if (col_offset < 0 || col_offset + ctx->st_A * ctx->st_D > n_cols_total)
@@ -1116,9 +1155,11 @@ int ta_stage_synth(ta_ctx* ctx, int slab, uint64_t seed, int64_t col_offset, int
     TA_HIP_TRY(ctx, launch_synth(ctx->d_slabs[slab], ctx->st_dev_f32, ctx->st_pitch, ctx->st_A * ctx->st_D, ctx->st_T, seed,
                                  col_offset, n_cols_total, (hipStream_t)stream));
     return TA_OK;
+    });
 }
 
 int ta_stage_read_dev(ta_ctx* ctx, int slab, double* d_dst, int64_t ld_row, void* stream) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx || !d_dst) return fail(ctx, TA_E_INVALID, "null argument");
     if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
     if (ld_row < ctx->st_A * ctx->st_D) return fail(ctx, TA_E_INVALID, "ld_row smaller than n_atoms*dim");
@@ -1127,48 +1168,64 @@ int ta_stage_read_dev(ta_ctx* ctx, int slab, double* d_dst, int64_t ld_row, void
     TA_HIP_TRY(ctx, launch_unlayout(ctx->d_slabs[slab], ctx->st_dev_f32, ctx->st_pitch, ctx->st_A * ctx->st_D, ctx->st_T, d_dst,
                                     ld_row, (hipStream_t)stream));
     return TA_OK;
+    });
 }
 
 int ta_stage_device(ta_ctx* ctx, int slab, double** d_slab, int64_t* pitch_rows, int64_t* n_pairs) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx || !d_slab) return fail(ctx, TA_E_INVALID, "null argument");
     if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
     *d_slab = ctx->d_slabs[slab];
     if (pitch_rows) *pitch_rows = ctx->st_pitch;
     if (n_pairs) *n_pairs = (ctx->st_A * ctx->st_D + 1) / 2;
     return TA_OK;
+    });
 }
 
 /* --------------------------------------------------------- device compute */
 int ta_vacf_fft_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int D, int64_t ld_row,
                     double* d_lagsum, double* d_bp, int64_t ld_bp, void* stream) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     return dev_entry(ctx, W_FFT, d_vel, nullptr, nullptr, T, A, D, ld_row, 1.0, d_lagsum, d_bp, ld_bp, stream);
+    });
 }
 
 int ta_vacf_direct_dev(ta_ctx* ctx, const double* d_vel, int64_t T, int64_t A, int D, int64_t ld_row,
                        double* d_lagsum, double* d_bp, int64_t ld_bp, void* stream) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     return dev_entry(ctx, W_DIRECT, d_vel, nullptr, nullptr, T, A, D, ld_row, 1.0, d_lagsum, d_bp, ld_bp, stream);
+    });
 }
 
 int ta_helfand_msd_dev(ta_ctx* ctx, const double* d_vel, const double* d_pos, const double* d_masses,
                        int64_t T, int64_t A, int D, int64_t ld_row, double scale, double* d_lagsum,
                        double* d_bp, int64_t ld_bp, void* stream) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     return dev_entry(ctx, W_HELFAND, d_vel, d_pos, d_masses, T, A, D, ld_row, scale, d_lagsum, d_bp, ld_bp, stream);
+    });
 }
 
 int ta_vacf_fft_staged(ta_ctx* ctx, double* d_lagsum, double* d_bp, int64_t ld_bp, void* stream) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     return staged_entry(ctx, W_FFT, nullptr, 1.0, d_lagsum, d_bp, ld_bp, stream);
+    });
 }
 
 int ta_vacf_direct_staged(ta_ctx* ctx, double* d_lagsum, double* d_bp, int64_t ld_bp, void* stream) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     return staged_entry(ctx, W_DIRECT, nullptr, 1.0, d_lagsum, d_bp, ld_bp, stream);
+    });
 }
 
 int ta_helfand_msd_staged(ta_ctx* ctx, const double* d_masses, double scale, double* d_lagsum,
                           double* d_bp, int64_t ld_bp, void* stream) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     return staged_entry(ctx, W_HELFAND, d_masses, scale, d_lagsum, d_bp, ld_bp, stream);
+    });
 }
 
 int ta_last_timing(ta_ctx* ctx, float* total_ms, float* main_kernel_ms) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     if (!ctx->timing_valid) return fail(ctx, TA_E_STATE, "no completed compute call to time");
     TA_HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
@@ -1178,9 +1235,11 @@ int ta_last_timing(ta_ctx* ctx, float* total_ms, float* main_kernel_ms) {
     if (total_ms) *total_ms = t;
     if (main_kernel_ms) *main_kernel_ms = m;
     return TA_OK;
+    });
 }
 
 int ta_timing_history(ta_ctx* ctx, int max_n, float* total_ms, float* main_kernel_ms, int* n_out) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx || !n_out) return fail(ctx, TA_E_INVALID, "null argument");
     const long have = std::min<long>(ctx->n_calls, ta_ctx::kRing);
     const int n = (int)std::min<long>(have, std::max(0, max_n));
@@ -1195,9 +1254,11 @@ int ta_timing_history(ta_ctx* ctx, int max_n, float* total_ms, float* main_kerne
     }
     *n_out = n;
     return TA_OK;
+    });
 }
 
 int ta_clock_probe(ta_ctx* ctx, int n_launches, double* mhz, double* cycles_per_unit_pass, double* ms_per_launch) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     if (ctx->st_nslabs < 1) return fail(ctx, TA_E_STATE, "slabs have not been staged");
     if (n_launches < 1) return fail(ctx, TA_E_INVALID, "need at least one launch");
@@ -1250,9 +1311,11 @@ int ta_clock_probe(ta_ctx* ctx, int n_launches, double* mhz, double* cycles_per_
     if (cycles_per_unit_pass) *cycles_per_unit_pass = cyc / unit_passes;
     if (ms_per_launch) *ms_per_launch = ms / n_launches;
     return TA_OK;
+    });
 }
 
 int ta_kernel_timeline(ta_ctx* ctx, int max_n, const char** names, float* ms, int* n_out) {
+    return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx || !n_out) return fail(ctx, TA_E_INVALID, "null argument");
     *n_out = 0;
     if (ctx->marks.size() < 2) return TA_OK;  // option off, or no call yet
@@ -1273,6 +1336,7 @@ int ta_kernel_timeline(ta_ctx* ctx, int max_n, const char** names, float* ms, in
     }
     *n_out = n;
     return TA_OK;
+    });
 }
 
 /* ------------------------------------------------- host-facing (blocking) */
@@ -1373,6 +1437,8 @@ extern "C" {
 
 static int host_compute(ta_ctx* ctx, int which, const double* h_masses, double scale,
                         double* h_ts, double* h_bp) {
+    // (an exception after the launch: the queued kernels and copies into the caller's arrays finish before the error returns)
+    return ta::guard([&](int c_, const std::string& m_) { if (ctx) (void)host_wait(ctx); return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     if (!h_ts) return fail(ctx, TA_E_INVALID, "h_timeseries is NULL");
     double* d_total = nullptr;
@@ -1384,6 +1450,7 @@ static int host_compute(ta_ctx* ctx, int which, const double* h_masses, double s
     const double n_at = (double)ctx->st_A;  // mean over atoms (velocityautocorr.py:214,237)
     for (int64_t k = 0; k < T; ++k) h_ts[k] /= n_at;
     return TA_OK;
+    });
 }
 
 int ta_vacf_fft(ta_ctx* ctx, double* h_ts, double* h_bp) { return host_compute(ctx, W_FFT, nullptr, 1.0, h_ts, h_bp); }

@@ -118,9 +118,12 @@ struct ta_group {
 
 namespace {
 
-int gfail(ta_group* g, int code, const std::string& msg) {
-    if (g) g->err = msg;
-    g_group_tls_error = msg;
+int gfail(ta_group* g, int code, const std::string& msg) noexcept {
+    try {
+        if (g) g->err = msg;
+        g_group_tls_error = msg;
+    } catch (...) {
+    }
     return code;
 }
 #define TAG_TRY(g, expr)                                                                             \
@@ -256,7 +259,7 @@ void drain_members(ta_group* g, const std::vector<int>& who) {
     for (int i : who) (void)host_wait(g->ctx[i]);
 }
 
-int group_compute(ta_group* g, int which, const double* h_masses, double scale, double* h_ts, double* h_bp) {
+int group_compute_impl(ta_group* g, int which, const double* h_masses, double scale, double* h_ts, double* h_bp) {
     if (!g) return gfail(nullptr, TA_E_INVALID, "null group");
     if (!h_ts) return gfail(g, TA_E_INVALID, "h_timeseries is NULL");
     if (g->T == 0) return gfail(g, TA_E_STATE, "slabs have not been staged");
@@ -301,11 +304,25 @@ int group_compute(ta_group* g, int which, const double* h_masses, double scale, 
     return TA_OK;
 }
 
+// ... behind the guard of the entry points: an exception after the members' launches drains them first (the caller may
+// free its arrays as soon as the call returns)
+int group_compute(ta_group* g, int which, const double* h_masses, double scale, double* h_ts, double* h_bp) {
+    return ta::guard(
+        [&](int c_, const std::string& m_) {
+            if (g)
+                for (ta_ctx* c : g->ctx)
+                    if (c) (void)host_wait(c);
+            return gfail(g, c_, m_);
+        },
+        [&]() -> int { return group_compute_impl(g, which, h_masses, scale, h_ts, h_bp); });
+}
+
 }  // namespace
 
 extern "C" {
 
 int ta_group_create(const int* device_ids, int n_dev, ta_group** out) {
+    return ta::guard([&](int c_, const std::string& m_) { return gfail(nullptr, c_, m_); }, [&]() -> int {
     if (!out) return gfail(nullptr, TA_E_INVALID, "out is NULL");
     *out = nullptr;
     if (!device_ids || n_dev < 1 || n_dev > 64) return gfail(nullptr, TA_E_INVALID, "need 1..64 device ids");
@@ -347,9 +364,11 @@ int ta_group_create(const int* device_ids, int n_dev, ta_group** out) {
         }
     *out = g;
     return TA_OK;
+    });
 }
 
 int ta_group_destroy(ta_group* g) {
+    return ta::guard([&](int c_, const std::string& m_) { return gfail(g, c_, m_); }, [&]() -> int {
     if (!g) return TA_OK;
     for (size_t i = 0; i < g->comms.size(); ++i)
         if (g->comms[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comms[i]);
@@ -365,6 +384,7 @@ int ta_group_destroy(ta_group* g) {
     for (ta_ctx* c : g->ctx) ta_ctx_destroy(c);
     delete g;
     return TA_OK;
+    });
 }
 
 const char* ta_group_last_error(const ta_group* g) { return g ? g->err.c_str() : g_group_tls_error.c_str(); }
@@ -372,17 +392,21 @@ const char* ta_group_last_error(const ta_group* g) { return g ? g->err.c_str() :
 int ta_group_size(const ta_group* g) { return g ? (int)g->ctx.size() : 0; }
 
 int ta_group_member(ta_group* g, int i, ta_ctx** ctx, int* device) {
+    return ta::guard([&](int c_, const std::string& m_) { return gfail(g, c_, m_); }, [&]() -> int {
     if (!g || i < 0 || i >= (int)g->ctx.size()) return gfail(g, TA_E_INVALID, "no such member");
     if (ctx) *ctx = g->ctx[i];
     if (device) *device = g->devices[i];
     return TA_OK;
+    });
 }
 
 int ta_group_shard(const ta_group* g, int64_t n_atoms, int i, int64_t* atom_lo, int64_t* atom_hi) {
+    return ta::guard([&](int c_, const std::string& m_) { return gfail(const_cast<ta_group*>(g), c_, m_); }, [&]() -> int {
     if (!g || i < 0 || i >= (int)g->ctx.size() || n_atoms < 0 || !atom_lo || !atom_hi)
         return gfail(const_cast<ta_group*>(g), TA_E_INVALID, "bad argument");
     shard(n_atoms, i, (int)g->ctx.size(), atom_lo, atom_hi);
     return TA_OK;
+    });
 }
 
 const char* ta_group_reduce_kind(const ta_group* g) { return g ? g->reduce_kind.c_str() : ""; }
@@ -392,6 +416,7 @@ const char* ta_group_reduce_note(const ta_group* g) { return g ? g->reduce_note.
 int ta_group_rccl_ranks(const ta_group* g) { return g ? g->rccl_ranks : 0; }
 
 int ta_group_set_option(ta_group* g, const char* key, int64_t value) {
+    return ta::guard([&](int c_, const std::string& m_) { return gfail(g, c_, m_); }, [&]() -> int {
     if (!g || !key) return gfail(g, TA_E_INVALID, "null argument");
     // the group's own options; every other key goes to the members' contexts
     if (!strcmp(key, "reduce_mode") || !strcmp(key, "force_rccl")) {
@@ -405,10 +430,12 @@ int ta_group_set_option(ta_group* g, const char* key, int64_t value) {
         if (rc) return mfail(g, (int)i, rc);
     }
     return TA_OK;
+    });
 }
 
 int ta_group_stage_alloc(ta_group* g, int64_t n_frames, int64_t n_atoms, int dim, int dtype, int n_slabs,
                          void** h_slabs) {
+    return ta::guard([&](int c_, const std::string& m_) { return gfail(g, c_, m_); }, [&]() -> int {
     if (!g) return gfail(nullptr, TA_E_INVALID, "null group");
     if (!h_slabs) return gfail(g, TA_E_INVALID, "h_slabs is NULL");
     if (n_frames < 1 || n_atoms < 1 || dim < 1 || dim > 3 || n_slabs < 1 || n_slabs > 4)
@@ -428,9 +455,11 @@ int ta_group_stage_alloc(ta_group* g, int64_t n_frames, int64_t n_atoms, int dim
     }
     g->T = n_frames, g->A = n_atoms, g->D = dim, g->n_slabs = n_slabs;
     return TA_OK;
+    });
 }
 
 int ta_group_stage_alloc_device(ta_group* g, int64_t n_frames, int64_t n_atoms, int dim, int n_slabs) {
+    return ta::guard([&](int c_, const std::string& m_) { return gfail(g, c_, m_); }, [&]() -> int {
     if (!g) return gfail(nullptr, TA_E_INVALID, "null group");
     if (n_frames < 1 || n_atoms < 1 || dim < 1 || dim > 3 || n_slabs < 1 || n_slabs > 4)
         return gfail(g, TA_E_INVALID, "need n_frames >= 1, n_atoms >= 1, 1 <= dim <= 3, 1 <= n_slabs <= 4");
@@ -447,9 +476,11 @@ int ta_group_stage_alloc_device(ta_group* g, int64_t n_frames, int64_t n_atoms, 
     }
     g->T = n_frames, g->A = n_atoms, g->D = dim, g->n_slabs = n_slabs;
     return TA_OK;
+    });
 }
 
 int ta_group_stage_synth(ta_group* g, int slab, uint64_t seed, int64_t col_offset, int64_t n_cols_total) {
+    return ta::guard([&](int c_, const std::string& m_) { return gfail(g, c_, m_); }, [&]() -> int {
     if (!g) return gfail(nullptr, TA_E_INVALID, "null group");
     if (g->T == 0) return gfail(g, TA_E_STATE, "slabs have not been staged");
     for (size_t i = 0; i < g->ctx.size(); ++i) {  // member i: its own columns of the ONE synthetic tensor
@@ -459,9 +490,11 @@ int ta_group_stage_synth(ta_group* g, int slab, uint64_t seed, int64_t col_offse
         if (rc) return mfail(g, (int)i, rc);
     }
     return TA_OK;
+    });
 }
 
 int ta_group_stage_commit(ta_group* g, int64_t frame_lo, int64_t frame_hi) {
+    return ta::guard([&](int c_, const std::string& m_) { return gfail(g, c_, m_); }, [&]() -> int {
     if (!g) return gfail(nullptr, TA_E_INVALID, "null group");
     if (g->T == 0) return gfail(g, TA_E_STATE, "ta_group_stage_alloc has not been called");
     for (size_t i = 0; i < g->ctx.size(); ++i) {  // queued on each device's own streams: the devices overlap
@@ -470,19 +503,24 @@ int ta_group_stage_commit(ta_group* g, int64_t frame_lo, int64_t frame_hi) {
         if (rc) return mfail(g, (int)i, rc);
     }
     return TA_OK;
+    });
 }
 
 int ta_group_stage_free(ta_group* g) {
+    return ta::guard([&](int c_, const std::string& m_) { return gfail(g, c_, m_); }, [&]() -> int {
     if (!g) return gfail(nullptr, TA_E_INVALID, "null group");
     for (ta_ctx* c : g->ctx) ta_stage_free(c);
     g->T = g->A = 0;
     return TA_OK;
+    });
 }
 
 int ta_group_vacf_fft(ta_group* g, double* h_ts, double* h_bp) { return group_compute(g, 0, nullptr, 1.0, h_ts, h_bp); }
 int ta_group_vacf_direct(ta_group* g, double* h_ts, double* h_bp) { return group_compute(g, 1, nullptr, 1.0, h_ts, h_bp); }
 int ta_group_helfand_msd(ta_group* g, const double* h_masses, double scale, double* h_ts, double* h_bp) {
+    return ta::guard([&](int c_, const std::string& m_) { return gfail(g, c_, m_); }, [&]() -> int {
     return group_compute(g, 2, h_masses, scale, h_ts, h_bp);
+    });
 }
 
 }  // extern "C"

@@ -206,6 +206,7 @@ extern "C" {
 
 int ta_stage_frame(ta_ctx* ctx, int slab, int64_t frame, const void* h_src, int src_dtype, int64_t ld_row, int col0,
                    int col_step, int n_col, int64_t atom_lo, const int64_t* h_index, int64_t n_atoms) {
+    return ta::guard([&](int c_, const std::string& m_) { return ta::ctx_fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return ta::ctx_fail(nullptr, TA_E_INVALID, "null context");
     void* h = nullptr;
     int64_t T = 0, A = 0;
@@ -222,10 +223,12 @@ int ta_stage_frame(ta_ctx* ctx, int slab, int64_t frame, const void* h_src, int 
     j.dst = (char*)h + (size_t)frame * A * D * (j.dst_f32 ? 4 : 8);
     Pool::get().run(&j, 1);
     return TA_OK;
+    });
 }
 
 int ta_group_stage_frame(ta_group* g, int slab, int64_t frame, const void* h_src, int src_dtype, int64_t ld_row, int col0,
                          int col_step, int n_col, int64_t atom_lo, const int64_t* h_index, int64_t n_atoms) {
+    return ta::guard([&](int c_, const std::string& m_) { return ta::ctx_fail(nullptr, c_, m_); }, [&]() -> int {
     const int n = ta_group_size(g);
     if (n < 1) return TA_E_INVALID;
     std::vector<Job> jobs;
@@ -252,9 +255,16 @@ int ta_group_stage_frame(ta_group* g, int slab, int64_t frame, const void* h_src
     }
     if (!jobs.empty()) Pool::get().run(jobs.data(), (int)jobs.size());
     return TA_OK;
+    });
 }
 
-int ta_stage_threads(void) { return Pool::get().helpers() + 1; }
+int ta_stage_threads(void) {
+    try {  // (the first call starts the helper threads)
+        return Pool::get().helpers() + 1;
+    } catch (...) {
+        return 1;
+    }
+}
 
 }  // extern "C"
 

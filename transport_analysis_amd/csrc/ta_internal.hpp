@@ -3,14 +3,46 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
+#include "../../include/ta_hip.h"
 #include "fft_engine.hpp"
 
 struct ta_ctx;
 
 namespace ta {
+
+// No exception leaves an extern "C" function (every call returns an int status).  Every entry point's
+// body runs inside guard(report, body): std::bad_alloc becomes TA_E_NOMEM, anything else TA_E_HIP, the message goes
+// through `report(code, text)` -- the file's fail / gfail, which records it for ta_last_error and returns the code
+// (and must not throw itself: they swallow a failing string copy).
+template <class Report, class Body>
+int guard(Report&& report, Body&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try {
+            return report(TA_E_NOMEM, "out of host memory (std::bad_alloc inside the library)");
+        } catch (...) {
+            return TA_E_NOMEM;
+        }
+    } catch (const std::exception& e) {
+        try {
+            return report(TA_E_HIP, std::string("internal error: ") + e.what());
+        } catch (...) {
+            return TA_E_HIP;
+        }
+    } catch (...) {
+        try {
+            return report(TA_E_HIP, "internal error: unknown exception");
+        } catch (...) {
+            return TA_E_HIP;
+        }
+    }
+}
 
 // api.hip, for group.hip (several contexts driven by one host thread): one context's share of a
 // host-facing call queued on its streams (which: 0 FFT VACF, 1 windowed VACF, 2 Helfand), the sum
