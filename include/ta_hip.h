@@ -66,6 +66,15 @@ extern "C" {
 #define TA_F32 0
 #define TA_F64 1
 
+/* ta_ctx_create(TA_DEVICE_CPU, ...): the OPT-IN CPU backend behind the same symbols (csrc/cpu_backend.cpp, C++/OpenMP,
+ * SURVEY.md section 8(b)): host slabs only, ta_stage_alloc / ta_stage_frame / ta_stage_commit (a no-op) / ta_vacf_fft /
+ * ta_vacf_direct / ta_helfand_msd / ta_stage_synth (into the host slab) / ta_set_option ("cpu_threads") / ta_stage_free /
+ * ta_trim work as documented below and
+ * compute on the host cores; every device-facing call (ta_stage_alloc_device, *_dev, *_staged, ta_stage_commit_dev,
+ * timings, ta_group_*) returns TA_E_UNSUPPORTED.  It is never chosen on the caller's behalf: every other
+ * device index is a GPU and fails without one.                                                              */
+#define TA_DEVICE_CPU (-1)
+
 typedef struct ta_ctx ta_ctx;
 
 /* ---- context ---------------------------------------------------------- */

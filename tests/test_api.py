@@ -29,13 +29,17 @@ def g(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
-@pytest.fixture(params=["oracle-backed", pytest.param("hip", marks=pytest.mark.gpu)])
+@pytest.fixture(params=["oracle-backed", "cpu", pytest.param("hip", marks=pytest.mark.gpu)])
 def backend(request, monkeypatch):
     if request.param == "oracle-backed":
         from fake_backend import OracleContext, OracleGroup
 
         monkeypatch.setattr(_lib, "Context", OracleContext)
         monkeypatch.setattr(_lib, "Group", OracleGroup)
+    elif request.param == "cpu":
+        # the library's own opt-in CPU backend (csrc/cpu_backend.cpp) through the real C-ABI: what a user asks for with
+        # device="cpu" / $TA_AMD_DEVICE=cpu
+        monkeypatch.setenv("TA_AMD_DEVICE", "cpu")
     else:
         assert _lib.device_count() >= 1
     return request.param
@@ -353,6 +357,8 @@ def test_group_partition_matches_the_per_process_one():
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
 @pytest.mark.parametrize("fft", [True, False])
 def test_devices_one_frame_loop_column_ranges(backend, water, devices, fft):
+    if backend == "cpu":
+        pytest.skip("device groups are GPU contexts (ta_group_*: TA_E_UNSUPPORTED on the CPU backend)")
     """devices=[...]: ONE pass over the trajectory fills every member's column block, the result is
     the single-context one -- timeseries over ALL atoms, ONE (n_frames, n_particles) by-particle
     array whose column ranges the members fill.  On the GPU box the members share the one GPU
@@ -390,6 +396,8 @@ def test_devices_one_frame_loop_column_ranges(backend, water, devices, fft):
 
 
 def test_devices_more_gpus_than_atoms_and_exclusive_with_distributed(backend):
+    if backend == "cpu":
+        pytest.skip("device groups are GPU contexts")
     rng = np.random.default_rng(11)
     v = rng.standard_normal((12, 2, 3)).astype(np.float32)
     u = ArrayUniverse(velocities=v, positions=np.cumsum(v, axis=0), masses=[1.0, 2.0],

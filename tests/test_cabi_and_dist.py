@@ -21,20 +21,18 @@ def test_library_exports_header_symbols():
     assert L.ta_abi_version() == 5
 
 
-def test_no_cpu_fallback():
-    """Without a GPU the product path must fail loudly, not compute on the host."""
+def test_cpu_backend_is_opt_in():
+    """Without a GPU the default product path fails loudly; the CPU backend behind the same symbols computes only for a
+    caller who asks for it (ta_ctx_create(TA_DEVICE_CPU)) -- tests/test_cpu_backend.py has its parity set."""
     from transport_analysis_amd import _lib
 
     if _lib.device_count() > 0:
         pytest.skip("a GPU is visible")
     with pytest.raises(_lib.TAError, match="no usable HIP device"):
         _lib.Context(0)
-    from transport_analysis_amd import VelocityAutocorr
-    from transport_analysis_amd._mini_mda import ArrayUniverse
-
-    u = ArrayUniverse(velocities=np.ones((4, 2, 3)), positions=np.ones((4, 2, 3)))
-    with pytest.raises(_lib.TAError):
-        VelocityAutocorr(u.atoms).run()
+    c = _lib.Context("cpu")
+    assert c.is_cpu
+    c.close()
 
 
 def test_plan_info():

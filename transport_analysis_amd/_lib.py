@@ -293,16 +293,42 @@ class PinnedResult:
         return self._arr
 
 
+DEVICE_CPU = -1  # ta_hip.h: TA_DEVICE_CPU
+
+
+def device_index(device):
+    """A GPU index, or DEVICE_CPU for "cpu" / -1: the opt-in CPU backend behind the same C symbols
+    (csrc/cpu_backend.cpp).  Nothing picks it on the caller's behalf."""
+    if isinstance(device, str):
+        if device.strip().lower() == "cpu":
+            return DEVICE_CPU
+        return int(device)
+    return int(device)
+
+
+class _PlainHome:
+    """result_home of a CPU context: an ordinary array (there is no device to copy from)"""
+
+    def __init__(self, shape):
+        self._shape = tuple(int(x) for x in np.atleast_1d(shape))
+
+    def get(self):
+        return np.empty(self._shape, dtype=np.float64)
+
+
 class Context:
-    """One ta_ctx: owns a stream, plan tables, workspaces and the staged slabs."""
+    """One ta_ctx: owns a stream, plan tables, workspaces and the staged slabs.  `device`: a GPU index, or
+    "cpu" / DEVICE_CPU for the opt-in CPU backend (host slabs, OpenMP; the device-pointer calls are unsupported)."""
 
     def __init__(self, device=0):
         self._h = ctypes.c_void_p(None)
         L = lib()
-        rc = L.ta_ctx_create(int(device), ctypes.byref(self._h))
+        device = device_index(device)
+        rc = L.ta_ctx_create(device, ctypes.byref(self._h))
         if rc != 0:
             raise TAError(rc, L.ta_last_error(None).decode())
-        self.device = int(device)
+        self.device = device
+        self.is_cpu = device == DEVICE_CPU
         self._slabs = []
 
     # -- plumbing -------------------------------------------------------
@@ -328,6 +354,8 @@ class Context:
 
     def result_home(self, shape):
         """Start page-locking the by-particle result array of `shape`; `.get()` returns it."""
+        if getattr(self, "is_cpu", False):
+            return _PlainHome(shape)
         return PinnedResult(shape, device=self.device)
 
     # -- staging --------------------------------------------------------
@@ -413,7 +441,7 @@ class Context:
                 raise ValueError("out must be a C-contiguous float64 array of shape (n_frames, n_atoms)")
             bp = out
         elif by_particle:
-            bp = result_empty((T, A), device=self.device)
+            bp = np.empty((T, A), dtype=np.float64) if getattr(self, "is_cpu", False) else result_empty((T, A), device=self.device)
         self._check(fn(self._h, *extra, _ptr(ts), _ptr(bp)))
         return ts, bp
 

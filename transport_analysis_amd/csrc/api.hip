@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/ta_hip.h"
+#include "cpu_backend.hpp"
 #include "direct_kernels.hpp"
 #include "ta_internal.hpp"
 
@@ -34,6 +35,10 @@ struct DevBuf {
 }  // namespace
 
 struct ta_ctx {
+    // a CPU context (ta_ctx_create(TA_DEVICE_CPU, ...): the opt-in backend of cpu_backend.cpp) owns host slabs only;
+    // no HIP call is ever made on its behalf and every device-facing entry point rejects it (TA_NO_CPU)
+    bool is_cpu = false;
+    ta::cpu::State cpu;
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
@@ -119,6 +124,12 @@ int fail(ta_ctx* ctx, int code, const std::string& msg) noexcept {
     }
     return code;
 }
+
+#define TA_NO_CPU(ctx)                                                                                                   \
+    do {                                                                                                                  \
+        if ((ctx) && (ctx)->is_cpu)                                                                                       \
+            return fail(ctx, TA_E_UNSUPPORTED, "not available on the CPU backend (device pointers, streams and kernel timings belong to GPU contexts)"); \
+    } while (0)
 
 #define TA_HIP_TRY(ctx, expr)                                                                  \
     do {                                                                                       \
@@ -650,6 +661,7 @@ int relayout_input(ta_ctx* ctx, int k, const double* d_src, int64_t T, int64_t n
 int dev_entry(ta_ctx* ctx, int which, const double* d_vel, const double* d_pos, const double* d_masses,
               int64_t T, int64_t A, int D, int64_t ld_row, double scale, double* d_lagsum, double* d_bp,
               int64_t ld_bp, void* stream) {
+    TA_NO_CPU(ctx);
     int rc = check_shape(ctx, T, A, D, ld_row);
     if (rc) return rc;
     if (!d_vel || !d_lagsum || (which == W_HELFAND && (!d_pos || !d_masses)))
@@ -680,6 +692,7 @@ int order_after_staging(ta_ctx* ctx, hipStream_t st) {
 int staged_entry(ta_ctx* ctx, int which, const double* d_masses, double scale, double* d_lagsum,
                  double* d_bp, int64_t ld_bp, void* stream) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    TA_NO_CPU(ctx);
     const int need = which == W_HELFAND ? 2 : 1;
     if (ctx->st_nslabs < need) return fail(ctx, TA_E_STATE, "slabs have not been staged");
     if (!d_lagsum || (which == W_HELFAND && !d_masses)) return fail(ctx, TA_E_INVALID, "null device pointer");
@@ -710,13 +723,24 @@ int ta_ctx_create(int device, ta_ctx** out) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(nullptr, c_, m_); }, [&]() -> int {
     if (!out) return fail(nullptr, TA_E_INVALID, "out is NULL");
     *out = nullptr;
+    if (device == TA_DEVICE_CPU) {  // the opt-in CPU backend: no HIP call at all
+        if (!ta::cpu::supported()) return fail(nullptr, TA_E_UNSUPPORTED, "the CPU backend is built for hosts with AVX2 and FMA");
+        ta_ctx* c = new (std::nothrow) ta_ctx();
+        if (!c) return fail(nullptr, TA_E_NOMEM, "out of host memory");
+        c->is_cpu = true;
+        c->device = TA_DEVICE_CPU;
+        c->n_cu = 0;
+        c->cpu.threads = ta::cpu::hardware_threads();
+        *out = c;
+        return TA_OK;
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n < 1)
         return fail(nullptr, TA_E_HIP,
                     "no usable HIP device (this library has no CPU fallback): " +
                         std::string(e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
-    if (device < 0 || device >= n) return fail(nullptr, TA_E_INVALID, "device index out of range");
+    if (device < 0 || device >= n) return fail(nullptr, TA_E_INVALID, "device index out of range (TA_DEVICE_CPU = -1 asks for the CPU backend)");
     ta_ctx* ctx = new (std::nothrow) ta_ctx();
     if (!ctx) return fail(nullptr, TA_E_NOMEM, "out of host memory");
     ctx->device = device;
@@ -742,6 +766,16 @@ int ta_ctx_create(int device, ta_ctx** out) {
 int ta_stage_free(ta_ctx* ctx) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    if (ctx->is_cpu) {
+        for (auto& b : ctx->h_blocks)
+            if (b.base) host_block_unmap(b);
+        ctx->h_blocks.clear();
+        ctx->h_slabs.clear();
+        ctx->cpu.slabs.clear();
+        ctx->st_nslabs = 0;
+        ctx->st_T = ctx->st_A = ctx->st_pitch = 0;
+        return TA_OK;
+    }
     (void)commit_flush(ctx);  // (an error of a commit into slabs that are going away is dropped with them)
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
@@ -764,6 +798,11 @@ int ta_stage_free(ta_ctx* ctx) {
 int ta_ctx_destroy(ta_ctx* ctx) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return TA_OK;
+    if (ctx->is_cpu) {
+        ta_stage_free(ctx);
+        delete ctx;
+        return TA_OK;
+    }
     (void)commit_flush(ctx);
     commit_stop(ctx);
     hipSetDevice(ctx->device);
@@ -796,6 +835,7 @@ int ta_ctx_destroy(ta_ctx* ctx) {
 int ta_trim(ta_ctx* ctx) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    if (ctx->is_cpu) return TA_OK;  // (no workspaces outlive a call)
     if (int rc = commit_flush(ctx)) return rc;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
@@ -825,6 +865,10 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "helfand_fft")) ctx->opt_helfand_fft = value;
     else if (!strcmp(key, "bp_block")) ctx->opt_bp_block = value;
     else if (!strcmp(key, "bp_spec_atoms")) ctx->opt_bp_spec_atoms = value;
+    else if (!strcmp(key, "cpu_threads")) {  // CPU backend: OpenMP team size (0: the runtime's default)
+        if (value < 0 || value > 4096) return fail(ctx, TA_E_INVALID, "cpu_threads: 0 (default) .. 4096");
+        ctx->cpu.threads = value > 0 ? (int)value : ta::cpu::hardware_threads();
+    }
     else if (!strcmp(key, "fail_alloc_after")) ctx->opt_fail_alloc_after = value;
     else if (!strcmp(key, "fail_throw_after")) ctx->opt_fail_throw_after = value;
     else if (!strcmp(key, "bp_prefetch")) ctx->opt_bp_prefetch = value;
@@ -928,6 +972,31 @@ static int stage_alloc_common(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, in
     if (rc) return rc;
     if (n_slabs < 1 || n_slabs > 4) return fail(ctx, TA_E_INVALID, "bad slab count");
     if (dtype != TA_F32 && dtype != TA_F64) return fail(ctx, TA_E_INVALID, "bad dtype");
+    if (ctx->is_cpu) {
+        // host slabs in the reference's (n_frames, n_atoms, dim) layout, zero-filled mappings like the GPU contexts' (never
+        // page-locked); the CPU backend reads them where they are
+        if (!h_slabs) return fail(ctx, TA_E_UNSUPPORTED, "the CPU backend has no device slabs");
+        ta_stage_free(ctx);
+        const size_t bytes = (size_t)n_frames * n_atoms * dim * (dtype == TA_F32 ? 4 : 8);
+        for (int i = 0; i < n_slabs; ++i) {
+            HostBlock blk;
+            if (host_block_map(bytes, &blk) != 0) {
+                ta_stage_free(ctx);
+                return fail(ctx, TA_E_NOMEM, "staging allocation failed: no host memory for the slab");
+            }
+            ctx->h_slabs.push_back(blk.base);
+            ctx->h_blocks.push_back(blk);
+            ctx->cpu.slabs.push_back(blk.base);
+            h_slabs[i] = blk.base;
+        }
+        ctx->st_T = ctx->cpu.T = n_frames;
+        ctx->st_A = ctx->cpu.A = n_atoms;
+        ctx->st_D = ctx->cpu.D = dim;
+        ctx->st_dtype = ctx->cpu.dtype = dtype;
+        ctx->st_nslabs = n_slabs;
+        ctx->st_pitch = pm_pitch(n_frames);
+        return TA_OK;
+    }
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     ta_stage_free(ctx);
     const size_t n = (size_t)n_frames * n_atoms * dim;
@@ -1111,6 +1180,7 @@ int ta_stage_commit(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
         return fail(ctx, TA_E_INVALID, "frame range out of bounds");
     if (!ctx->h_slabs[0]) return fail(ctx, TA_E_STATE, "device-only slabs: use ta_stage_commit_dev");
     if (frame_hi == frame_lo) return TA_OK;
+    if (ctx->is_cpu) return TA_OK;  // the CPU backend reads the host slab in place
     if (!ctx->opt_async_commit) {
         if (int rc = commit_flush(ctx)) return rc;
         return stage_commit_now(ctx, frame_lo, frame_hi);
@@ -1129,6 +1199,7 @@ int ta_stage_commit_dev(ta_ctx* ctx, int slab, const void* d_src, int dtype, int
                         int64_t frame_lo, int64_t frame_hi, void* stream) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx || !d_src) return fail(ctx, TA_E_INVALID, "null argument");
+    TA_NO_CPU(ctx);
     if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
     if (dtype != TA_F32 && dtype != TA_F64) return fail(ctx, TA_E_INVALID, "bad dtype");
     if (frame_lo < 0 || frame_hi > ctx->st_T || frame_lo > frame_hi)
@@ -1150,6 +1221,10 @@ int ta_stage_synth(ta_ctx* ctx, int slab, uint64_t seed, int64_t col_offset, int
     if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
     if (col_offset < 0 || col_offset + ctx->st_A * ctx->st_D > n_cols_total)
         return fail(ctx, TA_E_INVALID, "column block outside the synthetic tensor");
+    if (ctx->is_cpu) {  // the same generator into the host slab
+        ta::cpu::synth(ctx->cpu, slab, seed, col_offset, n_cols_total);
+        return TA_OK;
+    }
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc_ = order_after_staging(ctx, (hipStream_t)stream)) return rc_;
     TA_HIP_TRY(ctx, launch_synth(ctx->d_slabs[slab], ctx->st_dev_f32, ctx->st_pitch, ctx->st_A * ctx->st_D, ctx->st_T, seed,
@@ -1161,6 +1236,7 @@ int ta_stage_synth(ta_ctx* ctx, int slab, uint64_t seed, int64_t col_offset, int
 int ta_stage_read_dev(ta_ctx* ctx, int slab, double* d_dst, int64_t ld_row, void* stream) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx || !d_dst) return fail(ctx, TA_E_INVALID, "null argument");
+    TA_NO_CPU(ctx);
     if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
     if (ld_row < ctx->st_A * ctx->st_D) return fail(ctx, TA_E_INVALID, "ld_row smaller than n_atoms*dim");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1174,6 +1250,7 @@ int ta_stage_read_dev(ta_ctx* ctx, int slab, double* d_dst, int64_t ld_row, void
 int ta_stage_device(ta_ctx* ctx, int slab, double** d_slab, int64_t* pitch_rows, int64_t* n_pairs) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx || !d_slab) return fail(ctx, TA_E_INVALID, "null argument");
+    TA_NO_CPU(ctx);
     if (slab < 0 || slab >= ctx->st_nslabs) return fail(ctx, TA_E_INVALID, "no such slab");
     *d_slab = ctx->d_slabs[slab];
     if (pitch_rows) *pitch_rows = ctx->st_pitch;
@@ -1227,6 +1304,7 @@ int ta_helfand_msd_staged(ta_ctx* ctx, const double* d_masses, double scale, dou
 int ta_last_timing(ta_ctx* ctx, float* total_ms, float* main_kernel_ms) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    TA_NO_CPU(ctx);
     if (!ctx->timing_valid) return fail(ctx, TA_E_STATE, "no completed compute call to time");
     TA_HIP_TRY(ctx, hipEventSynchronize(ctx->ev[3]));
     float t = 0.f, m = 0.f;
@@ -1241,6 +1319,7 @@ int ta_last_timing(ta_ctx* ctx, float* total_ms, float* main_kernel_ms) {
 int ta_timing_history(ta_ctx* ctx, int max_n, float* total_ms, float* main_kernel_ms, int* n_out) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx || !n_out) return fail(ctx, TA_E_INVALID, "null argument");
+    TA_NO_CPU(ctx);
     const long have = std::min<long>(ctx->n_calls, ta_ctx::kRing);
     const int n = (int)std::min<long>(have, std::max(0, max_n));
     for (int i = 0; i < n; ++i) {  // chronological: oldest of the last n first
@@ -1260,6 +1339,7 @@ int ta_timing_history(ta_ctx* ctx, int max_n, float* total_ms, float* main_kerne
 int ta_clock_probe(ta_ctx* ctx, int n_launches, double* mhz, double* cycles_per_unit_pass, double* ms_per_launch) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    TA_NO_CPU(ctx);
     if (ctx->st_nslabs < 1) return fail(ctx, TA_E_STATE, "slabs have not been staged");
     if (n_launches < 1) return fail(ctx, TA_E_INVALID, "need at least one launch");
     if (ctx->st_dev_f32) return fail(ctx, TA_E_UNSUPPORTED, "clock probe: float64 device slabs only");
@@ -1317,6 +1397,7 @@ int ta_clock_probe(ta_ctx* ctx, int n_launches, double* mhz, double* cycles_per_
 int ta_kernel_timeline(ta_ctx* ctx, int max_n, const char** names, float* ms, int* n_out) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx || !n_out) return fail(ctx, TA_E_INVALID, "null argument");
+    TA_NO_CPU(ctx);
     *n_out = 0;
     if (ctx->marks.size() < 2) return TA_OK;  // option off, or no call yet
     TA_HIP_TRY(ctx, hipEventSynchronize(ctx->marks.back().ev));
@@ -1352,6 +1433,7 @@ namespace ta {
 int host_launch(ta_ctx* ctx, int which, const double* h_masses, double scale, double* h_bp, int64_t ld_host,
                 double** d_total) {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
+    TA_NO_CPU(ctx);
     const int need = which == W_HELFAND ? 2 : 1;
     if (ctx->st_nslabs < need) return fail(ctx, TA_E_STATE, "slabs have not been staged");
     TA_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1441,6 +1523,18 @@ static int host_compute(ta_ctx* ctx, int which, const double* h_masses, double s
     return ta::guard([&](int c_, const std::string& m_) { if (ctx) (void)host_wait(ctx); return fail(ctx, c_, m_); }, [&]() -> int {
     if (!ctx) return fail(nullptr, TA_E_INVALID, "null context");
     if (!h_ts) return fail(ctx, TA_E_INVALID, "h_timeseries is NULL");
+    if (ctx->is_cpu) {
+        const int need = which == W_HELFAND ? 2 : 1;
+        if (ctx->st_nslabs < need) return fail(ctx, TA_E_STATE, "slabs have not been staged");
+        if (which == W_HELFAND && !h_masses) return fail(ctx, TA_E_INVALID, "h_masses is NULL");
+        const int rc = which == W_FFT      ? ta::cpu::vacf_fft(ctx->cpu, h_ts, h_bp)
+                       : which == W_DIRECT ? ta::cpu::vacf_direct(ctx->cpu, h_ts, h_bp)
+                                           : ta::cpu::helfand(ctx->cpu, h_masses, scale, h_ts, h_bp);
+        if (rc) return fail(ctx, rc, "CPU backend: out of host memory");
+        const double n_at = (double)ctx->st_A;  // mean over atoms (velocityautocorr.py:214,237; viscosity.py:233)
+        for (int64_t k = 0; k < ctx->st_T; ++k) h_ts[k] /= n_at;
+        return TA_OK;
+    }
     double* d_total = nullptr;
     int rc = host_launch(ctx, which, h_masses, scale, h_bp, ctx->st_A, &d_total);
     if (rc) return rc;

@@ -326,6 +326,8 @@ int ta_group_create(const int* device_ids, int n_dev, ta_group** out) {
     if (!out) return gfail(nullptr, TA_E_INVALID, "out is NULL");
     *out = nullptr;
     if (!device_ids || n_dev < 1 || n_dev > 64) return gfail(nullptr, TA_E_INVALID, "need 1..64 device ids");
+    for (int i = 0; i < n_dev; ++i)
+        if (device_ids[i] < 0) return gfail(nullptr, TA_E_UNSUPPORTED, "device groups are made of GPU contexts (TA_DEVICE_CPU is a context of its own)");
     ta_group* g = new (std::nothrow) ta_group();
     if (!g) return gfail(nullptr, TA_E_NOMEM, "out of host memory");
     for (int i = 0; i < n_dev; ++i) {

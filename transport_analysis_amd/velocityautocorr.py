@@ -99,7 +99,7 @@ class VelocityAutocorr(AnalysisBase):
                 device = default_device()
             else:
                 device = os.environ.get("TA_AMD_DEVICE", 0)
-        self._device = int(device)
+        self._device = _lib.device_index(device)
         super().__init__(atomgroup.universe.trajectory, **kwargs)
 
         if isinstance(atomgroup, UpdatingAtomGroup):

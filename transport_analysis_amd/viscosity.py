@@ -75,7 +75,7 @@ class ViscosityHelfand(AnalysisBase):
                 device = default_device()
             else:
                 device = os.environ.get("TA_AMD_DEVICE", 0)
-        self._device = int(device)
+        self._device = _lib.device_index(device)
         self._float32 = bool(kwargs.pop("float32", False))
         self._fft = bool(kwargs.pop("fft", False))
         if self._fft and self._float32:
