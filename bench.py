@@ -641,6 +641,94 @@ def host_path_by_particle(dev_index, T, D):
     return res
 
 
+def cpu_rehearsal(args, world, rank):
+    """TA_BENCH_CPU=1: the N-rank path of this file with every rank on the library's opt-in CPU backend
+    (ta_ctx_create(TA_DEVICE_CPU)) and gloo -- launcher, WORLD_SIZE checks, atom sharding under both scalings, the
+    all-reduce of the lag sums, max-over-ranks timing, ONE JSON line from rank 0 -- at rank counts a one-GPU box may
+    not put on its card (the driver's N = 8).  A REHEARSAL OF THE PLUMBING: its `value` is host arithmetic and is
+    labelled so; it is never the benchmark."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from transport_analysis_amd import _lib
+    from transport_analysis_amd.dist import atom_shard, reduce_lagsum
+
+    if args.mode != "fft" or args.by_particle:
+        raise SystemExit("TA_BENCH_CPU=1 rehearses --mode fft lag sums")
+    grouped = world > 1
+    if grouped:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    T, D = args.frames, args.dim
+    if args.scaling == "weak":
+        a_total = args.atoms * world
+        lo, hi = args.atoms * rank, args.atoms * (rank + 1)
+    else:
+        a_total = args.atoms
+        lo, hi = atom_shard(a_total, rank, world)
+    A = hi - lo
+    ctx = _lib.Context("cpu")
+    ctx.set_option("cpu_threads", max(1, (os.cpu_count() or 1) // max(world, 1)))
+    if A:
+        ctx.stage_alloc(T, A, D, dtype=np.float64)
+        ctx.stage_synth(0, SEED + 3, lo * D, a_total * D)
+    result = {}
+
+    def step():
+        lag = np.zeros(T)
+        if A:
+            ts, _ = ctx.vacf_fft(by_particle=False)
+            lag = ts * A  # this rank's lag SUMS
+        result["ts"] = reduce_lagsum(torch.from_numpy(lag), a_total)
+
+    for _ in range(args.warmup):
+        step()
+    if grouped:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if grouped:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [{"rank": rank, "atoms": A, "atom_range": [lo, hi]}]
+    collective = None
+    if grouped:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+        collective = {"backend": dist.get_backend(), "library": "gloo (CPU-backend rehearsal, lag sums on the host)",
+                      "ranks": dist.get_world_size(), "op": f"all_reduce(sum) of ({T},) float64 lag sums on the host",
+                      "launcher": os.environ.get("TA_BENCH_LAUNCHER", "torch.distributed.run (started by the caller)")}
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    # the reduced series against the whole tensor computed by this rank alone (small rehearsal shapes only)
+    check = None
+    if T * a_total * D <= 4_000_000:
+        ctx.stage_alloc(T, a_total, D, dtype=np.float64)
+        ctx.stage_synth(0, SEED + 3, 0, a_total * D)
+        whole, _ = ctx.vacf_fft(by_particle=False)
+        check = float(np.max(np.abs(result["ts"].numpy() - whole)) / np.max(np.abs(whole)))
+    ctx.close()
+    print(json.dumps({
+        "metric": "VACF lag-points/sec (n_frames x n_atoms / s)", "value": T * a_total / (elapsed / args.steps),
+        "unit": "lag-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "rehearsal": "TA_BENCH_CPU=1: every rank on the library's CPU backend; plumbing only, NOT a GPU measurement",
+        "config": {"workload": f"CPU-backend rehearsal of the {world}-rank path: FFT VACF timeseries, {T} frames x {a_total} atoms x {D}",
+                   "n_frames": T, "n_atoms_total": a_total, "n_atoms_this_rank": A, "dim": D, "mode": "fft", "by_particle": False,
+                   "sharding": f"atoms x{world}", "collective": collective, "per_rank": per_rank},
+        "roofline": None, "cpu_baseline": None,
+        "check": {"reduced_series_vs_one_rank_scale_rel": check}}), flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
@@ -653,6 +741,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("TA_BENCH_CPU") == "1" and not args.single_process:
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        return cpu_rehearsal(args, world, rank)
     if args.single_process:
         if world > 1:
             raise SystemExit("--single-process drives the GPUs itself: do not launch it under torchrun")

@@ -272,3 +272,37 @@ def test_bench_bare_gpus_n_is_its_own_launcher():
     assert res.returncode != 0
     assert "bench.py needs a GPU" in res.stderr and "torch.distributed.run" not in res.stdout
     assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("scaling,atoms,total", [("weak", 3, 24), ("strong", 29, 29), ("strong", 5, 5)])
+def test_bench_eight_ranks_rehearsal_on_the_cpu_backend(scaling, atoms, total):
+    """The driver's N = 8 command shape (`python bench.py --gpus 8`, which starts torch.distributed.run itself) with
+    every rank on the library's opt-in CPU backend (TA_BENCH_CPU=1, gloo): rank-count plumbing, atom_shard
+    remainders (29 atoms over 8 ranks; 5 atoms: three ranks hold none), config.collective.ranks == 8, ONE JSON line
+    from rank 0, rc 0, and the reduced series equal to the whole tensor's.  A one-GPU box may not carry eight ranks
+    on its card; the GPU-side rehearsals (tests/test_gpu_dist.py) stop at four."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(TA_BENCH_CPU="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--frames", "300", "--atoms", str(atoms), "--scaling", scaling]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == scaling and d["config"]["n_atoms_total"] == total
+    assert d["config"]["collective"]["ranks"] == 8 and d["config"]["sharding"] == "atoms x8"
+    assert d["value"] == pytest.approx(300 * total / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    ranges = [tuple(r["atom_range"]) for r in sorted(d["config"]["per_rank"], key=lambda r: r["rank"])]
+    assert ranges[0][0] == 0 and ranges[-1][1] == total and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    if scaling == "strong":
+        from transport_analysis_amd.dist import atom_shard
+
+        assert ranges == [atom_shard(total, r, 8) for r in range(8)]
+    assert d["check"]["reduced_series_vs_one_rank_scale_rel"] < 1e-12
+    assert "bench.py started" in d["config"]["collective"]["launcher"]

@@ -438,3 +438,70 @@ def test_bench_single_process_line_is_complete():
     assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9)
     assert d["config"]["collective"]["kind"] == "peer-copy" and d["config"]["collective"]["members"] == 2
     assert d["cpu_baseline"]["value"] > 0 and d["check"]["lag0_vs_numpy_block_mean_square"]
+
+
+@pytest.mark.parametrize("A", [37, 5])
+def test_group_of_eight_members_on_one_device(A):
+    """The in-library fan-out at the member count of the driver's node, on what a one-GPU box can run: EIGHT members
+    that share device 0 (peer-copy reduce in member order).  device_ranges = atom_shard over 8 (A = 5: three members
+    hold no atom), the by-particle column ranges tile the array, and the lag sums equal the single context's to
+    rounding (the sum is re-associated across members) -- and bit for bit from call to call."""
+    from transport_analysis_amd import _lib
+    from transport_analysis_amd.dist import atom_shard
+
+    rng = np.random.default_rng(8)
+    T, D = 1100, 3
+    v = rng.standard_normal((T, A, D))
+    c = _lib.Context(0)
+    g = _lib.Group([0] * 8)
+    try:
+        (slab,) = c.stage_alloc(T, A, D, n_slabs=1, dtype=np.float64)
+        slab[...] = v
+        c.stage_commit(0, T)
+        ts0, bp0 = c.vacf_fft(by_particle=True)
+        (views,) = g.stage_alloc(T, A, D, n_slabs=1, dtype=np.float64)
+        assert g.shards == [atom_shard(A, i, 8) for i in range(8)]
+        for view, (lo, hi) in zip(views, g.shards):
+            assert (view is None) == (hi == lo)
+            if view is not None:
+                view[...] = v[:, lo:hi]
+        g.stage_commit(0, T)
+        ts1, bp1 = g.vacf_fft(by_particle=True)
+        assert g.reduce_kind == "peer-copy"
+        # (a member's block starts on its own column-pair boundary: which columns share a complex transform differs from
+        # the single context's, hence rounding-level differences per particle too)
+        assert scale_rel_err(bp1, bp0) < 1e-13
+        assert scale_rel_err(ts1, ts0) < 1e-14
+        ts2, bp2 = g.vacf_fft(by_particle=True)
+        assert np.array_equal(ts1, ts2) and np.array_equal(bp1, bp2)
+        d1, _ = g.vacf_direct(by_particle=False)
+        d0, _ = c.vacf_direct(by_particle=False)
+        assert scale_rel_err(d1, d0) < 1e-13
+    finally:
+        g.close()
+        c.close()
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_four_ranks_rehearsal_on_one_gpu(scaling):
+    """bench.py's N > 1 path with FOUR ranks on this box's one GPU (TA_BENCH_ONE_GPU=1; a box allows six processes
+    on its card, this test's own included): atom counts that do not divide (strong: 3001 over 4), one JSON line."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["TA_BENCH_ONE_GPU"] = "1"
+    atoms = 1500 if scaling == "weak" else 3001
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+           "--frames", "2000", "--atoms", str(atoms), "--scaling", scaling, "--cpu-sample-atoms", "100"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    total = 6000 if scaling == "weak" else 3001
+    assert d["n_gpus"] == 4 and d["config"]["n_atoms_total"] == total and d["config"]["collective"]["ranks"] == 4
+    assert sum(r["atoms"] for r in d["roofline"]["per_rank"]) == total and len(d["config"]["rank_devices"]) == 4
+    assert d["value"] == pytest.approx(2000 * total / (d["ms_per_step"] * 1e-3), rel=1e-9)
