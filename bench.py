@@ -889,6 +889,8 @@ def main():
     key = (f"{args.mode}_{T}x{A}x{D}" + ("_bp" if args.by_particle else "") + ("_hfft" if args.helfand_fft else "")
            + ("_f32" if args.float32 else "") + ("_slab32" if args.slab32 else ""))
     roof["traffic"] = recorded_traffic(key)
+    used_ms = total_ms if composite else kernel_ms
+    roof["frac_kernel"], roof["frac_call"] = roof["frac"] * used_ms / kernel_ms, roof["frac"] * used_ms / total_ms
     if world > 1:
         # N > 1: `achieved` is the SLOWEST rank's rate (its own bytes over its own kernel time); the reduce is apart
         rates = []
@@ -980,9 +982,16 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, T, D, a_total * D, seconds=12.0 if world == 1 else 4.0)
     if "other_configs" in out:
         # LAST key of the line (a log that keeps only the tail of stdout still has every config's figures)
-        out["summary"] = [{"workload": "headline: " + workload, "ms": round(ms_per_step, 4), "frac": round(roof["frac"], 4),
-                           "bound": roof["bound"]}] + [
+        # per row: `frac_kernel` = the path's algorithmic bytes (flops) over its dominant kernel alone, `frac_call` = over the
+        # whole call (every launch of the path); `frac` is the one the row's roofline object is quoted with
+        head = {"workload": "headline: " + workload, "ms": round(ms_per_step, 4), "frac": round(roof["frac"], 4),
+                "frac_kernel": round(roof["frac_kernel"], 4), "frac_call": round(roof["frac_call"], 4), "bound": roof["bound"],
+                "input": "the library's pair-major device slab"}
+        if isinstance(out.get("staging"), dict) and "vacf_fft_dev_ms" in out["staging"]:
+            head["ms_from_frame_major_input"] = round(out["staging"]["vacf_fft_dev_ms"], 4)  # the reference's (T, A, D) layout on the device: + k_relayout
+        out["summary"] = [head] + [
             {"workload": c["workload"], "ms": round(c["ms_per_step"], 4), "frac": round(c["roofline"]["frac"], 4),
+             "frac_kernel": round(c["roofline"]["frac_kernel"], 4), "frac_call": round(c["roofline"]["frac_call"], 4),
              "bound": c["roofline"]["bound"]} if "error" not in c else {"workload": c["workload"], "error": c["error"][:80]}
             for c in out["other_configs"]]
     line = json.dumps(out)
@@ -1041,6 +1050,9 @@ def other_configs(torch, dist, _lib, ctx, dev):
             r["traffic"] = recorded_traffic(f"{mode}_{T}x{A}x3" + ("_bp" if byp else "") + ("_hfft" if hfft else "")
                                             + ("_f32" if f32 else "") + ("_slab32" if slab32 else ""))
             r["kernels"] = kernel_split(ctx, c, torch)
+            # the same bytes / flops over the dominant kernel alone and over the whole call (every launch of the path)
+            used = tms if composite else kms
+            r["frac_kernel"], r["frac_call"] = r["frac"] * used / kms, r["frac"] * used / tms
             res.append({"workload": name, "ms_per_step": el / steps * 1e3, "steps": steps,
                         "value": T * A / (el / steps), "unit": "lag-points/s",
                         "device_ms": {"whole_call_median": tms, "dominant_kernel_median": kms}, "roofline": r})

@@ -296,13 +296,6 @@ int ta_clock_probe(ta_ctx *ctx, int n_launches, double *mhz, double *cycles_per_
  * Beyond that ta_vacf_fft* compute the same quantity with the direct correlator and this
  * call returns TA_E_UNSUPPORTED.                                              */
 int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_stages);
-/* Host only: how the matrix-core lag-sum kernels ("direct_mfma", band_kernels.hpp) cut their work for
- * n_frames on a device of n_cu compute units: time in blocks of 16 frames, block lags in groups of 16,
- * group g a band of ceil(n_frames/16) - 16 g steps per group of columns; the band is cut into equal
- * shares for 256 wave slots per XCD, *octets_in_flight column groups at a time.  The call verifies
- * that every step belongs to exactly one piece and every piece to exactly one wave
- * (TA_E_UNSUPPORTED otherwise: a bug); *max_over_mean: the busiest wave's share over the average.  */
-int ta_band_plan_info(int64_t n_frames, int n_cu, int *n_pieces, int *octets_in_flight, double *max_over_mean);
 /* options (key, value):
  *   "direct_f32" 0|1 : direct correlators (ta_vacf_direct*, ta_helfand_msd*) round the staged values (Helfand:
  *                      P = (m v) x, formed in float64) ONCE to float32, form products / squared differences
@@ -311,20 +304,18 @@ int ta_band_plan_info(int64_t n_frames, int n_cu, int *n_pieces, int *octets_in_
  *                      v_mfma_f32_16x16x4_f32 on a float32 product slab, T*A*D*4 bytes more), with or without
  *                      the by-particle array, any dim: 2.2x the float32 vector kernel; the windowed VACF stays on
  *                      the vector kernel.  Default 0 = float64.
- *   "direct_mfma" 1|0|2|3: ta_vacf_direct* and ta_helfand_msd* on the matrix cores (float64: FP64,
- *                      v_mfma_f64_16x16x4_f64; under "direct_f32": FP32 for Helfand).  Two families exist.
- *                      Time-packed (bandbp_kernels.hpp, band32tp_kernels.hpp): the instruction's k-slots are filled
- *                      from the time axis, a particle's columns live in a per-wave LDS ring; with or without the
- *                      by-particle arrays; Helfand from products of rows centred on a nearby frame (every lag and
- *                      particle within 1e-9 of the difference-first vector kernel, pure trend included; needs
- *                      T*A*D*8 bytes for the product slab, else the vector kernel runs).  Column-packed
- *                      (band_kernels.hpp, band32_kernels.hpp): lag sums as diagonal sums of the frames' Gram matrix
- *                      over column groups, no per-particle cost; by particle only k_band32_bp (float32, dim = 3).
- *                      1 (default) = by n_frames, what is faster (the time-packed kernels fill a ring and run an
- *                      epilogue per particle and lag group): windowed VACF lag sums time-packed from 1536 frames, by
- *                      particle from 144 (below: vector kernel); Helfand float64 lag sums from 896, by particle always;
- *                      float32 lag sums from 1408, by particle from 224 (below: k_band32_bp at dim = 3).
- *                      0 = the vector kernels everywhere; 2 = column-packed wherever it exists; 3 = time-packed always.
+ *   "direct_mfma" 1|0|3: ta_vacf_direct* and ta_helfand_msd* on the matrix cores (float64: FP64,
+ *                      v_mfma_f64_16x16x4_f64; under "direct_f32": FP32 for Helfand) -- bandbp_kernels.hpp,
+ *                      band32tp_kernels.hpp: the instruction's k-slots are filled from the time axis, a particle's
+ *                      columns live in a per-wave LDS ring; with or without the by-particle arrays; Helfand from
+ *                      products of rows centred on a nearby frame (every lag and particle within 1e-9 of the
+ *                      difference-first vector kernel, pure trend included; needs T*A*D*8 (float32: *4) bytes for
+ *                      the product slab, else the vector kernel runs).
+ *                      1 (default) = by n_frames (these kernels fill a ring and run an epilogue per particle and lag
+ *                      group): windowed VACF lag sums from 112 frames, by particle from 144 (below: vector kernel);
+ *                      every Helfand form always.  0 = the vector kernels everywhere; 3 = matrix cores always.
+ *                      (2, the column-packed forms of rounds 4-5 with their inline-assembly LDS-DMA, is rejected
+ *                      since round 6: those kernels are tools/band/, built on demand as a second opinion.)
  *   "helfand_fft" 0|1: ta_helfand_msd* evaluate the mean squared differences in O(T log T)
  *                      (n_frames <= 163840, else as default): sum (P[i]-P[i+k])^2 = S1(k) - 2 S2(k), S2 by the FFT
  *                      lag sums of the product slab P = (m v) x, S1 by prefix sums.  An

@@ -157,7 +157,7 @@ def main(n_cases, seed=1234):
         ctx.set_option("direct_nwg", int(rng.choice([0, 0, 1, 2, 5])))
         f32 = int(kind in ("direct", "helfand") and rng.random() < 0.3)
         ctx.set_option("direct_f32", f32)
-        ctx.set_option("direct_mfma", int(rng.choice([1, 3, 3, 2, 0])))  # by length / time-packed / column-packed matrix-core forms, vector kernels
+        ctx.set_option("direct_mfma", int(rng.choice([1, 3, 3, 0])))  # by length / matrix cores always / vector kernels
         hfft = int(kind == "helfand" and not f32 and rng.random() < 0.4)
         ctx.set_option("helfand_fft", hfft)  # S1 - 2 S2 through the FFT lag-sum path
         lag = torch.full((T,), -3.0, dtype=torch.float64, device="cuda")

@@ -18,7 +18,7 @@ def test_library_exports_header_symbols():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ta_abi_version() == 5
+    assert L.ta_abi_version() == 6
 
 
 def test_cpu_backend_is_opt_in():
@@ -53,28 +53,6 @@ def test_plan_info():
         info = _lib.fft_plan_info(T)
         assert info["M"] == M
     assert _lib.fft_plan_info(163841) is None  # handled by the direct correlator
-
-
-def test_band_plan_covers_every_step_once():
-    """ta_band_plan_info (host only): the cut of the matrix-core lag-sum kernels' band — every step
-    of every group in exactly one piece, every piece in exactly one wave slot — for frame counts on
-    both sides of the 16-frame blocks and 256-lag groups, and other device sizes; the busiest wave's
-    share stays within 10 % of the average once the band is long enough to cut."""
-    from transport_analysis_amd import _lib
-
-    for T in list(range(1, 50)) + [255, 256, 257, 271, 272, 273, 511, 512, 513, 999, 1000, 4095, 4096, 4097, 5000,
-                                   8191, 8192, 10000, 20000, 65537, 200000]:
-        for n_cu in (256, 304, 64, 8):
-            info = _lib.band_plan_info(T, n_cu)
-            assert info is not None, (T, n_cu)
-            assert info["n_pieces"] >= 1 and 1 <= info["octets_in_flight"] <= 64
-            if T >= 2000 and n_cu == 256:
-                assert info["max_over_mean"] < 1.10, (T, info)
-    assert _lib.band_plan_info(0) is None and _lib.band_plan_info(1 << 24) is None
-    # the largest frame count the call accepts: checked by intervals, not cell by cell (which was ~137 GB of
-    # bookkeeping and took the process down)
-    big = _lib.band_plan_info((1 << 24) - 1)
-    assert big is not None and big["n_pieces"] >= 256
 
 
 def test_atom_shard_partition():

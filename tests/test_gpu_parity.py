@@ -162,12 +162,12 @@ def test_vacf_direct_vs_oracle_shapes(ctx, T, A, D):
                                    (255, 7, 3), (256, 3, 3), (257, 9, 1), (271, 4, 3), (272, 4, 3), (273, 5, 2),
                                    (511, 6, 3), (513, 11, 3), (1000, 37, 3), (2049, 8, 3), (4100, 3, 3),
                                    (5000, 21, 3), (9000, 3, 1), (300, 2001, 1), (300, 2003, 3)])
-@pytest.mark.parametrize("form", [3, 2])
+@pytest.mark.parametrize("form", [3])
 def test_vacf_direct_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
-    """Windowed VACF without the by-particle array = diagonal sums of the frames' Gram matrix, both
-    matrix-core forms: "direct_mfma" 3 (the default from 1536 frames) k_band_bp_vacf with a unit's particles summed in its
-    accumulators (k-slots from the time axis, bandbp_kernels.hpp), 2 the column-packed k_band_lags
-    (band_kernels.hpp) — against the oracle and against the vector kernel ("direct_mfma" 0); frame counts on
+    """Windowed VACF without the by-particle array = diagonal sums of the frames' Gram matrix on the FP64 matrix cores:
+    "direct_mfma" 3 (the default from 112 frames) k_band_bp_vacf with a unit's particles summed in its
+    accumulators (k-slots from the time axis, bandbp_kernels.hpp) — against the oracle and against the vector kernel
+    ("direct_mfma" 0; the column-packed second form of rounds 4-5 is tools/band/ since round 6); frame counts on
     both sides of the 16-frame blocks and the 256-lag groups, odd column counts (the unpaired column's zero
     partner), few and many columns."""
     from oracle import numpy_oracle as orc
@@ -178,7 +178,7 @@ def test_vacf_direct_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
     ctx.set_option("direct_mfma", form)
     try:
         ts_m, _ = run_vacf(ctx, v, False, False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_bp_vacf" if form == 3 else "k_band_lags"]
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_bp_vacf"]
         ts_again, _ = ctx.vacf_direct(by_particle=False)
         assert np.array_equal(ts_m, ts_again)  # fixed summation order: the same bits every launch
         ctx.set_option("direct_mfma", 0)
@@ -229,12 +229,11 @@ def test_vacf_direct_by_particle_on_the_matrix_cores(ctx, T, A, D):
 @pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 2, 3), (15, 3, 1), (16, 5, 3), (17, 2, 2), (241, 3, 3), (256, 3, 3),
                                    (257, 9, 1), (272, 4, 3), (273, 5, 2), (513, 11, 3), (1000, 37, 3), (2049, 8, 3),
                                    (4100, 3, 3), (5000, 7, 3), (300, 2001, 1), (300, 2001, 3)])
-@pytest.mark.parametrize("form", [3, 2])
+@pytest.mark.parametrize("form", [3])
 def test_helfand_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
-    """Einstein-Helfand mean squared differences without the by-particle array, both matrix-core forms:
-    "direct_mfma" 3 (the default from 896 frames) k_band_bp_helf with a unit's particles summed in its accumulators (k-slots from
-    the time axis), 2 the column-packed k_band_lags<helfand> (norms carried in the fourth lane group); both on
-    the product slab with rows centred on a nearby frame, against the oracle (viscosity.py:201-233: difference
+    """Einstein-Helfand mean squared differences without the by-particle array on the FP64 matrix cores ("direct_mfma" 3 =
+    the default at every length): k_band_bp_helf with a unit's particles summed in its accumulators (k-slots from
+    the time axis), on the product slab with rows centred on a nearby frame, against the oracle (viscosity.py:201-233: difference
     first) and against the vector kernel ("direct_mfma" 0); positions with a large offset and a drift, so that P
     is far from zero-mean."""
     from oracle import numpy_oracle as orc
@@ -247,7 +246,7 @@ def test_helfand_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
     ctx.set_option("direct_mfma", form)
     try:
         ts_m, _ = run_helfand(ctx, v, x, m, scale, False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_bp_helf" if form == 3 else "k_band_lags"]
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_bp_helf"]
         ts_again, _ = ctx.helfand_msd(m, scale, by_particle=False)
         assert np.array_equal(ts_m, ts_again)
         ctx.set_option("direct_mfma", 0)
@@ -325,7 +324,7 @@ def test_helfand_by_particle_matrix_cores_on_a_pure_trend_and_in_other_units(ctx
         assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL, (sv, sx)
 
 
-@pytest.mark.parametrize("form", [3, 2])
+@pytest.mark.parametrize("form", [3])
 def test_helfand_matrix_cores_on_a_pure_trend(ctx, form):
     """The case the plain expansion S1 - 2 S2 loses (3.6e-9 on the reference's own
     step trajectory): v = t, x = t^2 / 2, so P = m t^3 / 2 grows by nine orders of magnitude while
@@ -350,12 +349,11 @@ def test_helfand_matrix_cores_on_a_pure_trend(ctx, form):
 @pytest.mark.parametrize("T,A,D", [(1, 1, 1), (2, 2, 3), (15, 3, 1), (16, 5, 3), (17, 2, 2), (241, 3, 3), (256, 3, 3),
                                    (257, 9, 1), (272, 4, 3), (273, 5, 2), (513, 11, 3), (1000, 37, 3), (2049, 8, 3),
                                    (4100, 3, 3), (5000, 7, 3), (300, 2001, 1), (300, 2001, 3)])
-@pytest.mark.parametrize("form", [3, 2])
+@pytest.mark.parametrize("form", [3])
 def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
-    """BASELINE configs[4]'s float32 path without the by-particle array, both FP32 matrix-core forms: "direct_mfma" 3
-    (the default from 1408 frames) k_band32_tp (band32tp_kernels.hpp: k-slots from the time axis, a unit's particles summed in its
-    accumulators), 2 the column-packed k_band32_lags (band32_kernels.hpp: rows fetched by LDS-DMA); float32
-    accumulators flushed into float64 — against the oracle (viscosity.py:201-233) at the float32 path's bar, 2e-6 of the series'
+    """BASELINE configs[4]'s float32 path without the by-particle array on the FP32 matrix cores ("direct_mfma" 3 = the
+    default at every length): k_band32_tp (band32tp_kernels.hpp: k-slots from the time axis, a unit's particles summed in its
+    accumulators); float32 accumulators flushed into float64 — against the oracle (viscosity.py:201-233) at the float32 path's bar, 2e-6 of the series'
     scale, on the shapes of the float64 form's test: both sides of the 16-frame blocks and the 256-lag
     groups, ragged column counts (sextets with one and two pairs, an unpaired last column), P far from
     zero-mean.  Same bits every launch; and the float32 vector kernel ("direct_mfma" 0) agrees."""
@@ -370,7 +368,7 @@ def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
     ctx.set_option("direct_mfma", form)
     try:
         ts_m, _ = run_helfand(ctx, v, x, m, scale, False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp" if form == 3 else "k_band32_lags"]
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp"]
         ts_again, _ = ctx.helfand_msd(m, scale, by_particle=False)
         assert np.array_equal(ts_m, ts_again)  # fixed summation order
         ctx.set_option("direct_mfma", 0)
@@ -389,11 +387,10 @@ def test_helfand_float32_lag_sums_on_the_matrix_cores(ctx, T, A, D, form):
 
 @pytest.mark.parametrize("T,A", [(1, 2), (2, 3), (16, 5), (17, 3), (63, 3), (65, 2), (239, 2), (240, 3), (241, 2), (257, 7), (449, 3),
                                  (481, 5), (513, 2), (1000, 9), (2049, 3), (4100, 2), (300, 300)])
-@pytest.mark.parametrize("form", [3, 2])
+@pytest.mark.parametrize("form", [3])
 def test_helfand_float32_by_particle_on_the_matrix_cores(ctx, T, A, form):
-    """The float32 option WITH results.visc_by_particle (the class default output): "direct_mfma" 3 (the default from 224 frames)
-    k_band32_tp (k-slots from the time axis; any dim), 2 k_band32_bp (dim = 3: a particle's x, y, z in three of the
-    MFMA's four k-slots, units that own 240 lags; dim < 3 on the vector kernel) — against the oracle at 2e-6 of the
+    """The float32 option WITH results.visc_by_particle (the class default output): k_band32_tp (k-slots from the time
+    axis; any dim; "direct_mfma" 3 = the default at every length) — against the oracle at 2e-6 of the
     scale, frame counts on both sides of the 16-frame blocks, the 64-frame chunks and the 240- / 256-lag units; the
     timeseries is the mean of the by-particle array."""
     from oracle import numpy_oracle as orc
@@ -407,12 +404,12 @@ def test_helfand_float32_by_particle_on_the_matrix_cores(ctx, T, A, form):
     ctx.set_option("direct_mfma", form)
     try:
         ts, bp = run_helfand(ctx, v, x, m, scale, True)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp" if form == 3 else "k_band32_bp",
+        assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product32", "k_band32_tp",
                                                          "k_bp_transpose", "k_sum_partials"]
         ts2, bp2 = ctx.helfand_msd(m, scale, by_particle=True)
         assert np.array_equal(bp, bp2) and np.array_equal(ts, ts2)
         _, bp_d2 = run_helfand(ctx, v[:, :, :2], x[:, :, :2], m, scale, True)
-        assert ("k_band32_tp" if form == 3 else "k_direct") in [n for n, _ in ctx.kernel_timeline()]
+        assert "k_band32_tp" in [n for n, _ in ctx.kernel_timeline()]
         _, bp_d1 = run_helfand(ctx, v[:, :, 1:2], x[:, :, 1:2], m, scale, True)
     finally:
         ctx.set_option("direct_mfma", 1)
@@ -456,7 +453,7 @@ def test_helfand_float32_matrix_cores_trend_units_and_float32_slabs(ctx):
             assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL_F32, (sv, sx)
         # (c) float32 device slabs, both matrix-core forms
         v32, x32 = v2.astype(np.float32), x2.astype(np.float32)
-        for form, kernel in ((3, "k_band32_tp"), (2, "k_band32_lags")):
+        for form, kernel in ((3, "k_band32_tp"),):
             ctx.set_option("direct_mfma", form)
             want, _ = run_helfand(ctx, v32.astype(np.float64), x32.astype(np.float64), m2, 1.0, False)
             ctx.set_option("stage_device_f32", 1)
@@ -661,8 +658,8 @@ def test_vacf_fft_long_trajectory(ctx, T, A, D):
 def test_vacf_beyond_the_fft_plans(ctx):
     """n_frames > 163840: ta_vacf_fft computes the same quantity with the O(T^2) correlators on the matrix
     cores — 10241 block lags, 641 groups of 16: the time-packed kernel's 641 units of one particle (lag sums and
-    by particle), and under "direct_mfma" 2 the column-packed kernel (more groups than wave slots, so every wave
-    runs several whole groups) — against the FFT oracle."""
+    by particle), and under "direct_mfma" 0 the vector kernel (the column staged in an L2-resident buffer: it does not
+    fit the LDS) — against the FFT oracle."""
     from oracle import numpy_oracle as orc
 
     T, A, D = 163841, 1, 2
@@ -672,9 +669,9 @@ def test_vacf_beyond_the_fft_plans(ctx):
     try:
         ts, bp = run_vacf(ctx, v, True, False)
         assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_bp_vacf"]
-        ctx.set_option("direct_mfma", 2)
+        ctx.set_option("direct_mfma", 0)
         ts2, _ = ctx.vacf_fft(by_particle=False)
-        assert [n for n, _ in ctx.kernel_timeline()] == ["k_band_lags"]
+        assert "k_direct" in [n for n, _ in ctx.kernel_timeline()]
     finally:
         ctx.set_option("direct_mfma", 1)
         ctx.set_option("timeline", 0)
@@ -1526,22 +1523,23 @@ def test_kernel_timeline_sums_to_the_call(ctx):
 
 
 def test_direct_forms_by_trajectory_length(ctx):
-    """"direct_mfma" 1 (the default) picks the form by n_frames: the time-packed matrix-core kernels pay a ring fill and an
-    epilogue per particle and lag group, so short trajectories run the column-packed forms (lag sums) or the vector
-    kernel (windowed VACF by particle) — thresholds from profiles/r05_direct_forms_sweep*.txt.  Whatever is picked
-    agrees with the forced forms."""
+    """"direct_mfma" 1 (the default) picks the form by n_frames: the matrix-core kernels pay a ring fill and an epilogue
+    per particle and lag group, so the windowed VACF of short trajectories runs the vector kernel — thresholds from
+    profiles/r05_direct_forms_sweep*.txt (the column-packed forms of those sweeps left the library in round 6); every
+    Einstein-Helfand form is on the matrix cores at every length.  Whatever is picked agrees with the forced forms, and
+    "direct_mfma" 2 is rejected."""
     from oracle import numpy_oracle as orc
+    from transport_analysis_amd import _lib
 
     def names():
         return [n for n, _ in ctx.kernel_timeline() if n.startswith(("k_band", "k_direct"))]
 
+    with pytest.raises(_lib.TAError, match="tools/band"):
+        ctx.set_option("direct_mfma", 2)
     ctx.set_option("timeline", 1)
     try:
-        for T, vacf_bp, vacf_ls, helf_ls, f32_bp, f32_ls in (
-                (100, "k_direct", "k_band_lags", "k_band_lags", "k_band32_bp", "k_band32_lags"),
-                (200, "k_band_bp_vacf", "k_band_lags", "k_band_lags", "k_band32_bp", "k_band32_lags"),
-                (900, "k_band_bp_vacf", "k_band_lags", "k_band_bp_helf", "k_band32_tp", "k_band32_lags"),
-                (1600, "k_band_bp_vacf", "k_band_bp_vacf", "k_band_bp_helf", "k_band32_tp", "k_band32_tp")):
+        for T, vacf_bp, vacf_ls in ((100, "k_direct", "k_direct"), (120, "k_direct", "k_band_bp_vacf"),
+                                    (200, "k_band_bp_vacf", "k_band_bp_vacf"), (1600, "k_band_bp_vacf", "k_band_bp_vacf")):
             v, x, m, vol = orc.synthetic_helfand(T, 5, 3, seed=41 + T)
             ts_d, bp_d = run_vacf(ctx, v, False, True)
             assert names() == [vacf_bp], (T, names())
@@ -1550,14 +1548,14 @@ def test_direct_forms_by_trajectory_length(ctx):
             hs_b, hb = run_helfand(ctx, v, x, m, 1.0, True)
             assert names() == ["k_band_bp_helf"], (T, names())
             hs_l, _ = ctx.helfand_msd(m, 1.0, by_particle=False)
-            assert names() == [helf_ls], (T, names())
+            assert names() == ["k_band_bp_helf"], (T, names())
             ctx.set_option("direct_f32", 1)
             fs_b, fb = ctx.helfand_msd(m, 1.0, by_particle=True)
-            assert names() == [f32_bp], (T, names())
+            assert names() == ["k_band32_tp"], (T, names())
             fs_l, _ = ctx.helfand_msd(m, 1.0, by_particle=False)
-            assert names() == [f32_ls], (T, names())
+            assert names() == ["k_band32_tp"], (T, names())
             ctx.set_option("direct_f32", 0)
-            for form in (3, 2, 0):
+            for form in (3, 0):
                 ctx.set_option("direct_mfma", form)
                 assert scale_rel_err(ctx.helfand_msd(m, 1.0, by_particle=False)[0], hs_l) < 1e-11
                 assert scale_rel_err(ctx.helfand_msd(m, 1.0, by_particle=True)[1], hb) < 1e-11
@@ -1720,13 +1718,6 @@ def test_helfand_matrix_cores_do_not_depend_on_the_unit(ctx):
         for sv, sx in ((1e-6, 1e-6), (1e4, 1e4), (1e-3, 1.0)):
             got, _ = run_helfand(ctx, v * sv, x * sx, m, 1.0, False)
             assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_bp_helf"]
-            assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL, (sv, sx)
-        ctx.set_option("direct_mfma", 2)  # the column-packed form
-        base2, _ = run_helfand(ctx, v, x, m, 1.0, False)
-        assert scale_rel_err(base2, base) < 1e-12
-        for sv, sx in ((1e-6, 1e-6), (1e4, 1e4), (1e-3, 1.0)):
-            got, _ = run_helfand(ctx, v * sv, x * sx, m, 1.0, False)
-            assert [n for n, _ in ctx.kernel_timeline()] == ["k_helfand_product", "k_band_lags"]
             assert scale_rel_err(got / (sv * sx) ** 2, base) < TOL, (sv, sx)
     finally:
         ctx.set_option("direct_mfma", 1)

@@ -8,7 +8,8 @@
 #include <new>
 
 #include "../../include/ta_hip.h"
-#include "ta_internal.hpp"
+#include "../../transport_analysis_amd/csrc/ta_internal.hpp"
+#include "band_tools.hpp"
 
 namespace ta {
 

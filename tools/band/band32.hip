@@ -5,25 +5,10 @@
 #include "band32_kernels.hpp"
 
 #include "../../include/ta_hip.h"
-#include "ta_internal.hpp"
+#include "../../transport_analysis_amd/csrc/ta_internal.hpp"
+#include "band_tools.hpp"
 
 namespace ta {
-
-// P32 = float32((m v) x), pair-major 8-byte rows; vel / pos: pair-major float64 or (src_f32) float32 slabs
-hipError_t launch_helfand_product32(const void* vel, const void* pos, bool src_f32, const double* masses, long pitch, long T,
-                                    long n_cols, int D, float* P32, hipStream_t st) {
-    const long n_pairs = (n_cols + 1) / 2;
-    // grid.x covers the rows two at a time, grid.y walks the pairs
-    const unsigned gx = (unsigned)std::max<long>(1, std::min<long>(64, (T / 2 + 255) / 256));
-    const unsigned gy = (unsigned)std::max<long>(1, std::min<long>(n_pairs, 65535));
-    if (src_f32)
-        hipLaunchKernelGGL(k_helfand_product32<float>, dim3(gx, gy), dim3(256), 0, st, (const float*)vel, (const float*)pos, masses,
-                           pitch, T, n_cols, D, P32);
-    else
-        hipLaunchKernelGGL(k_helfand_product32<double>, dim3(gx, gy), dim3(256), 0, st, (const double*)vel, (const double*)pos,
-                           masses, pitch, T, n_cols, D, P32);
-    return hipGetLastError();
-}
 
 // lagsum[k] = factor * sum over columns and origins of (P32[i, c] - P32[i + k, c])^2 / (n_frames - k), lagsum[0] = 0
 hipError_t launch_band32_lags(BandCache** cache, int n_cu, const float* pm32, long pitch, int T, long n_cols, double factor,

@@ -11,7 +11,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../transport_analysis_amd/csrc/band32_kernels.hpp"
+#include "band32_kernels.hpp"
 using namespace ta;
 
 #ifndef B32_NW  // defaults = what band32.hip launches: 8 waves per workgroup (two per SIMD), requests 2 steps ahead

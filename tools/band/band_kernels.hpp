@@ -30,15 +30,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../transport_analysis_amd/csrc/band_common.hpp"
+
 #include <algorithm>
 #include <vector>
 
 namespace ta {
 
-typedef double band_d2 __attribute__((ext_vector_type(2)));
-typedef double band_d4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBandPartial = 272;  // lags 16 d0 - 15 ... 16 d0 + 255, padded to a multiple of 16
 
 struct BandPiece {
     int d0;     // first block lag of the 16 accumulators (a multiple of 16)
@@ -175,7 +174,6 @@ struct BandSrc {
 };
 #define TA_BAND_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-#define TA_BAND_MFMA(A, B, C) __builtin_amdgcn_mfma_f64_16x16x4f64((A), (B), (C), 0, 0, 0)
 
 // one piece on one octet: acc[d] += sum_{I in [i0, i1)} F_I^T F_{I + d0 + d}
 // ring: this wave's LDS ring (kBandNS slots of 128 rows).  Step x's rows — A block x and the window's newest
@@ -236,23 +234,6 @@ __device__ __forceinline__ void band_visit(const BandSrc& src, band_d2* ring, in
 #endif
 constexpr int kBandRef = TA_BAND_REF;
 
-typedef unsigned band_u2 __attribute__((ext_vector_type(2)));
-
-// s0 + s1 + s2 + s3 of the four 16-lane rows, lane by lane, in every row: two register-to-register
-// swaps (lane bit 5, lane bit 4) instead of trips through the LDS crossbar
-__device__ __forceinline__ double band_sum_halves(double s) {  // lane l: s[l] + s[l ^ 32]
-    const band_u2 w = __builtin_bit_cast(band_u2, s);
-    const band_u2 x0 = __builtin_amdgcn_permlane32_swap(w.x, w.x, false, false);
-    const band_u2 x1 = __builtin_amdgcn_permlane32_swap(w.y, w.y, false, false);
-    return __builtin_bit_cast(double, band_u2{x0.x, x1.x}) + __builtin_bit_cast(double, band_u2{x0.y, x1.y});
-}
-__device__ __forceinline__ double band_sum_row_pairs(double u) {  // lane l: u[l] + u[l ^ 16]
-    const band_u2 v = __builtin_bit_cast(band_u2, u);
-    const band_u2 y0 = __builtin_amdgcn_permlane16_swap(v.x, v.x, false, false);
-    const band_u2 y1 = __builtin_amdgcn_permlane16_swap(v.y, v.y, false, false);
-    return __builtin_bit_cast(double, band_u2{y0.x, y1.x}) + __builtin_bit_cast(double, band_u2{y0.y, y1.y});
-}
-__device__ __forceinline__ double band_sum_rows(double s) { return band_sum_row_pairs(band_sum_halves(s)); }
 
 struct BandHelf {
     int T, i;

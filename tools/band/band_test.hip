@@ -9,7 +9,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../transport_analysis_amd/csrc/band_kernels.hpp"
+#include "band_kernels.hpp"
 using namespace ta;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e), __LINE__); exit(1); } } while (0)

@@ -22,7 +22,7 @@ def main():
                 A = max(64, int(5000 * 5000 * 20000 / (T * T)) // 64 * 64)
                 A = min(A, int(20e9 / (T * 3 * 8 * (2 if mode == "helfand" else 1) + (T * 8 * 2 if bp else 0))))
                 row = []
-                for form in (1, 0, 2):
+                for form in (1, 0):
                     ctx.stage_free()
                     ctx.trim()
                     torch.cuda.empty_cache()

@@ -8,7 +8,7 @@ for mode, f32 in (("direct", False), ("helfand", False), ("helfand", True)):
     for bp in (False, True):
         for T, A in ((20000, 16), (20000, 64), (20000, 256), (20000, 1024), (5000, 64), (5000, 512), (5000, 4096)):
             row = []
-            for form in (3, 2, 0):
+            for form in (3, 0):
                 ctx.stage_free(); ctx.trim(); torch.cuda.empty_cache()
                 c = bench.Case(torch, ctx, dev, mode, T, A, 3, 0, A * 3, bench.SEED + 4, bp, f32, False, False)
                 ctx.set_option("direct_mfma", form)

@@ -20,7 +20,11 @@
 #include <cstring>
 #include <vector>
 
+#ifdef WF_ABLATIONS  // build.sh: csrc/wfft.hpp with ablations.patch applied (the WF_ABL / WF_INV_STAMP instrumentation that left the product header in round 6)
+#include "wfft_abl.hpp"
+#else
 #include "../../transport_analysis_amd/csrc/wfft.hpp"
+#endif
 #include "wfused.hpp"
 
 using namespace ta;

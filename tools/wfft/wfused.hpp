@@ -21,7 +21,9 @@
 // values); thread u then owns the lags u + 512 j + M jo, sums the four passes' terms in registers and
 // writes the atom's row of the atom-major scratch that k_bp_transpose turns into (n_frames, n_atoms).
 #pragma once
+#ifndef WF_ABLATIONS
 #include "../../transport_analysis_amd/csrc/wfft.hpp"
+#endif
 
 namespace ta {
 

@@ -25,7 +25,7 @@ EXPORTS = (
     "ta_vacf_fft", "ta_vacf_direct", "ta_helfand_msd",
     "ta_vacf_fft_dev", "ta_vacf_direct_dev", "ta_helfand_msd_dev",
     "ta_vacf_fft_staged", "ta_vacf_direct_staged", "ta_helfand_msd_staged",
-    "ta_last_timing", "ta_timing_history", "ta_kernel_timeline", "ta_clock_probe", "ta_fft_plan_info", "ta_band_plan_info",
+    "ta_last_timing", "ta_timing_history", "ta_kernel_timeline", "ta_clock_probe", "ta_fft_plan_info",
     "ta_set_option",
     "ta_host_alloc", "ta_host_alloc_on", "ta_host_free",
     "ta_group_create", "ta_group_destroy", "ta_group_last_error", "ta_group_size", "ta_group_member",
@@ -128,7 +128,6 @@ def lib():
     L.ta_host_alloc_on.argtypes = [ctypes.c_int, i64, ctypes.POINTER(vp)]
     L.ta_host_free.argtypes = [vp]
     L.ta_fft_plan_info.argtypes = [i64, ctypes.POINTER(i64), ctypes.POINTER(ci), ctypes.POINTER(ci)]
-    L.ta_band_plan_info.argtypes = [i64, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_double)]
     L.ta_set_option.argtypes = [vp, ctypes.c_char_p, i64]
     L.ta_group_create.argtypes = [ctypes.POINTER(ci), ci, ctypes.POINTER(vp)]
     L.ta_group_destroy.argtypes = [vp]
@@ -168,15 +167,6 @@ def fft_plan_info(n_frames):
     if rc != 0:
         return None
     return {"M": m.value, "n_threads": nt.value, "n_stages": ns.value}
-
-
-def band_plan_info(n_frames, n_cu=256):
-    """How the matrix-core lag-sum kernels cut their band (host only; the call checks the cut)."""
-    n, ph, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
-    rc = lib().ta_band_plan_info(int(n_frames), int(n_cu), ctypes.byref(n), ctypes.byref(ph), ctypes.byref(r))
-    if rc != 0:
-        return None
-    return {"n_pieces": n.value, "octets_in_flight": ph.value, "max_over_mean": r.value}
 
 
 def _ptr(a):

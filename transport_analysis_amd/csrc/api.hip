@@ -89,7 +89,6 @@ struct ta_ctx {
     int64_t opt_direct_groups = 0;
     int64_t opt_direct_chunk = 0;
     int64_t opt_direct_mfma = 1;  // windowed VACF lag sums without the by-particle array: matrix-core kernel
-    BandCache* band = nullptr;
     int64_t opt_helfand_fft = 0;
     int64_t opt_bp_block = 0;
     int64_t opt_bp_spec_atoms = 0;
@@ -211,44 +210,34 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
                 const double* d_masses, int64_t T, int64_t A, int D, int64_t pitch, double scale,
                 double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st, bool src_f32 = false) {
     const bool f32 = ctx->opt_direct_f32 != 0;  // src_f32 only comes with it (compute_pm)
-    // Lag sums alone are GEMM-shaped — the windowed VACF's are the diagonal sums of the frames' Gram
-    // matrix, the Helfand squared differences follow from products of rows centred on a nearby frame —
-    // and run on the FP64 matrix cores (band_kernels.hpp).  The by-particle arrays and the float32
-    // option stay on the vector kernels below.
+    // The O(T^2) correlators run on the matrix cores wherever that wins: FP64 (bandbp_kernels.hpp) and, for the float32
+    // option's Helfand forms, FP32 (band32tp_kernels.hpp: P rounded once to float32 like the float32 vector kernel's staged
+    // values, float32 products, float64 accumulation) -- the k-slots of the MFMA filled from the time axis.  "direct_mfma":
+    // 1 = by trajectory length (these kernels pay a ring fill and an epilogue per particle (block) and lag group; below ~100-150
+    // frames the vector kernels win the windowed VACF: profiles/r05_direct_forms_sweep*.txt, equal work, 64 ... 5000 frames),
+    // 3 = always, 0 = vector kernels (the parity tests' second opinion).  (The column-packed forms of rounds 4-5 --
+    // "direct_mfma" 2, inline-assembly LDS-DMA -- live under tools/band/ since round 6.)
     const bool band_ok = !d_bp && !f32 && !src_f32 && ctx->opt_direct_mfma && T < ((int64_t)1 << 24);
-    // ... and the float32 option's Helfand forms on the FP32 matrix cores: P rounded once to float32 like the float32 vector
-    // kernel's staged values, float32 products, float64 accumulation.  Default: the time-packed kernel
-    // (band32tp_kernels.hpp: all four k-slots do arithmetic; 259 ms per configs[4] share with or without the by-particle
-    // array); "direct_mfma" 2: the column-packed forms of band32_kernels.hpp (340 ms lag sums, 393 ms by particle at dim = 3).
-    // Which matrix-core form ("direct_mfma"): 1 = by trajectory length — the time-packed kernels pay a ring fill and an epilogue
-    // per particle (block) and lag group, the column-packed ones and the vector kernels do not: below a few hundred to 1500
-    // frames those win (profiles/r05_direct_forms_sweep*.txt: equal work, 64 ... 5000 frames); 2 = column-packed wherever it
-    // exists; 3 = time-packed always; 0 = vector kernels.
     const int mf = (int)ctx->opt_direct_mfma;
     auto time_packed = [&](int64_t from_frames) { return mf == 3 || (mf == 1 && T >= from_frames); };
-    const bool tp32 = d_bp ? (time_packed(224) || (mf == 1 && D != 3)) : time_packed(1408);
     if (!d_bp && f32 && mode == MODE_HELFAND && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
         const int64_t n_cols = A * D;
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK &&
-            (!tp32 || (ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
-                       ensure(ctx, ctx->unit_counter, 64) == TA_OK))) {
+            ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
+            ensure(ctx, ctx->unit_counter, 64) == TA_OK) {
             tl_mark(ctx, "k_helfand_product32", st);
             TA_HIP_TRY(ctx, launch_helfand_product32(d_vel, d_pos, src_f32, d_masses, pitch, T, n_cols, D, (float*)ctx->helf_p.p, st));
-            tl_mark(ctx, tp32 ? "k_band32_tp" : "k_band32_lags", st);
+            tl_mark(ctx, "k_band32_tp", st);
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-            if (tp32)
-                TA_HIP_TRY(ctx, launch_band32_tp_lags(ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, A, D, scale / (double)D,
-                                                      (double*)ctx->bp_scratch.p, (unsigned long long*)ctx->unit_counter.p, d_lagsum, st));
-            else
-                TA_HIP_TRY(ctx, launch_band32_lags(&ctx->band, ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, n_cols,
-                                                   scale / (double)D, d_lagsum, st));
+            TA_HIP_TRY(ctx, launch_band32_tp_lags(ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, A, D, scale / (double)D,
+                                                  (double*)ctx->bp_scratch.p, (unsigned long long*)ctx->unit_counter.p, d_lagsum, st));
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
             return TA_OK;
         }
         (void)hipGetLastError();  // out of memory for the product slab: the vector kernel needs none
     }
-    // ... and with the by-particle array (the column-packed form: dim = 3 only, a particle's x, y, z in three of the four k-slots)
-    if (d_bp && f32 && mode == MODE_HELFAND && (tp32 || D == 3) && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
+    // ... and with the by-particle array
+    if (d_bp && f32 && mode == MODE_HELFAND && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
         const int64_t n_cols = A * D, Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK &&
             ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
@@ -256,14 +245,10 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
             ensure(ctx, ctx->unit_counter, 64) == TA_OK) {
             tl_mark(ctx, "k_helfand_product32", st);
             TA_HIP_TRY(ctx, launch_helfand_product32(d_vel, d_pos, src_f32, d_masses, pitch, T, n_cols, D, (float*)ctx->helf_p.p, st));
-            tl_mark(ctx, tp32 ? "k_band32_tp" : "k_band32_bp", st);
+            tl_mark(ctx, "k_band32_tp", st);
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-            if (tp32)
-                TA_HIP_TRY(ctx, launch_band32_tp_bp(ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, A, D, scale / (double)D,
-                                                    (double*)ctx->bp_scratch.p, Tp, (unsigned long long*)ctx->unit_counter.p, st));
-            else
-                TA_HIP_TRY(ctx, launch_band32_bp(ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, A, scale / (double)D,
-                                                 (double*)ctx->bp_scratch.p, Tp, st));
+            TA_HIP_TRY(ctx, launch_band32_tp_bp(ctx->n_cu, (const float*)ctx->helf_p.p, pitch, (int)T, A, D, scale / (double)D,
+                                                (double*)ctx->bp_scratch.p, Tp, (unsigned long long*)ctx->unit_counter.p, st));
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
             tl_mark(ctx, "k_bp_transpose", st);
             TA_HIP_TRY(ctx, launch_bp_transpose((const double*)ctx->bp_scratch.p, Tp, A, T, d_bp, ld_bp, (double*)ctx->ts_partial.p, st));
@@ -275,7 +260,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
     }
     // ... and the windowed VACF with its by-particle array (the class default) on the FP64 matrix cores: the k-slots
     // are filled from the time axis (bandbp_kernels.hpp)
-    if (d_bp && !f32 && !src_f32 && mode == MODE_VACF && (mf == 2 || time_packed(144)) && T < ((int64_t)1 << 24)) {
+    if (d_bp && !f32 && !src_f32 && mode == MODE_VACF && time_packed(144) && T < ((int64_t)1 << 24)) {
         const int64_t Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
         if (ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
             ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T) == TA_OK &&
@@ -319,8 +304,8 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         (void)hipGetLastError();
     }
     // windowed VACF lag sums alone: the by-particle kernel with a unit's particles summed in its accumulators (work handed out
-    // by a counter instead of a fixed cut: 52.3 against 54.2 ms at 5000 x 50000 x 3); "direct_mfma" 2: the column-packed k_band_lags
-    if (band_ok && mode == MODE_VACF && time_packed(1536) &&
+    // by a counter: 51.4 ms at 5000 x 50000 x 3)
+    if (band_ok && mode == MODE_VACF && time_packed(112) &&
         ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
         ensure(ctx, ctx->unit_counter, 64) == TA_OK) {
         tl_mark(ctx, "k_band_bp_vacf", st);
@@ -330,40 +315,23 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
         return TA_OK;
     }
-    if (band_ok && mode == MODE_VACF) {
-        tl_mark(ctx, "k_band_lags", st);
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-        TA_HIP_TRY(ctx, launch_band_lags(&ctx->band, ctx->n_cu, false, (const double*)d_vel, pitch, (int)T, A * D, 1.0, d_lagsum, st));
-        TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-        return TA_OK;
-    }
     if (band_ok && mode == MODE_HELFAND) {
         // the product slab P = (m v) x first (T*A*D*8 bytes more; without them: the vector kernel); then the kernel of the
         // by-particle form with the particles of a unit summed in its accumulators (k-slots from the time axis: all four do
-        // arithmetic, where the column-packed k_band_lags<true> gives two of its eight to the norms: 445 against 646 ms per
-        // configs[4] share).  "direct_mfma" 2 selects the column-packed form.
+        // arithmetic: 463 ms per configs[4] share).
         const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2;
         const int n_parts = (int)std::min<int64_t>(1024, n_pairs);
-        const bool tp64 = time_packed(896);
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)) == TA_OK &&
             ensure(ctx, ctx->helf_small, sizeof(double) * (size_t)n_parts * T) == TA_OK &&
-            (!tp64 || (ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
-                              ensure(ctx, ctx->unit_counter, 64) == TA_OK))) {
+            ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
+            ensure(ctx, ctx->unit_counter, 64) == TA_OK) {
             tl_mark(ctx, "k_helfand_product", st);
             TA_HIP_TRY(ctx, launch_helfand_product((const double*)d_vel, (const double*)d_pos, d_masses, pitch, T, n_cols, D,
                                                    (double*)ctx->helf_p.p, (double*)ctx->helf_small.p, n_parts, st));
-            if (tp64) {
-                tl_mark(ctx, "k_band_bp_helf", st);
-                TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-                TA_HIP_TRY(ctx, launch_band_bp_helf_lags(ctx->n_cu, (const double*)ctx->helf_p.p, pitch, (int)T, A, D, scale / (double)D,
-                                                         (double*)ctx->bp_scratch.p, (unsigned long long*)ctx->unit_counter.p, d_lagsum, st));
-                TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
-                return TA_OK;
-            }
-            tl_mark(ctx, "k_band_lags", st);
+            tl_mark(ctx, "k_band_bp_helf", st);
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
-            TA_HIP_TRY(ctx, launch_band_lags(&ctx->band, ctx->n_cu, true, (const double*)ctx->helf_p.p, pitch, (int)T, n_cols,
-                                             scale / (double)D, d_lagsum, st));
+            TA_HIP_TRY(ctx, launch_band_bp_helf_lags(ctx->n_cu, (const double*)ctx->helf_p.p, pitch, (int)T, A, D, scale / (double)D,
+                                                     (double*)ctx->bp_scratch.p, (unsigned long long*)ctx->unit_counter.p, d_lagsum, st));
             TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
             return TA_OK;
         }
@@ -709,7 +677,7 @@ int staged_entry(ta_ctx* ctx, int which, const double* d_masses, double scale, d
 
 extern "C" {
 
-int ta_abi_version(void) { return 5; }
+int ta_abi_version(void) { return 6; }
 
 int ta_device_count(void) {
     int n = 0;
@@ -809,7 +777,6 @@ int ta_ctx_destroy(ta_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     ta_stage_free(ctx);
     for (auto& kv : ctx->wf_tables) hipFree(kv.second);
-    band_cache_free(ctx->band);
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_lagsum, &ctx->out_bp,
                       &ctx->masses, &ctx->bounce, &ctx->stage_buf, &ctx->helf_p,
                       &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1], &ctx->bp_scratch, &ctx->bp_spec,
@@ -839,8 +806,6 @@ int ta_trim(ta_ctx* ctx) {
     if (int rc = commit_flush(ctx)) return rc;
     hipSetDevice(ctx->device);
     hipDeviceSynchronize();
-    band_cache_free(ctx->band);
-    ctx->band = nullptr;
     for (DevBuf* b : {&ctx->partial, &ctx->spec, &ctx->ts_partial, &ctx->out_bp, &ctx->bounce, &ctx->bounce2, &ctx->stage_buf,
                       &ctx->helf_p, &ctx->helf_small, &ctx->pm_in[0], &ctx->pm_in[1],
                       &ctx->bp_scratch, &ctx->bp_spec})
@@ -861,7 +826,12 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "direct_f32")) ctx->opt_direct_f32 = value;
     else if (!strcmp(key, "direct_groups")) ctx->opt_direct_groups = value;
     else if (!strcmp(key, "direct_chunk")) ctx->opt_direct_chunk = value;
-    else if (!strcmp(key, "direct_mfma")) ctx->opt_direct_mfma = value;
+    else if (!strcmp(key, "direct_mfma")) {
+        if (value != 0 && value != 1 && value != 3)
+            return fail(ctx, TA_E_INVALID, "direct_mfma: 0 vector kernels, 1 by trajectory length (default), 3 matrix cores always "
+                                           "(2, the column-packed forms, left the library in round 6: tools/band/)");
+        ctx->opt_direct_mfma = value;
+    }
     else if (!strcmp(key, "helfand_fft")) ctx->opt_helfand_fft = value;
     else if (!strcmp(key, "bp_block")) ctx->opt_bp_block = value;
     else if (!strcmp(key, "bp_spec_atoms")) ctx->opt_bp_spec_atoms = value;

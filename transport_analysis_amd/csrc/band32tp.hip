@@ -3,10 +3,29 @@
 // (/root/reference/transport_analysis/viscosity.py:201-233, P rounded once to float32).
 #include "band32tp_kernels.hpp"
 
+#include <algorithm>
+
 #include "../../include/ta_hip.h"
 #include "ta_internal.hpp"
 
 namespace ta {
+
+// P32 = float32((m v) x), pair-major 8-byte rows; vel / pos: pair-major float64 or (src_f32) float32 slabs
+hipError_t launch_helfand_product32(const void* vel, const void* pos, bool src_f32, const double* masses, long pitch, long T,
+                                    long n_cols, int D, float* P32, hipStream_t st) {
+    const long n_pairs = (n_cols + 1) / 2;
+    // grid.x covers the rows two at a time, grid.y walks the pairs
+    const unsigned gx = (unsigned)std::max<long>(1, std::min<long>(64, (T / 2 + 255) / 256));
+    const unsigned gy = (unsigned)std::max<long>(1, std::min<long>(n_pairs, 65535));
+    if (src_f32)
+        hipLaunchKernelGGL(k_helfand_product32<float>, dim3(gx, gy), dim3(256), 0, st, (const float*)vel, (const float*)pos, masses,
+                           pitch, T, n_cols, D, P32);
+    else
+        hipLaunchKernelGGL(k_helfand_product32<double>, dim3(gx, gy), dim3(256), 0, st, (const double*)vel, (const double*)pos,
+                           masses, pitch, T, n_cols, D, P32);
+    return hipGetLastError();
+}
+
 
 namespace {
 constexpr int kWaves32tp = 12;  // three per SIMD (168 registers: 8 / 12 waves 245 / 238 ms; the rings and flush images of 12 waves take 158 KiB of LDS)

@@ -17,7 +17,7 @@
 #pragma once
 #include <utility>
 
-#include "band32_kernels.hpp"
+#include "band_common.hpp"
 #include "bandbp_kernels.hpp"
 
 namespace ta {

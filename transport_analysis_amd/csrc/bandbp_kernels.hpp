@@ -23,7 +23,7 @@
 // super-step ahead (registers, then a ds_write at the top of the next super-step): nothing here is hidden from the
 // compiler, no inline assembly, no hand-placed wait.
 #pragma once
-#include "band_kernels.hpp"
+#include "band_common.hpp"
 
 namespace ta {
 

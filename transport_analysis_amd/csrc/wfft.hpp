@@ -41,10 +41,6 @@ namespace ta {
 #define WF_NW_R0 0  // experiment: plan R0 = WF_NW_R0 runs with WF_NW_VAL waves per workgroup
 #define WF_NW_VAL 0
 #endif
-#ifndef WF_ABL
-#define WF_ABL 0  // timing ablations (wrong results): 1 no S2, 2 no S1 arithmetic, 3 no row loads,
-                  // 4 no S2 arithmetic (LDS traffic only), 5 no S2 exchanges (arithmetic only)
-#endif
 
 template <int LO, int HI, class F>
 __device__ __forceinline__ void static_for_range(F&& f) {
@@ -419,43 +415,33 @@ struct WfSubPost {
         for (int n2 = 0; n2 < 8; ++n2) v[n2] = reg[64 * n2 + lane];
     }
     __device__ __forceinline__ void stage_a(cd* __restrict__ reg, cd (&v)[8], const cd (&twa)[7]) const {
-#if WF_ABL != 4
         Dft<8>::run(v);
 #pragma unroll
         for (int a = 1; a < 8; ++a) v[a] = cmul(v[a], twa[a - 1]);
-#endif
         __builtin_amdgcn_wave_barrier();
-#if WF_ABL != 5
 #pragma unroll
         for (int a = 0; a < 8; ++a) reg[a * 64 + (lane ^ (8 * (a & 1)))] = v[a];
         __builtin_amdgcn_wave_barrier();
         const int base = hi * 64 + (lo ^ (8 * (hi & 1)));  // (8 n1 + lo) ^ 8 (hi&1), n1 = 0
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) v[n1] = reg[base ^ (8 * n1)];
-#endif
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ void stage_b(cd* __restrict__ reg, cd (&v)[8], const cd (&twb)[7]) const {
-#if WF_ABL != 4
         Dft<8>::run(v);
 #pragma unroll
         for (int b = 1; b < 8; ++b) v[b] = cmul(v[b], twb[b - 1]);
-#endif
         __builtin_amdgcn_wave_barrier();
-#if WF_ABL != 5
         const int x = lo ^ hi;
 #pragma unroll
         for (int b = 0; b < 8; ++b) reg[(hi * 8 + b) * 8 + (x ^ b)] = v[b];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int n0 = 0; n0 < 8; ++n0) v[n0] = reg[lane * 8 + (n0 ^ x)];
-#endif
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ void stage_c(cd (&v)[8], double (&acc)[8]) const {
-#if WF_ABL != 4
         Dft<8>::run(v);
-#endif
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = fma(v[c].y, v[c].y, fma(v[c].x, v[c].x, acc[c]));
         __builtin_amdgcn_wave_barrier();
@@ -607,23 +593,17 @@ struct WfSub {
     // of this sub-series
     template <unsigned SO>
     __device__ __forceinline__ void stage_a_w(cd (&v)[8]) const {
-#if WF_ABL != 4
         Dft<8>::run(v);
-#endif
         __builtin_amdgcn_wave_barrier();
-#if WF_ABL != 5
 #pragma unroll
         for (int a = 0; a < 8; ++a) at(a & 1 ? ad.wo : ad.we, SO + 1024u * a) = v[a];
-#endif
         __builtin_amdgcn_wave_barrier();
     }
     template <unsigned SO>
     __device__ __forceinline__ void stage_a_r(cd (&v)[8]) const {
         __builtin_amdgcn_wave_barrier();
-#if WF_ABL != 5
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) v[n1] = at(n1 & 1 ? ad.ro : ad.re, SO + 128u * n1);
-#endif
         __builtin_amdgcn_wave_barrier();
     }
     // XV: exchange 1 (register index a <-> lane bits 3..5) in the register file instead of the
@@ -633,9 +613,7 @@ struct WfSub {
     template <unsigned SO, bool XV = false>
     __device__ __forceinline__ void stage_a(cd (&v)[8]) const {
         if constexpr (XV) {
-#if WF_ABL != 4
             Dft<8>::run(v);
-#endif
             wf_transpose_hi(v);
         } else {
             stage_a_w<SO>(v);
@@ -644,23 +622,17 @@ struct WfSub {
     }
     template <unsigned SO>
     __device__ __forceinline__ void stage_b_w(cd (&v)[8], const WfTw& tw) const {
-#if WF_ABL != 4
         wf_dft8_tw(v, tw.b);
-#endif
         __builtin_amdgcn_wave_barrier();
-#if WF_ABL != 5
 #pragma unroll
         for (int b = 0; b < 8; ++b) at(ad.w2(b), SO + 128u * b) = v[b];
-#endif
         __builtin_amdgcn_wave_barrier();
     }
     template <unsigned SO>
     __device__ __forceinline__ void stage_b_r(cd (&v)[8]) const {
         __builtin_amdgcn_wave_barrier();
-#if WF_ABL != 5
 #pragma unroll
         for (int n0 = 0; n0 < 8; ++n0) v[n0] = at(ad.r2(n0), SO);
-#endif
         __builtin_amdgcn_wave_barrier();
     }
     template <unsigned SO>
@@ -669,9 +641,7 @@ struct WfSub {
         stage_b_r<SO>(v);
     }
     __device__ __forceinline__ void stage_c(cd (&v)[8], const WfTw& tw, double (&acc)[8]) const {
-#if WF_ABL != 4
         wf_dft8_tw(v, tw.c);
-#endif
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = fma(v[c].y, v[c].y, fma(v[c].x, v[c].x, acc[c]));
     }
@@ -1004,7 +974,6 @@ __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
             h = wf_load(twr, (unsigned)(u * pass) * 16u, 0u);
         };
         if constexpr (!LONG) load_seeds();
-#if WF_ABL != 2
         if constexpr (LONG) {
             // u_c[u + 512 j] = sum_jo z[u + 512 j + M jo] U(j, jo), U = W_L^{c (512 j + M jo)} lane-uniform,
             // its index advanced by c 512 per j and c M per jo (mod L: one conditional subtraction)
@@ -1060,7 +1029,6 @@ __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
             for (int j = 1; j < R0; ++j) x[j] = cmul(x[j], cd{WfTwist<R0>::re(j), WfTwist<R0>::im(j)});
         }
         Dft<R0>::run(x);
-#endif
         {
             // output twiddles W_L^{u (2R q + c)} = h g^q: two chains (even / odd q) by g^2, each
             // output stored as soon as it is scaled (the 20 stores of a wave take ~260 LDS-path
@@ -1112,7 +1080,7 @@ __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
         const __amdgpu_buffer_rsrc_t nrs = unit_rsrc(nitem, nk, &nkind);
         // the next unit's rows: a quarter at each of four points of the wave's (first) S2 call
         auto row_hook = [&](auto part_c) {
-#if WF_LOAD_PARTS == 4 && WF_ABL != 3
+#if WF_LOAD_PARTS == 4
             issue_loads_part(part_c, nrs, nkind);
 #endif
         };
@@ -1131,9 +1099,6 @@ __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
                     wf_sub512_w<s, P::kRegExchangeSingle>(wsub, stw, acc[s], (q1 >> s & 1u) ? 1.0 : 2.0);
             });
         } else
-#if WF_ABL == 1
-        if (T < 0)
-#endif
         if constexpr (NS1 == 3 && P::NLO == 2 && P::REM != 0) {
             // two full slots and a partial third: the waves that own three sub-series take them
             // three at a time, the others two at a time (no row requests along S2 in these plans:
@@ -1194,9 +1159,7 @@ __global__ void __launch_bounds__(P::NT, P::min_waves(BYP, LONG))
             if (nitem >= n_units) store_acc(tuple);
         }
         __builtin_amdgcn_sched_barrier(0);
-#if WF_ABL != 3
         issue_loads_tail(nrs, nkind);
-#endif
         kind = nkind, item = nitem, k = nk, crs = nrs;
         if constexpr (STAMP) st_tail += __builtin_amdgcn_s_memtime() - st_s2end;  // the row requests behind S2
         WF_STAMP(1)
@@ -1293,14 +1256,6 @@ struct WfSubT {
 };
 
 
-#ifndef WF_INV_STAMP
-#define WF_INV_STAMP 0  // diagnostic builds (tools/wfft): shader cycles per phase of k_winverse, summed over
-                        // workgroups (wave 0) into wf_inv_stamps: [0] sub-series stage incl. waiting for the
-                        // spectrum, [1] radix-R0 stage, [2] Q to LDS, [3] untangling + stores, [4] items
-#endif
-#if WF_INV_STAMP
-__device__ unsigned long long wf_inv_stamps[8];
-#endif
 
 template <class P, bool LONG = false, int PF = 0>
 __global__ void __launch_bounds__(P::NT)
@@ -1353,23 +1308,9 @@ __global__ void __launch_bounds__(P::NT)
                 rnorm[k1][j] = n < T ? 1.0 / (2.0 * (double)M * (double)(T - n)) : 0.0;
             }
     }
-#if WF_INV_STAMP
-    unsigned long long ist[5] = {0, 0, 0, 0, 0}, iprev = __builtin_amdgcn_s_memtime();
-#define WF_ISTAMP(i)                                                      \
-    {                                                                     \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime();     \
-        ist[i] += now_ - iprev;                                           \
-        iprev = now_;                                                     \
-    }
-#else
-#define WF_ISTAMP(i)
-#endif
 #pragma unroll
     for (int s = 0; s < PF; ++s) load_spec(blockIdx.x, 0, s);
     for (long item = blockIdx.x; item < n_items; item += gridDim.x) {
-#if WF_INV_STAMP
-        ++ist[4];
-#endif
         for (int cp = 0; cp < R; ++cp) {
             // per-thread offsets and LDS addresses are re-formed per transform: hoisted out of the
             // loops they would be spilled
@@ -1390,7 +1331,6 @@ __global__ void __launch_bounds__(P::NT)
                     if (NW * s + NW - 1 < R0 || q < R0) wt.run(lds + q * N1, v[s], twa, twb);
                 }
             }
-            WF_ISTAMP(0)
             __syncthreads();
             if constexpr (PF > 0) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -1421,7 +1361,6 @@ __global__ void __launch_bounds__(P::NT)
                 }
                 Dft<R0>::run(x);  // x[j'] = Q[u + 512 j']
             }
-            WF_ISTAMP(1)
             // No barrier here: thread u has read G_q[u] for every q -- column u of every 8 KiB block --
             // and writes Q[u + 512 j] into the SAME column of the same blocks; nobody else touches it.
             // (Round 4: the barrier that stood here cost the waves of a SIMD their skew twice.)
@@ -1433,7 +1372,6 @@ __global__ void __launch_bounds__(P::NT)
 #pragma unroll
                 for (int j = 0; j < R0; ++j) lds[u + N1 * j] = xx[k1][j];
             }
-            WF_ISTAMP(2)
             __syncthreads();
             double* o = out + item * ld;
 #pragma unroll
@@ -1495,15 +1433,9 @@ __global__ void __launch_bounds__(P::NT)
                     }
                 }
             }
-            WF_ISTAMP(3)
             __syncthreads();  // Q consumed before the next transform's sub-series overwrite the LDS
         }
     }
-#if WF_INV_STAMP
-    if (tid == 0)
-        for (int i = 0; i < 5; ++i) atomicAdd(&wf_inv_stamps[i], ist[i]);
-#endif
-#undef WF_ISTAMP
 }
 
 // ================================================================================================
