@@ -228,9 +228,75 @@ static int run_fused(int argc, char** argv) {
     }
 }
 
+// ---- the forward kernel in by-particle mode with the in-kernel stamps (round 6: why a unit costs more there than in
+// lag-sum mode):   wfft_test bptime <n_atoms> [T] [reps] [D]
+template <int R0>
+static int run_bptime(int argc, char** argv) {
+    using P = WPlan<R0>;
+    const int M = P::M, L = 2 * M;
+    const long A = argc > 2 ? atol(argv[2]) : 25600;
+    const int T = argc > 3 ? atoi(argv[3]) : (M == 10240 ? 10000 : M - 37);
+    const int reps = argc > 4 ? atoi(argv[4]) : 5;
+    const int D = argc > 5 ? atoi(argv[5]) : 3;
+    const long pitch = (T + 7) / 8 * 8, n_pairs = (A * D + 1) / 2;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const long groups = D & 1 ? (A + 1) / 2 : A;
+    const int nwg = (int)std::max<long>(16, std::min<long>(prop.multiProcessorCount, 2 * groups) / 16 * 16);
+    std::vector<cd> tw(wf_table_elems(R0, 1));
+    wf_fill_table(R0, 1, tw.data());
+    cd* d_tw;
+    double *d_pm, *d_acc;
+    unsigned long long* d_st;
+    CK(hipMalloc(&d_tw, tw.size() * sizeof(cd)));
+    CK(hipMemcpy(d_tw, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_pm, (size_t)n_pairs * pitch * 16));
+    CK(hipMalloc(&d_acc, (size_t)A * L * 8));
+    CK(hipMalloc(&d_st, (size_t)nwg * 16 * 8));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, d_pm, (size_t)n_pairs * pitch * 2, 12345ull);
+    CK(hipDeviceSynchronize());
+    auto kern = k_wsplit_accum<P, true, false, true>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::kLds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r <= reps; ++r) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(P::NT), P::kLds, 0, d_pm, pitch, T, A, d_tw, d_acc, D, 1, d_st);
+        CK(hipGetLastError());
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r) best = std::min(best, ms);
+    }
+    std::vector<unsigned long long> st((size_t)nwg * 16);
+    CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+#ifdef WF_MIX  // (built with tools/wfft/mixed_units.patch applied: 3 units per pair of atoms at dim 3, 1 per pair at dim 1)
+    const long units_per_atom_x2 = WF_MIX ? (D == 3 ? 3 : D == 1 ? 1 : 2) : (D == 3 ? 4 : 2);
+#else
+    const long units_per_atom_x2 = D == 3 ? 4 : 2;
+#endif
+    const double unit_passes = (double)A * units_per_atom_x2 / 2.0 * 2.0;  // all workgroups together
+    for (int h = 0; h < 2; ++h) {
+        double sacc[4] = {0, 0, 0, 0}, tail = 0;
+        for (int w = 0; w < nwg; ++w) {
+            tail += (double)st[(size_t)w * 16 + 8 + h];
+            for (int i = 0; i < 4; ++i) sacc[i] += (double)st[(size_t)w * 16 + h * 4 + i];
+        }
+        printf("by-particle forward R0=%d T=%d atoms=%ld D=%d nwg=%d: cycles per unit and pass (wave %d): S1 %.0f  S2 %.0f (row requests + barrier wait %.0f)  total %.0f  clock %.0f MHz\n",
+               R0, T, A, D, nwg, 4 * h, sacc[0] / unit_passes, sacc[1] / unit_passes, tail / unit_passes, (sacc[0] + sacc[1]) / unit_passes,
+               sacc[2] / sacc[3] * 100.0);
+    }
+    printf("by-particle forward: best %.3f ms (x100000 atoms: %.2f ms)\n", best, best * 100000.0 / A);
+    return 0;
+}
+
 template <int R0>
 static int run(int R, int argc, char** argv) {
     if (argc > 1 && (!strcmp(argv[1], "fcheck") || !strcmp(argv[1], "ftime"))) return run_fused<R0>(argc, argv);
+    if (argc > 1 && !strcmp(argv[1], "bptime")) return run_bptime<R0>(argc, argv);
     using P = WPlan<R0>;
     const int M = P::M, L = 2 * R * M;
     if (argc > 1 && !strcmp(argv[1], "inv")) {
