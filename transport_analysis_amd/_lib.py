@@ -530,6 +530,11 @@ class Group:
     def close(self):
         if self._h:
             self._drop_views()
+            for ref in self.__dict__.get("_member_views", []):
+                c = ref()
+                if c is not None:  # a borrowed member context must not outlive the group's handle
+                    c._h = ctypes.c_void_p(None)
+            self._member_views = []
             lib().ta_group_destroy(self._h)
             self._h = ctypes.c_void_p(None)
 
@@ -571,7 +576,11 @@ class Group:
         h, dev = ctypes.c_void_p(), ctypes.c_int()
         self._check(lib().ta_group_member(self._h, int(i), ctypes.byref(h), ctypes.byref(dev)))
         c = Context.__new__(Context)
-        c._h, c.device, c._slabs, c._borrowed = h, dev.value, [], True
+        c._h, c.device, c._slabs, c._borrowed, c.is_cpu = h, dev.value, [], True, False
+        c._group = self  # the member's context lives as long as its group: the view keeps the group alive ...
+        import weakref
+
+        self.__dict__.setdefault("_member_views", []).append(weakref.ref(c))  # ... and close() invalidates the view
         return c
 
     def shard(self, n_atoms, i):

@@ -101,6 +101,7 @@ struct ta_ctx {
     // loop at 10000 x 50000 x 3).  Everything that touches the slabs or the streams joins the queue first
     // (commit_flush); an error of a queued commit is returned there.
     int64_t opt_async_commit = 1;
+    int64_t opt_lock_ahead = 1;  // "lock_ahead": the commit worker page-locks the chunks behind the one it committed
     std::thread cq_thread;
     std::mutex cq_m;
     std::condition_variable cq_cv;
@@ -112,12 +113,18 @@ struct ta_ctx {
 
 int commit_flush(ta_ctx* ctx);  // (defined with ta_stage_commit)
 static void commit_stop(ta_ctx* ctx);
+static void commit_worker(ta_ctx* ctx);
 
 namespace {
 
+// (the commit worker thread reports errors too: the context's message is written and read under a lock)
+std::mutex g_err_m;
 int fail(ta_ctx* ctx, int code, const std::string& msg) noexcept {
     try {  // (a failing copy of the message must not turn an error return into an exception)
-        if (ctx) ctx->err = msg;
+        if (ctx) {
+            std::lock_guard<std::mutex> lk(g_err_m);
+            ctx->err = msg;
+        }
         g_tls_error = msg;
     } catch (...) {
     }
@@ -685,7 +692,18 @@ int ta_device_count(void) {
     return n;
 }
 
-const char* ta_last_error(const ta_ctx* ctx) { return ctx ? ctx->err.c_str() : g_tls_error.c_str(); }
+const char* ta_last_error(const ta_ctx* ctx) {
+    if (!ctx) return g_tls_error.c_str();
+    // a copy made under the lock, owned by the calling thread until its next call
+    thread_local std::string copy;
+    try {
+        std::lock_guard<std::mutex> lk(g_err_m);
+        copy = ctx->err;
+    } catch (...) {
+        return "out of memory while reading the error message";
+    }
+    return copy.c_str();
+}
 
 int ta_ctx_create(int device, ta_ctx** out) {
     return ta::guard([&](int c_, const std::string& m_) { return fail(nullptr, c_, m_); }, [&]() -> int {
@@ -835,6 +853,7 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "helfand_fft")) ctx->opt_helfand_fft = value;
     else if (!strcmp(key, "bp_block")) ctx->opt_bp_block = value;
     else if (!strcmp(key, "bp_spec_atoms")) ctx->opt_bp_spec_atoms = value;
+    else if (!strcmp(key, "lock_ahead")) ctx->opt_lock_ahead = value;
     else if (!strcmp(key, "cpu_threads")) {  // CPU backend: OpenMP team size (0: the runtime's default)
         if (value < 0 || value > 4096) return fail(ctx, TA_E_INVALID, "cpu_threads: 0 (default) .. 4096");
         ctx->cpu.threads = value > 0 ? (int)value : ta::cpu::hardware_threads();
@@ -1010,6 +1029,15 @@ static int stage_alloc_common(ta_ctx* ctx, int64_t n_frames, int64_t n_atoms, in
     ctx->st_pitch = pm_pitch(n_frames);
     // the zero fill ran on the context's stream; later fills may come on any stream
     TA_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_slabs && ctx->opt_async_commit && ctx->opt_lock_ahead) {
+        // the worker starts page-locking the slabs' first chunks while the caller sets up its frame loop (an empty job)
+        if (!ctx->cq_thread.joinable()) ctx->cq_thread = std::thread(commit_worker, ctx);
+        {
+            std::lock_guard<std::mutex> lk(ctx->cq_m);
+            ctx->cq.emplace_back(0, 0);
+        }
+        ctx->cq_cv.notify_all();
+    }
     return TA_OK;
 }
 
@@ -1093,6 +1121,20 @@ static int stage_commit_now(ta_ctx* ctx, int64_t frame_lo, int64_t frame_hi) {
     return TA_OK;
 }
 
+// Page-locking ahead of the frame loop (round 6): behind a commit the worker registers the next chunks of every slab --
+// pages no frame has touched yet, which the registration faults in -- so that the filling threads find their pages present
+// and the commits that follow find their chunks registered (before: every chunk was registered by the commit that first
+// needed it, with the loop's threads page-faulting on it meanwhile: frame fills 0.12 s -> 0.42 s at 10000 x 50000 x 3).
+static void stage_lock_ahead(ta_ctx* ctx, int64_t frame_from) {
+    constexpr size_t kAhead = 3;
+    const size_t row = (size_t)ctx->st_A * ctx->st_D, esz = ctx->st_dtype == TA_F32 ? 4 : 8;
+    const size_t s0 = (size_t)frame_from * row * esz;
+    for (size_t i = 0; i < ctx->h_blocks.size(); ++i) {
+        HostBlock& blk = ctx->h_blocks[i];
+        if (blk.base && s0 < blk.bytes) (void)host_block_lock(blk, s0, std::min(blk.bytes, s0 + kAhead * HostBlock::kChunk));
+    }
+}
+
 static void commit_worker(ta_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     std::unique_lock<std::mutex> lk(ctx->cq_m);
@@ -1104,10 +1146,16 @@ static void commit_worker(ta_ctx* ctx) {
         ctx->cq_busy = true;
         lk.unlock();
         // (an exception on this thread would end the process: it becomes the queued commit's error)
-        const int rc = ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); },
-                                 [&]() -> int { return stage_commit_now(ctx, job.first, job.second); });
+        const int rc = ta::guard([&](int c_, const std::string& m_) { return fail(ctx, c_, m_); }, [&]() -> int {
+            const int r = job.second > job.first ? stage_commit_now(ctx, job.first, job.second) : TA_OK;  // (an empty job: lock ahead only)
+            if (r == TA_OK && ctx->opt_lock_ahead) stage_lock_ahead(ctx, job.second);
+            return r;
+        });
         lk.lock();
-        if (rc && ctx->cq_rc == TA_OK) ctx->cq_rc = rc, ctx->cq_err = ctx->err;  // the first failure is the one reported
+        if (rc && ctx->cq_rc == TA_OK) {  // the first failure is the one reported
+            std::lock_guard<std::mutex> el(g_err_m);
+            ctx->cq_rc = rc, ctx->cq_err = ctx->err;
+        }
         ctx->cq_busy = false;
         ctx->cq_cv.notify_all();
     }

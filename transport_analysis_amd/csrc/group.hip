@@ -19,7 +19,25 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>  // types and prototypes only: librccl.so is dlopen'ed (struct Rccl)
+#else  // a ROCm install without the RCCL development headers: the few declarations this file needs, as RCCL 2.x publishes them
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclFloat64 = 8 } ncclDataType_t;
+ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommAbort(ncclComm_t comm);
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count);
+ncclResult_t ncclReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, int root,
+                        ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <algorithm>
 #include <cstdlib>
@@ -46,6 +64,7 @@ struct Rccl {
     void* handle = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;  // (optional: a library without it destroys the communicator instead)
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -64,6 +83,7 @@ struct Rccl {
         auto sym = [&](const char* n) { return dlsym(handle, n); };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
         CommCount = (decltype(CommCount))sym("ncclCommCount");
         Reduce = (decltype(Reduce))sym("ncclReduce");
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
@@ -179,12 +199,15 @@ int reduce_members(ta_group* g, const std::vector<int>& who, std::vector<double*
         // every later RCCL call made from it (the caller's torch.distributed ones included).
         ncclResult_t rc = g_rccl.GroupStart();
         hipError_t he = hipSuccess;
+        int launched = 0;  // calls RCCL accepted inside the group
         if (rc == ncclSuccess) {
             for (int i = 0; i < n && rc == ncclSuccess && he == hipSuccess; ++i) {
                 he = hipSetDevice(g->devices[i]);
-                if (he == hipSuccess)
+                if (he == hipSuccess) {
                     rc = g_rccl.Reduce(d_tot[i], d_tot[i], (size_t)T, ncclFloat64, ncclSum, 0, g->comms[i],
                                        ctx_stream(g->ctx[i]));
+                    if (rc == ncclSuccess) ++launched;
+                }
             }
             const ncclResult_t rc2 = g_rccl.GroupEnd();
             if (rc == ncclSuccess) rc = rc2;
@@ -198,11 +221,18 @@ int reduce_members(ta_group* g, const std::vector<int>& who, std::vector<double*
         const std::string why = he != hipSuccess ? std::string("hipSetDevice: ") + hipGetErrorString(he)
                                                  : "ncclReduce: " + g_rccl.what(rc);
         if (mode == RED_RCCL) return gfail(g, TA_E_HIP, why);
-        // RED_AUTO: the members' vectors are untouched by a collective that never launched; make sure of
-        // it (drain the streams), drop the communicators and add the vectors by peer copies instead
-        for (int i = 0; i < n; ++i) {
-            (void)hipSetDevice(g->devices[i]);
-            (void)hipStreamSynchronize(ctx_stream(g->ctx[i]));
+        // RED_AUTO.  Falling back to peer copies is only safe when NOTHING of the collective was enqueued: the reduce is
+        // in place on the root's vector, and ncclGroupEnd launches whatever calls were accepted before the failing one.
+        // That is the case when ncclGroupStart itself failed, or the very first member's hipSetDevice / ncclReduce did
+        // (`launched` counts the calls RCCL accepted).  Otherwise the members' sums may be half-reduced and their streams
+        // may wait on ranks that never arrive: the communicators are aborted and the call fails.
+        if (launched > 0) {
+            for (ncclComm_t c : g->comms)
+                if (c) (void)(g_rccl.CommAbort ? g_rccl.CommAbort(c) : g_rccl.CommDestroy(c));
+            g->comms.clear();
+            g->reduce_note = why;
+            return gfail(g, TA_E_HIP, "RCCL reduce failed after " + std::to_string(launched) + " of " + std::to_string(n) +
+                                          " ranks had joined (" + why + "): the lag sums are not trustworthy; re-run with reduce_mode 1 (peer copies)");
         }
         for (ncclComm_t c : g->comms)
             if (c) (void)g_rccl.CommDestroy(c);

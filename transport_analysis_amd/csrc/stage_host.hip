@@ -278,19 +278,35 @@ namespace ta {
 // separately registered ranges ("invalid argument"), so copies out of a slab are cut at chunk boundaries
 // (tools/ubench/hostreg_probe.hip, profiles/r05_hostreg_probe.txt).
 int host_block_map(size_t bytes, HostBlock* b) {
-    const size_t len = (std::max<size_t>(bytes, 1) + (HostBlock::kChunk - 1)) / HostBlock::kChunk * HostBlock::kChunk;
+    // whole 64 MiB chunks for a slab of several; a small slab (a few atoms by a few hundred frames) maps, zeroes and
+    // page-locks its own size rounded up to 2 MiB only
+    const size_t want = std::max<size_t>(bytes, 1);
+    const size_t unit = want < HostBlock::kChunk ? ((size_t)2 << 20) : HostBlock::kChunk;
+    const size_t len = (want + unit - 1) / unit * unit;
     void* m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m == MAP_FAILED) return -1;
     (void)madvise(m, len, MADV_HUGEPAGE);
     b->base = (char*)m, b->bytes = len;
-    b->locked.assign(len / HostBlock::kChunk, 0);
+    b->locked.assign((len + HostBlock::kChunk - 1) / HostBlock::kChunk, 0);
     return 0;
 }
-hipError_t host_block_lock(HostBlock& b, size_t b0, size_t b1) {  // page-lock the chunks that cover [b0, b1)
+// page-lock the chunks that cover [b0, b1).  A chunk the runtime refuses to register (RLIMIT_MEMLOCK, a cgroup limit)
+// stays pageable -- marked 2, not tried again: copies out of it are ordinary pageable hipMemcpyAsync calls, slower,
+// same bytes -- instead of failing the analysis after its frames have been read.
+hipError_t host_block_lock(HostBlock& b, size_t b0, size_t b1) {
     for (size_t k = b0 / HostBlock::kChunk; k < b.locked.size() && k * HostBlock::kChunk < b1; ++k) {
         if (b.locked[k]) continue;
-        const hipError_t e = hipHostRegister(b.base + k * HostBlock::kChunk, HostBlock::kChunk, hipHostRegisterPortable);
-        if (e != hipSuccess) return e;
+        const size_t off = k * HostBlock::kChunk, len = std::min(HostBlock::kChunk, b.bytes - off);
+        const hipError_t e = hipHostRegister(b.base + off, len, hipHostRegisterPortable);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true))
+                fprintf(stderr, "transport_analysis_amd: hipHostRegister of a staging chunk failed (%s): copying from pageable memory\n",
+                        hipGetErrorString(e));
+            b.locked[k] = 2;
+            continue;
+        }
         b.locked[k] = 1;
     }
     return hipSuccess;
@@ -298,7 +314,7 @@ hipError_t host_block_lock(HostBlock& b, size_t b0, size_t b1) {  // page-lock t
 void host_block_unmap(HostBlock& b) {
     if (!b.base) return;
     for (size_t k = 0; k < b.locked.size(); ++k)
-        if (b.locked[k]) {
+        if (b.locked[k] == 1) {
             const hipError_t e = hipHostUnregister(b.base + k * HostBlock::kChunk);
             if (e != hipSuccess)  // the pages would stay pinned behind a mapping that is going away: say so
                 fprintf(stderr, "transport_analysis_amd: hipHostUnregister(%p): %s\n", (void*)(b.base + k * HostBlock::kChunk), hipGetErrorString(e));
