@@ -234,6 +234,9 @@ def test_helfand_float32_switch(backend, step_vtraj):
     # 6e-8 |P|, is what the shortest lags see; lag by lag they agree to a few 1e-6)
     assert np.max(np.abs(vh.results.timeseries - want)) < 2e-6 * np.max(np.abs(want))
     assert_allclose(vh.results.timeseries, want, rtol=5e-5)
+    # per lag: only the shortest lags of this pure trend see P's float32 rounding (measured on the GPU path: 1e-5 at lag 1,
+    # 2e-6 at lags 2-4, 3e-7 from lag 5 on; tools/f32_lag_accuracy.py) -- from lag 5 on the bound is that of the scale
+    assert_allclose(vh.results.timeseries[5:], want[5:], rtol=2e-6)
     assert vh.results.timeseries[0] == 0.0
     if backend == "oracle-backed":
         assert vh._ctx.options["direct_f32"] == 1

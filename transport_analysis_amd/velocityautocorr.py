@@ -42,9 +42,12 @@ class VelocityAutocorr(AnalysisBase):
         ``fft=False``: the lag sums are the diagonal sums of the frames' Gram matrix,
         on the FP64 matrix cores, no faster than with the array) and
         ``results.vacf_by_particle`` is ``None``.
-    device : int, keyword-only
+    device : int or "cpu", keyword-only
         GPU index (default: ``$TA_AMD_DEVICE`` or 0; with ``distributed=True``:
-        ``$TA_AMD_DEVICE``, else ``$LOCAL_RANK``, else torch's current device).
+        ``$TA_AMD_DEVICE``, else ``$LOCAL_RANK``, else torch's current device).  ``"cpu"`` (or
+        ``$TA_AMD_DEVICE=cpu``) asks for the library's opt-in CPU backend -- C++/OpenMP behind the
+        same C symbols (``csrc/cpu_backend.cpp``); it is never selected on the caller's behalf: without
+        a GPU every other value fails loudly.
     stage_dtype : numpy dtype, keyword-only
         Element type of the pinned staging slab.  Default: the dtype MDAnalysis hands the
         velocities out in (float32) -- lossless, half the PCIe bytes of the reference's

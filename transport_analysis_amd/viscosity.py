@@ -29,7 +29,9 @@ class ViscosityHelfand(AnalysisBase):
     by_particle : bool, keyword-only, default True — materialise
         ``results.visc_by_particle``; ``False`` computes the timeseries only.  Both run on the
         matrix cores (FP64; ``float32=True``: FP32), every lag to the path's accuracy.
-    device : int, keyword-only — GPU index (default ``$TA_AMD_DEVICE`` or 0).
+    device : int or "cpu", keyword-only — GPU index (default ``$TA_AMD_DEVICE`` or 0); ``"cpu"`` asks
+        for the library's opt-in CPU backend (C++/OpenMP behind the same C symbols; nothing selects it
+        on the caller's behalf).
     distributed : bool, keyword-only, default False — one process per GPU under
         ``torch.distributed``: each rank handles its contiguous block of atoms, one all-reduce of
         the lag sums gives ``results.timeseries`` on every rank; ``results.visc_by_particle``
@@ -37,7 +39,11 @@ class ViscosityHelfand(AnalysisBase):
     float32 : bool, keyword-only, default False — form the mass-weighted
         velocity-position products in float64, then evaluate the squared differences and
         their block sums in float32 (accumulated into float64): 2e-6 of the series' scale
-        instead of 1e-10 relative, 1.8x the throughput.
+        instead of 1e-10 relative, 1.9x the throughput.  The products are rounded to float32
+        ONCE before differences are formed, so the shortest lags of a smooth, trending series see
+        that rounding (6e-8 of |P|) against a small difference: on the reference's step trajectory
+        1e-5 relative at lag 1, 2e-6 at lags 2-4, 3e-7 from lag 5 on; a fit window that starts at
+        lag 5 or later is unaffected.  (The CPU backend computes this option in float64.)
 
     fft : bool, keyword-only, default False — an extension (the reference has only the
         O(n_frames^2) loop): evaluate the mean squared differences in
