@@ -295,10 +295,11 @@ def test_mdanalysis_parallel_backend_declaration():
         assert cls._analysis_algorithm_is_parallelizable is False
 
 
-@pytest.mark.gpu
-def test_ncbox_water_golden_vectors():
-    """BASELINE configs[0]: VelocityAutocorr(fft=True) on MDAnalysisTests' PRM_NCBOX/TRJ_NCBOX
-    water box through the REAL MDAnalysis AnalysisBase (plumbing).  Both vectors the reference
+@pytest.mark.parametrize("device", ["cpu", pytest.param(0, marks=pytest.mark.gpu)])
+def test_ncbox_water_golden_vectors(device):
+    """BASELINE configs[0] ("CPU path, plumbing, no GPU"): VelocityAutocorr(fft=True) on MDAnalysisTests' PRM_NCBOX/TRJ_NCBOX
+    water box through the REAL MDAnalysis AnalysisBase -- on the library's opt-in CPU backend (device="cpu": runs
+    wherever MDAnalysis is installed, GPU or not) and, marked gpu, on the HIP path.  Both vectors the reference
     prints: its module docstring (velocityautocorr.py:39-43, resname WAT and resid 1-5) and
     docs/tutorials/vacf_testing_examples.ipynb:52-55 (name O and resname WAT and resid 1-10);
     and its own FFT == windowed assertion (tests/test_velocityautocorr.py:297-315)."""
@@ -315,9 +316,9 @@ def test_ncbox_water_golden_vectors():
     for sel, key in (("resname WAT and resid 1-5", "ncbox_vacf_fft_WAT_resid_1_5"),
                      ("name O and resname WAT and resid 1-10", "ncbox_vacf_fft_O_resid_1_10")):
         ag = u.select_atoms(sel)
-        fft = VelocityAutocorr(ag, fft=True).run()
+        fft = VelocityAutocorr(ag, fft=True, device=device).run()
         np.testing.assert_allclose(fft.results.timeseries, const[key], rtol=1e-7)
-        win = VelocityAutocorr(ag, fft=False).run()
+        win = VelocityAutocorr(ag, fft=False, device=device).run()
         np.testing.assert_almost_equal(fft.results.timeseries, win.results.timeseries, decimal=4)
         np.testing.assert_almost_equal(fft.results.vacf_by_particle, win.results.vacf_by_particle, decimal=4)
 
