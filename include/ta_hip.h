@@ -80,6 +80,7 @@ typedef struct ta_ctx ta_ctx;
 /* ---- context ---------------------------------------------------------- */
 int ta_ctx_create(int device, ta_ctx **out);
 int ta_ctx_destroy(ta_ctx *ctx);
+/* the returned string is a per-thread copy: valid until the calling thread's next ta_last_error() */
 const char *ta_last_error(const ta_ctx *ctx);
 /* number of visible HIP devices (0 when none / runtime unusable) */
 int ta_device_count(void);
