@@ -139,7 +139,10 @@ def main(n_cases, seed=1234):
         elif kind == "fft":
             e = int(rng.choice(edges))
             T = int(np.clip(e + rng.integers(-3, 2), 1, 10240)) if rng.random() < 0.6 else int(rng.integers(1, 10241))
-            A_all = int(rng.integers(1, 24 if T > 3000 else 60))
+            A_all = int(rng.integers(1, 24 if T > 3000 else 60 if T > 64 else 400))
+        elif rng.random() < 0.3:  # short trajectories (short_kernels.hpp): several waves' worth of particles
+            T = int(rng.integers(1, 66))
+            A_all = int(rng.integers(1, 400))
         else:  # (the matrix-core band kernels: several 256-lag groups now and then)
             T = int(rng.integers(1, 700)) if rng.random() < 0.8 else int(rng.integers(700, 3000))
             A_all = int(rng.integers(1, 50 if T < 700 else 12))
@@ -157,7 +160,7 @@ def main(n_cases, seed=1234):
         ctx.set_option("direct_nwg", int(rng.choice([0, 0, 1, 2, 5])))
         f32 = int(kind in ("direct", "helfand") and rng.random() < 0.3)
         ctx.set_option("direct_f32", f32)
-        ctx.set_option("direct_mfma", int(rng.choice([1, 3, 3, 0])))  # by length / matrix cores always / vector kernels
+        ctx.set_option("direct_mfma", int(rng.choice([1, 1, 3, 3, 0])))  # by length / matrix cores always / vector kernels
         hfft = int(kind == "helfand" and not f32 and rng.random() < 0.4)
         ctx.set_option("helfand_fft", hfft)  # S1 - 2 S2 through the FFT lag-sum path
         lag = torch.full((T,), -3.0, dtype=torch.float64, device="cuda")

@@ -279,6 +279,7 @@ def test_helfand_by_particle_on_the_matrix_cores(ctx, T, A, D):
     scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
     want_bp, want_ts = orc.helfand(v, x, m, vol, 300.0)
     ctx.set_option("timeline", 1)
+    ctx.set_option("short_max", 0)  # (up to 64 frames the library would take k_short: test_short_trajectory_kernels)
     try:
         ts_m, bp_m = run_helfand(ctx, v, x, m, scale, True)
         assert "k_band_bp_helf" in [n for n, _ in ctx.kernel_timeline()]
@@ -289,6 +290,7 @@ def test_helfand_by_particle_on_the_matrix_cores(ctx, T, A, D):
         assert "k_direct" in [n for n, _ in ctx.kernel_timeline()]
     finally:
         ctx.set_option("direct_mfma", 1)
+        ctx.set_option("short_max", 64)
         ctx.set_option("timeline", 0)
     assert bp_m.shape == (T, A) and not bp_m[0].any()
     assert scale_rel_err(bp_m, want_bp) < TOL and scale_rel_err(ts_m, want_ts) < TOL
@@ -1784,3 +1786,66 @@ def test_exception_inside_a_group_call_becomes_a_status():
         assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("D", [1, 2, 3])
+@pytest.mark.parametrize("T", [1, 2, 7, 8, 9, 31, 32, 33, 50, 63, 64])
+def test_short_trajectory_kernels(ctx, T, D):
+    """Up to 64 frames the by-particle arrays of all three quantities and the O(T^2) lag sums come from k_short
+    (short_kernels.hpp: a lane per column, every lag in its registers, the by-particle array written in place): against
+    the oracle (velocityautocorr.py:208-215 / :217-238, viscosity.py:201-233), against the kernels it replaces
+    ("short_max" 0: the 512-point transforms, the workgroup-per-particle correlators, the matrix-core Helfand form),
+    particle by particle and lag by lag; particle counts on both sides of a wave's 64 / 32 / 21 particles and of a
+    workgroup's four waves; same bits every launch; 65 frames take the old kernels."""
+    from oracle import numpy_oracle as orc
+
+    def names():
+        return [n for n, _ in ctx.kernel_timeline() if not n.startswith(("k_sum", "end", "memset"))]
+
+    ctx.set_option("timeline", 1)
+    try:
+        for A in (1, 2, 20, 21, 22, 64, 65, 85, 257, 1000):
+            v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=7000 + 13 * T + A)
+            x = x + 50.0
+            scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+            want_bp, want_ts = orc.vacf_windowed(v)
+            want_hb, want_hs = orc.helfand(v, x, m, vol, 300.0)
+            got = {}
+            for short in (64, 0):
+                ctx.set_option("short_max", short)
+                hs, hb = run_helfand(ctx, v, x, m, scale, True)
+                if short:
+                    assert names() == ["k_short"], names()
+                    again = ctx.helfand_msd(m, scale, by_particle=True)
+                    assert np.array_equal(again[0], hs) and np.array_equal(again[1], hb)
+                hs_l, _ = ctx.helfand_msd(m, scale, by_particle=False)
+                ts_d, bp_d = ctx.vacf_direct(by_particle=True)
+                ts_dl, _ = ctx.vacf_direct(by_particle=False)
+                if short:
+                    assert names() == ["k_short"], names()
+                ts_f, bp_f = ctx.vacf_fft(by_particle=True)
+                assert names() == (["k_short"] if short else ["k_w1_bp", "k_bp_transpose"]), names()
+                ts_fl, _ = ctx.vacf_fft(by_particle=False)  # ("short_lags_max": the FFT path's lag sums alone, up to 48 frames)
+                assert ("k_short" in names()) == bool(short and T <= 48), names()
+                got[short] = (hs, hb, hs_l, ts_d, bp_d, ts_dl, ts_f, bp_f, ts_fl)
+                assert hb.shape == (T, A) and not hb[0].any()
+                for a, w in ((hb, want_hb), (hs, want_hs), (hs_l, want_hs), (bp_d, want_bp), (ts_d, want_ts),
+                             (ts_dl, want_ts), (bp_f, want_bp), (ts_f, want_ts), (ts_fl, want_ts)):
+                    assert scale_rel_err(a, w) < TOL, (T, A, D, short)
+            for a, b in zip(got[64], got[0]):
+                assert scale_rel_err(a, b) < 1e-12, (T, A, D)
+            if T > 1:  # lag by lag, particle by particle (Helfand: short lags are far below the long ones)
+                rel = np.abs(got[64][1][1:] - got[0][1][1:]) / np.abs(got[0][1][1:])
+                assert rel.max() < 1e-9, (T, A, D, rel.max())
+        ctx.set_option("short_max", 64)
+        ctx.set_option("short_lags_max", 64)
+        ts_s, _ = ctx.vacf_fft(by_particle=False)
+        assert names() == ["k_short"] and scale_rel_err(ts_s, want_ts) < TOL
+        ctx.set_option("short_lags_max", 48)
+        v = orc.synthetic_velocities(65, 30, D, seed=65)
+        run_vacf(ctx, v, False, True)
+        assert "k_short" not in names()
+    finally:
+        ctx.set_option("short_max", 64)
+        ctx.set_option("short_lags_max", 48)
+        ctx.set_option("timeline", 0)

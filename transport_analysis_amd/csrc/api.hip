@@ -93,6 +93,11 @@ struct ta_ctx {
     int64_t opt_bp_block = 0;
     int64_t opt_bp_spec_atoms = 0;
     int64_t opt_bp_prefetch = 2;
+    // "short_max": trajectories of up to this many frames (<= 64) take the register-resident kernels of short_kernels.hpp
+    // wherever float64 slabs are asked for a by-particle array or an O(T^2) form (0: never); "short_lags_max": the FFT
+    // path's lag sums alone as well, up to this many frames (per 12 GB: 2.1 against 3.9 ms at 32 frames, 3.8 against 4.6 at
+    // 48, 4.1 against 3.8 at 64: profiles/r06_short.txt)
+    int64_t opt_short_max = 64, opt_short_lags_max = 48;
     int64_t opt_stage_device_f32 = 0;
     int64_t opt_fail_alloc_after = 0, opt_fail_throw_after = 0;  // test hooks of ensure()
     // ta_stage_commit hands its frame range to a worker thread that makes the HIP calls (copies in pieces, the
@@ -213,10 +218,33 @@ int check_shape(ta_ctx* ctx, int64_t T, int64_t A, int D, int64_t ld_row) {
     return TA_OK;
 }
 
+// Short trajectories (short_kernels.hpp): a lane per column, every lag in its registers; the by-particle array is written in
+// place, the lag sums leave as one row per wave
+bool short_applies(const ta_ctx* ctx, int64_t T) { return T <= ctx->opt_short_max && T <= short_max_frames(); }
+
+int short_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos, const double* d_masses, int64_t T, int64_t A,
+               int D, int64_t pitch, double scale, double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st) {
+    const int nwg = short_grid(ctx->n_cu, mode, (int)T, A, D, d_bp != nullptr);
+    const int rows = nwg * short_waves();
+    int rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)rows * T);
+    if (rc) return rc;
+    tl_mark(ctx, "k_short", st);
+    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
+    TA_HIP_TRY(ctx, launch_short(mode, nwg, d_vel, d_pos, d_masses, pitch, (int)T, A, D,
+                                 mode == MODE_HELFAND ? scale / (double)D : 1.0, d_bp, ld_bp, (double*)ctx->ts_partial.p, st));
+    TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
+    tl_mark(ctx, "k_sum_partials", st);
+    TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, rows, T, d_lagsum, st));
+    return TA_OK;
+}
+
 int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
                 const double* d_masses, int64_t T, int64_t A, int D, int64_t pitch, double scale,
                 double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st, bool src_f32 = false) {
     const bool f32 = ctx->opt_direct_f32 != 0;  // src_f32 only comes with it (compute_pm)
+    if (!f32 && !src_f32 && ctx->opt_direct_mfma == 1 && short_applies(ctx, T))  // ("direct_mfma" 0 / 3 force a form)
+        return short_impl(ctx, mode, (const double*)d_vel, (const double*)d_pos, d_masses, T, A, D, pitch, scale, d_lagsum, d_bp,
+                          ld_bp, st);
     // The O(T^2) correlators run on the matrix cores wherever that wins: FP64 (bandbp_kernels.hpp) and, for the float32
     // option's Helfand forms, FP32 (band32tp_kernels.hpp: P rounded once to float32 like the float32 vector kernel's staged
     // values, float32 products, float64 accumulation) -- the k-slots of the MFMA filled from the time axis.  "direct_mfma":
@@ -437,6 +465,8 @@ int fft_impl(ta_ctx* ctx, const double* pm, int64_t pitch, int64_t T, int64_t A,
     int R0 = 0, R = 1;
     if (!wfft_choose((long)T, &R0, &R))
         return direct_impl(ctx, MODE_VACF, pm, nullptr, nullptr, T, A, D, pitch, 1.0, d_lagsum, d_bp, ld_bp, st);
+    if (!pm_f32 && short_applies(ctx, T) && (d_bp || T <= ctx->opt_short_lags_max))
+        return short_impl(ctx, MODE_VACF, pm, nullptr, nullptr, T, A, D, pitch, 1.0, d_lagsum, d_bp, ld_bp, st);
     cd* tw = nullptr;
     if ((rc = get_wf_table(ctx, R0, R, &tw))) return rc;
     const int64_t Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
@@ -861,6 +891,8 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "fail_alloc_after")) ctx->opt_fail_alloc_after = value;
     else if (!strcmp(key, "fail_throw_after")) ctx->opt_fail_throw_after = value;
     else if (!strcmp(key, "bp_prefetch")) ctx->opt_bp_prefetch = value;
+    else if (!strcmp(key, "short_max")) ctx->opt_short_max = value;
+    else if (!strcmp(key, "short_lags_max")) ctx->opt_short_lags_max = value;
     else if (!strcmp(key, "stage_device_f32")) ctx->opt_stage_device_f32 = value;
     else if (!strcmp(key, "timeline")) ctx->opt_timeline = value;
     else if (!strcmp(key, "async_commit")) {

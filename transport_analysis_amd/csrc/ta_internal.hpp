@@ -83,6 +83,14 @@ int direct_max_wg_per_cu(int mode, bool f32, int L, int nt, size_t lds_bytes, bo
 hipError_t launch_helfand_product32(const void* vel, const void* pos, bool src_f32, const double* masses, long pitch, long T,
                                     long n_cols, int D, float* P32, hipStream_t st);
 
+// short.hip: trajectories of up to short_max_frames() frames, a lane per column (short_kernels.hpp); bp (n_frames, ld_bp) or
+// NULL; partial [nwg * short_waves()][T] lag sums per wave (normalised); factor 1 (VACF) or scale / D (Helfand)
+int short_max_frames();
+int short_waves();
+int short_grid(int n_cu, int mode, int T, long n_atoms, int D, bool by_particle);
+hipError_t launch_short(int mode, int nwg, const double* vel, const double* pos, const double* masses, long pitch, int T,
+                        long n_atoms, int D, double factor, double* bp, long ld_bp, double* partial, hipStream_t st);
+
 hipError_t launch_row_sums(const double* bp, long n_rows, long n_cols, long ld, double* out,
                            hipStream_t st);
 // bandbp.hip: the windowed VACF with its by-particle array on the FP64 matrix cores (atom-major scratch, zeroed inside)
