@@ -312,16 +312,27 @@ class Case:
             self.ctx.helfand_msd_staged(self.masses.data_ptr(), 1.0, self.lagsum.data_ptr(), d_bp, self.A,
                                         self.stream)
 
+    def on_short_kernel(self):
+        """up to 64 frames (float64 arithmetic on float64 slabs): k_short (short_kernels.hpp) -- every by-particle array, the
+        O(T^2) lag sums, and the FFT path's lag sums up to 48 frames"""
+        if self.T > 64 or self.float32 or self.slab32 or self.helfand_fft:
+            return False
+        return self.bp is not None or self.mode != "fft" or self.T <= 48
+
     def on_matrix_cores(self):
         """lag sums alone of the O(T^2) correlators: FP64 MFMA band kernel (band_kernels.hpp); the float32 option's
         Helfand lag sums: FP32 MFMA (band32_kernels.hpp)"""
         if self.mode == "helfand" and self.helfand_fft:
+            return False
+        if self.on_short_kernel():
             return False
         if self.bp is not None:  # by-particle arrays: the float32 Helfand form (dim = 3) and both float64 forms
             return self.mode == "helfand" or not self.float32
         return self.mode == "helfand" or (self.mode == "direct" and not self.float32)
 
     def kernel_name(self):
+        if self.on_short_kernel():
+            return "k_short"
         if self.on_matrix_cores():
             if self.bp is not None:
                 return "k_band32_tp" if self.float32 else ("k_band_bp_vacf" if self.mode == "direct" else "k_band_bp_helf")
@@ -381,6 +392,14 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
     if case.bp is not None:
         bytes_algo += T * A * 8  # the by-particle array written once
     gbps = bytes_algo / (kernel_ms * 1e-3) / 1e9
+    if case.on_short_kernel():
+        # k_short (short_kernels.hpp): O(T^2) in registers, HBM-bound: T A D 8 bytes in (x 2 with positions), T A 8 out
+        fl = (3.0 * D * A * T * (T - 1) / 2) if case.mode == "helfand" else (2.0 * D * A * T * (T + 1) / 2)
+        tf = fl / (kernel_ms * 1e-3) / 1e12
+        return {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                "traffic": None, "kernel": "k_short", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_algo,
+                "valu": {"achieved_tflops": tf, "peak": FP64_PEAK_TFLOPS, "frac": tf / FP64_PEAK_TFLOPS,
+                         "algorithmic_flops_per_launch": fl}}
     if case.mode == "fft" or helfand_fft:
         M = _lib.fft_plan_info(T)["M"]
         fl = fft_flops(T, A * D, M)

@@ -4,7 +4,8 @@
 #      >= 3 warm-ups, next to the hipEvent medians of the SAME run; FETCH/WRITE/TCC passes
 #   2. HBM-traffic passes (FETCH_SIZE, WRITE_SIZE in separate runs) of the other workloads:
 #      by-particle, direct configs[3] (matrix cores, with and without the by-particle array), Helfand float64 and float32
-#      shares (time-packed matrix-core kernels, with and without the by-particle array), helfand_fft, 20000-frame path
+#      shares (time-packed matrix-core kernels, with and without the by-particle array), helfand_fft, 20000-frame path,
+#      32 frames x 15.6 M atoms with the by-particle array (k_short)
 # Everything lands in gpurun_out/prof_<tag>*/; hbm_traffic.json accumulates the entries, keyed by
 # the library's hash.  usage: profile_all.sh TAG [quick]
 set -u
@@ -34,4 +35,5 @@ run long fft_20000x25000x3 k_wsplit_accum 4 --steps 3 --warmup 1 --frames 20000 
 run longbp fft_20000x25000x3_bp k_wsplit_accum+k_winverse+k_bp_transpose+k_sum_partials 3 --steps 2 --warmup 1 --frames 20000 --atoms 25000 --by-particle
 run slab32 fft_10000x100000x3_slab32 k_wsplit_accum 13 --steps 10 --warmup 3 --slab32
 run slab32bp fft_10000x100000x3_bp_slab32 k_wsplit_accum+k_winverse+k_bp_transpose+k_sum_partials 3 --steps 2 --warmup 1 --slab32 --by-particle
+run short fft_32x15624960x3_bp k_short+k_sum_partials 4 --steps 3 --warmup 1 --frames 32 --atoms 15624960 --by-particle
 cat $TA_TRAFFIC_MERGE
