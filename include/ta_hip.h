@@ -313,10 +313,16 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *                      difference-first vector kernel, pure trend included; needs T*A*D*8 (float32: *4) bytes for
  *                      the product slab, else the vector kernel runs).
  *                      1 (default) = by n_frames (these kernels fill a ring and run an epilogue per particle and lag
- *                      group): windowed VACF lag sums from 112 frames, by particle from 144 (below: vector kernel);
- *                      every Helfand form always.  0 = the vector kernels everywhere; 3 = matrix cores always.
+ *                      group): windowed VACF lag sums from 112 frames, by particle from 144 (below: the vector kernel;
+ *                      up to 64 frames see "short_max"); every Helfand form always (65 frames and up).
+ *                      0 = the vector kernels everywhere; 3 = matrix cores always.
  *                      (2, the column-packed forms of rounds 4-5 with their inline-assembly LDS-DMA, is rejected
  *                      since round 6: those kernels are tools/band/, built on demand as a second opinion.)
+ *   "short_max" n    : trajectories of up to n frames (default and maximum 64; 0 = never) take the register-resident
+ *                      kernels of short_kernels.hpp wherever float64 arithmetic on float64 slabs is asked for a
+ *                      by-particle array (all three quantities) or an O(T^2) form ("direct_mfma" 1 only: 0 and 3 force
+ *                      their forms): a lane per column, every lag in its registers, the by-particle array written in
+ *                      place.  "short_lags_max" n (default 48): the lag sums of ta_vacf_fft* alone as well, up to n frames.
  *   "helfand_fft" 0|1: ta_helfand_msd* evaluate the mean squared differences in O(T log T)
  *                      (n_frames <= 163840, else as default): sum (P[i]-P[i+k])^2 = S1(k) - 2 S2(k), S2 by the FFT
  *                      lag sums of the product slab P = (m v) x, S1 by prefix sums.  An
