@@ -326,6 +326,9 @@ class Case:
             return False
         if self.on_short_kernel():
             return False
+        # ("direct_mfma" 1: the vector kernel below these lengths, api.hip direct_impl / profiles/r06_direct_mid_sweep.txt)
+        if self.T < (513 if self.mode == "direct" else 448 if self.float32 else 352):
+            return False
         if self.bp is not None:  # by-particle arrays: the float32 Helfand form (dim = 3) and both float64 forms
             return self.mode == "helfand" or not self.float32
         return self.mode == "helfand" or (self.mode == "direct" and not self.float32)

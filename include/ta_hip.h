@@ -313,9 +313,9 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *                      difference-first vector kernel, pure trend included; needs T*A*D*8 (float32: *4) bytes for
  *                      the product slab, else the vector kernel runs).
  *                      1 (default) = by n_frames (these kernels fill a ring and run an epilogue per particle and lag
- *                      group): windowed VACF lag sums from 112 frames, by particle from 144 (below: the vector kernel;
- *                      up to 64 frames see "short_max"); every Helfand form always (65 frames and up).
- *                      0 = the vector kernels everywhere; 3 = matrix cores always.
+ *                      group; the vector kernel packs 2 - 8 particles into a wave under ~640 frames): windowed VACF from
+ *                      513 frames, Helfand float64 from 352, its float32 option from 448 (below: the vector kernel; up
+ *                      to 64 frames see "short_max").  0 = the vector kernels everywhere; 3 = matrix cores always.
  *                      (2, the column-packed forms of rounds 4-5 with their inline-assembly LDS-DMA, is rejected
  *                      since round 6: those kernels are tools/band/, built on demand as a second opinion.)
  *   "short_max" n    : trajectories of up to n frames (default and maximum 64; 0 = never) take the register-resident
@@ -336,6 +336,9 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *   "fft_nwg", "direct_nwg" : persistent workgroup counts (0 = automatic);
  *   "direct_chunk" 0|8|10, "direct_groups" n : force the direct correlators' lags per chunk /
  *                      cap the atoms a workgroup works on at once (0 = automatic);
+ *   "direct_subwave" 1|0 : the vector kernel's column groups may be 8, 16 or 32 lanes where a column has that few
+ *                      pairs of lag chunks (under ~640 frames): several particles per wave, 3x at 65 ... 256 frames
+ *                      (0: a whole wave per column, as before round 6);
  *   "stage_device_f32" 0|1 : device slabs allocated AFTERWARDS hold float32 elements when the host
  *                      slabs are TA_F32 (or there are none: ta_stage_alloc_device): half the
  *                      device footprint (BASELINE configs[4]: 12 GB instead of 24 GB per GPU).

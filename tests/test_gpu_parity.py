@@ -279,7 +279,7 @@ def test_helfand_by_particle_on_the_matrix_cores(ctx, T, A, D):
     scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
     want_bp, want_ts = orc.helfand(v, x, m, vol, 300.0)
     ctx.set_option("timeline", 1)
-    ctx.set_option("short_max", 0)  # (up to 64 frames the library would take k_short: test_short_trajectory_kernels)
+    ctx.set_option("direct_mfma", 3)  # (the default, 1, takes k_short up to 64 frames and the vector kernel up to 351)
     try:
         ts_m, bp_m = run_helfand(ctx, v, x, m, scale, True)
         assert "k_band_bp_helf" in [n for n, _ in ctx.kernel_timeline()]
@@ -290,7 +290,6 @@ def test_helfand_by_particle_on_the_matrix_cores(ctx, T, A, D):
         assert "k_direct" in [n for n, _ in ctx.kernel_timeline()]
     finally:
         ctx.set_option("direct_mfma", 1)
-        ctx.set_option("short_max", 64)
         ctx.set_option("timeline", 0)
     assert bp_m.shape == (T, A) and not bp_m[0].any()
     assert scale_rel_err(bp_m, want_bp) < TOL and scale_rel_err(ts_m, want_ts) < TOL
@@ -1526,10 +1525,11 @@ def test_kernel_timeline_sums_to_the_call(ctx):
 
 def test_direct_forms_by_trajectory_length(ctx):
     """"direct_mfma" 1 (the default) picks the form by n_frames: the matrix-core kernels pay a ring fill and an epilogue
-    per particle and lag group, so the windowed VACF of short trajectories runs the vector kernel — thresholds from
-    profiles/r05_direct_forms_sweep*.txt (the column-packed forms of those sweeps left the library in round 6); every
-    Einstein-Helfand form is on the matrix cores at every length.  Whatever is picked agrees with the forced forms, and
-    "direct_mfma" 2 is rejected."""
+    per particle and lag group, and the vector kernel packs 2 - 8 particles into a wave under ~640 frames ("direct_subwave"),
+    so the vector kernel runs the windowed VACF up to 512 frames, Einstein-Helfand float64 up to 351 and its float32 option up
+    to 447 — thresholds from profiles/r06_direct_mid_sweep.txt (up to 64 frames: k_short, test_short_trajectory_kernels).
+    Whatever is picked agrees with the forced forms, whole-wave column groups ("direct_subwave" 0) agree with the packed
+    ones, and "direct_mfma" 2 is rejected."""
     from oracle import numpy_oracle as orc
     from transport_analysis_amd import _lib
 
@@ -1540,23 +1540,33 @@ def test_direct_forms_by_trajectory_length(ctx):
         ctx.set_option("direct_mfma", 2)
     ctx.set_option("timeline", 1)
     try:
-        for T, vacf_bp, vacf_ls in ((100, "k_direct", "k_direct"), (120, "k_direct", "k_band_bp_vacf"),
-                                    (200, "k_band_bp_vacf", "k_band_bp_vacf"), (1600, "k_band_bp_vacf", "k_band_bp_vacf")):
-            v, x, m, vol = orc.synthetic_helfand(T, 5, 3, seed=41 + T)
+        for T, vacf, helf, helf32 in ((100, "k_direct", "k_direct", "k_direct"), (351, "k_direct", "k_direct", "k_direct"), (352, "k_direct", "k_band_bp_helf", "k_direct"),
+                                      (512, "k_direct", "k_band_bp_helf", "k_band32_tp"),
+                                      (513, "k_band_bp_vacf", "k_band_bp_helf", "k_band32_tp"),
+                                      (1600, "k_band_bp_vacf", "k_band_bp_helf", "k_band32_tp")):
+            v, x, m, vol = orc.synthetic_helfand(T, 37, 3, seed=41 + T)
             ts_d, bp_d = run_vacf(ctx, v, False, True)
-            assert names() == [vacf_bp], (T, names())
+            assert names() == [vacf], (T, names())
             ts_l, _ = ctx.vacf_direct(by_particle=False)
-            assert names() == [vacf_ls], (T, names())
+            assert names() == [vacf], (T, names())
             hs_b, hb = run_helfand(ctx, v, x, m, 1.0, True)
-            assert names() == ["k_band_bp_helf"], (T, names())
+            assert names() == [helf], (T, names())
             hs_l, _ = ctx.helfand_msd(m, 1.0, by_particle=False)
-            assert names() == ["k_band_bp_helf"], (T, names())
+            assert names() == [helf], (T, names())
             ctx.set_option("direct_f32", 1)
             fs_b, fb = ctx.helfand_msd(m, 1.0, by_particle=True)
-            assert names() == ["k_band32_tp"], (T, names())
+            assert names() == [helf32], (T, names())
             fs_l, _ = ctx.helfand_msd(m, 1.0, by_particle=False)
-            assert names() == ["k_band32_tp"], (T, names())
+            assert names() == [helf32], (T, names())
             ctx.set_option("direct_f32", 0)
+            if T <= 640:  # the same kernel with a whole wave per column (the lags per chunk may differ: 8 or 10)
+                ctx.set_option("direct_mfma", 0)
+                packed = ctx.helfand_msd(m, 1.0, by_particle=True)
+                ctx.set_option("direct_subwave", 0)
+                whole = ctx.helfand_msd(m, 1.0, by_particle=True)
+                assert scale_rel_err(packed[1], whole[1]) < 1e-12 and scale_rel_err(packed[0], whole[0]) < 1e-12
+                ctx.set_option("direct_subwave", 1)
+                ctx.set_option("direct_mfma", 1)
             for form in (3, 0):
                 ctx.set_option("direct_mfma", form)
                 assert scale_rel_err(ctx.helfand_msd(m, 1.0, by_particle=False)[0], hs_l) < 1e-11
@@ -1571,6 +1581,7 @@ def test_direct_forms_by_trajectory_length(ctx):
             ctx.set_option("direct_mfma", 1)
     finally:
         ctx.set_option("direct_mfma", 1)
+        ctx.set_option("direct_subwave", 1)
         ctx.set_option("direct_f32", 0)
         ctx.set_option("timeline", 0)
 

@@ -98,6 +98,7 @@ struct ta_ctx {
     // path's lag sums alone as well, up to this many frames (per 12 GB: 2.1 against 3.9 ms at 32 frames, 3.8 against 4.6 at
     // 48, 4.1 against 3.8 at 64: profiles/r06_short.txt)
     int64_t opt_short_max = 64, opt_short_lags_max = 48;
+    int64_t opt_direct_subwave = 1;  // "direct_subwave": k_direct's column groups may be 16 or 32 lanes (under ~640 frames)
     int64_t opt_stage_device_f32 = 0;
     int64_t opt_fail_alloc_after = 0, opt_fail_throw_after = 0;  // test hooks of ensure()
     // ta_stage_commit hands its frame range to a worker thread that makes the HIP calls (copies in pieces, the
@@ -248,14 +249,15 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
     // The O(T^2) correlators run on the matrix cores wherever that wins: FP64 (bandbp_kernels.hpp) and, for the float32
     // option's Helfand forms, FP32 (band32tp_kernels.hpp: P rounded once to float32 like the float32 vector kernel's staged
     // values, float32 products, float64 accumulation) -- the k-slots of the MFMA filled from the time axis.  "direct_mfma":
-    // 1 = by trajectory length (these kernels pay a ring fill and an epilogue per particle (block) and lag group; below ~100-150
-    // frames the vector kernels win the windowed VACF: profiles/r05_direct_forms_sweep*.txt, equal work, 64 ... 5000 frames),
+    // 1 = by trajectory length (these kernels pay a ring fill and an epilogue per particle (block) and lag group; the vector
+    // kernel, whose column groups are 8 - 32 lanes under ~640 frames, wins the windowed VACF up to 512 frames, Helfand float64
+    // up to 351, float32 up to 447: profiles/r06_direct_mid_sweep.txt, 12 GB of input at every length),
     // 3 = always, 0 = vector kernels (the parity tests' second opinion).  (The column-packed forms of rounds 4-5 --
     // "direct_mfma" 2, inline-assembly LDS-DMA -- live under tools/band/ since round 6.)
     const bool band_ok = !d_bp && !f32 && !src_f32 && ctx->opt_direct_mfma && T < ((int64_t)1 << 24);
     const int mf = (int)ctx->opt_direct_mfma;
     auto time_packed = [&](int64_t from_frames) { return mf == 3 || (mf == 1 && T >= from_frames); };
-    if (!d_bp && f32 && mode == MODE_HELFAND && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
+    if (!d_bp && f32 && mode == MODE_HELFAND && time_packed(448) && T < ((int64_t)1 << 24)) {
         const int64_t n_cols = A * D;
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK &&
             ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
@@ -272,7 +274,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         (void)hipGetLastError();  // out of memory for the product slab: the vector kernel needs none
     }
     // ... and with the by-particle array
-    if (d_bp && f32 && mode == MODE_HELFAND && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
+    if (d_bp && f32 && mode == MODE_HELFAND && time_packed(448) && T < ((int64_t)1 << 24)) {
         const int64_t n_cols = A * D, Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols, true)) == TA_OK &&
             ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
@@ -295,7 +297,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
     }
     // ... and the windowed VACF with its by-particle array (the class default) on the FP64 matrix cores: the k-slots
     // are filled from the time axis (bandbp_kernels.hpp)
-    if (d_bp && !f32 && !src_f32 && mode == MODE_VACF && time_packed(144) && T < ((int64_t)1 << 24)) {
+    if (d_bp && !f32 && !src_f32 && mode == MODE_VACF && time_packed(513) && T < ((int64_t)1 << 24)) {
         const int64_t Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
         if (ensure(ctx, ctx->bp_scratch, sizeof(double) * (size_t)A * Tp) == TA_OK &&
             ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)n_tiles * T) == TA_OK &&
@@ -314,7 +316,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         (void)hipGetLastError();
     }
     // ... and the Einstein-Helfand by-particle array (float64) the same way, on the product slab
-    if (d_bp && !f32 && !src_f32 && mode == MODE_HELFAND && ctx->opt_direct_mfma && T < ((int64_t)1 << 24)) {
+    if (d_bp && !f32 && !src_f32 && mode == MODE_HELFAND && time_packed(352) && T < ((int64_t)1 << 24)) {
         const int64_t n_cols = A * D, n_pairs = (n_cols + 1) / 2, Tp = pm_pitch(T), n_tiles = (A + 63) / 64;
         const int n_parts = (int)std::min<int64_t>(1024, n_pairs);
         if (ensure(ctx, ctx->helf_p, pm_bytes(T, n_cols)) == TA_OK &&
@@ -340,7 +342,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
     }
     // windowed VACF lag sums alone: the by-particle kernel with a unit's particles summed in its accumulators (work handed out
     // by a counter: 51.4 ms at 5000 x 50000 x 3)
-    if (band_ok && mode == MODE_VACF && time_packed(112) &&
+    if (band_ok && mode == MODE_VACF && time_packed(513) &&
         ensure(ctx, ctx->bp_scratch, sizeof(double) * band_bp_helf_partial_doubles(ctx->n_cu, (int)T, A)) == TA_OK &&
         ensure(ctx, ctx->unit_counter, 64) == TA_OK) {
         tl_mark(ctx, "k_band_bp_vacf", st);
@@ -350,7 +352,7 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
         return TA_OK;
     }
-    if (band_ok && mode == MODE_HELFAND) {
+    if (band_ok && mode == MODE_HELFAND && time_packed(352)) {
         // the product slab P = (m v) x first (T*A*D*8 bytes more; without them: the vector kernel); then the kernel of the
         // by-particle form with the particles of a unit summed in its accumulators (k-slots from the time axis: all four do
         // arithmetic: 463 ms per configs[4] share).
@@ -380,7 +382,9 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
     // (slower, any length).  L (8 or 10 lags per chunk) is the one that wastes fewer lanes
     // and SIMD slots for this n_frames.
     const size_t lds_cap = 160 * 1024;
-    struct Shape { int L, W, G; size_t col; bool gs; double eff; } best{0, 0, 0, 0, false, -1.0};
+    // Trajectories under ~1000 frames have fewer chunk pairs than a wave has lanes: a column group is then 16 or 32 LANES
+    // ("direct_subwave" 1, the default), several groups per wave, up to 64 atoms per workgroup.
+    struct Shape { int L, GT, G; size_t col; bool gs; double eff; } best{0, 0, 0, 0, false, -1.0};
     for (int L : {8, 10}) {
         if (ctx->opt_direct_chunk > 0 && L != ctx->opt_direct_chunk) continue;
         if (!direct_chunk_supported(L)) continue;
@@ -389,23 +393,27 @@ int direct_impl(ta_ctx* ctx, int mode, const void* d_vel, const void* d_pos,
         c.col = direct_lds_bytes((int)T, f32, L);
         c.gs = c.col > lds_cap;
         const int npairs = ((int)((T + L - 1) / L) + 1) / 2;
-        c.W = std::min(16, (npairs + 63) / 64);
-        c.G = 16 / c.W;
+        c.GT = 64 * std::min(16, (npairs + 63) / 64);  // threads per column group
+        if (ctx->opt_direct_subwave && npairs <= 32) c.GT = npairs <= 8 ? 8 : npairs <= 16 ? 16 : 32;
+        c.G = 1024 / c.GT;
         if (!c.gs) c.G = (int)std::min<size_t>(c.G, lds_cap / c.col);
         if (ctx->opt_direct_groups > 0) c.G = (int)std::min<int64_t>(c.G, ctx->opt_direct_groups);
         c.G = (int)std::max<int64_t>(1, std::min<int64_t>(c.G, A));
-        const int rounds = (npairs + c.W * 64 - 1) / (c.W * 64);
-        const int waves = c.G * c.W;
-        c.eff = (double)npairs / ((double)rounds * c.W * 64) *   // active lanes
+        if (c.GT < 64) c.G = std::max(64 / c.GT, c.G / (64 / c.GT) * (64 / c.GT));  // whole waves
+        const int rounds = (npairs + c.GT - 1) / c.GT;
+        const int waves = (c.G * c.GT + 63) / 64;
+        c.eff = (double)npairs / ((double)rounds * c.GT) *       // active lanes
                 (double)waves / (4.0 * ((waves + 3) / 4)) *      // SIMD balance
                 (1.0 - 0.6 / L);                                 // per-tile overhead
+        if (c.GT < 64)  // sub-wave groups: the lanes in use decide; at equal use 8 lags per chunk are 5 - 15 % ahead
+            c.eff = 2.0 + (double)npairs / ((double)rounds * c.GT) * (L == 8 ? 1.0 : 0.93);
         if (c.eff > best.eff) best = c;
     }
     if (best.eff < 0) return fail(ctx, TA_E_INVALID, "direct_chunk option: unsupported chunk size");
-    const int L = best.L, W = best.W, G = best.G;
+    const int L = best.L, G = best.G;
     const size_t col = best.col;
     const bool global_stage = best.gs;
-    const int gnt = W * 64, nt = G * gnt;
+    const int gnt = best.GT, nt = G * gnt;
     const size_t lds = global_stage ? 0 : col * (size_t)G;
     const int per_cu = direct_max_wg_per_cu(mode, f32, L, nt, lds, global_stage);
     int64_t nwg = ctx->opt_direct_nwg > 0 ? ctx->opt_direct_nwg : (int64_t)ctx->n_cu * per_cu;
@@ -892,6 +900,7 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "fail_throw_after")) ctx->opt_fail_throw_after = value;
     else if (!strcmp(key, "bp_prefetch")) ctx->opt_bp_prefetch = value;
     else if (!strcmp(key, "short_max")) ctx->opt_short_max = value;
+    else if (!strcmp(key, "direct_subwave")) ctx->opt_direct_subwave = value;
     else if (!strcmp(key, "short_lags_max")) ctx->opt_short_lags_max = value;
     else if (!strcmp(key, "stage_device_f32")) ctx->opt_stage_device_f32 = value;
     else if (!strcmp(key, "timeline")) ctx->opt_timeline = value;
