@@ -1051,6 +1051,9 @@ def other_configs(torch, dist, _lib, ctx, dev):
         # lag-point this input has
         ("float32 device slab (MDAnalysis' dtype), float64 arithmetic: FFT VACF timeseries 10000 x 100000 x 3", "fft", 10000, 100000, False, False, False, 10, 3, True),
         ("float32 device slab with vacf_by_particle: FFT VACF 10000 x 100000 x 3", "fft", 10000, 100000, True, False, False, 3, 1, True),
+        # millions of particles, a few dozen frames (k_short, short_kernels.hpp: a lane per column, every lag in its registers)
+        ("short trajectories: FFT VACF timeseries 32 x 15624960 x 3 (12 GB)", "fft", 32, 15624960, False, False, False, 5, 2),
+        ("short trajectories with vacf_by_particle (the array written in place): FFT VACF 32 x 15624960 x 3", "fft", 32, 15624960, True, False, False, 3, 1),
     ]
     for spec in specs:
         name, mode, T, A, byp, f32, hfft, steps, warm = spec[:9]
