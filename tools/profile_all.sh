@@ -36,4 +36,5 @@ run longbp fft_20000x25000x3_bp k_wsplit_accum+k_winverse+k_bp_transpose+k_sum_p
 run slab32 fft_10000x100000x3_slab32 k_wsplit_accum 13 --steps 10 --warmup 3 --slab32
 run slab32bp fft_10000x100000x3_bp_slab32 k_wsplit_accum+k_winverse+k_bp_transpose+k_sum_partials 3 --steps 2 --warmup 1 --slab32 --by-particle
 run short fft_32x15624960x3_bp k_short+k_sum_partials 4 --steps 3 --warmup 1 --frames 32 --atoms 15624960 --by-particle
+run shortls fft_32x15624960x3 k_short 7 --steps 5 --warmup 2 --frames 32 --atoms 15624960
 cat $TA_TRAFFIC_MERGE
