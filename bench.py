@@ -319,12 +319,19 @@ class Case:
             return False
         return self.bp is not None or self.mode != "fft" or self.T <= 48
 
+    def on_mid_kernel(self):
+        """65 < n_frames <= 512, float64 on float64 slabs: k_mid (mid_kernels.hpp) runs the windowed VACF from 97 frames and
+        the Einstein-Helfand sums from 97 to 128 ("mid_max")"""
+        if self.float32 or self.slab32 or self.helfand_fft or self.mode == "fft":
+            return False
+        return 97 <= self.T <= (512 if self.mode == "direct" else 128)
+
     def on_matrix_cores(self):
         """lag sums alone of the O(T^2) correlators: FP64 MFMA band kernel (band_kernels.hpp); the float32 option's
         Helfand lag sums: FP32 MFMA (band32_kernels.hpp)"""
         if self.mode == "helfand" and self.helfand_fft:
             return False
-        if self.on_short_kernel():
+        if self.on_short_kernel() or self.on_mid_kernel():
             return False
         # ("direct_mfma" 1: the vector kernel below these lengths, api.hip direct_impl / profiles/r06_direct_mid_sweep.txt)
         if self.T < (513 if self.mode == "direct" else 448 if self.float32 else 352):
@@ -336,6 +343,8 @@ class Case:
     def kernel_name(self):
         if self.on_short_kernel():
             return "k_short"
+        if self.on_mid_kernel():
+            return "k_mid"
         if self.on_matrix_cores():
             if self.bp is not None:
                 return "k_band32_tp" if self.float32 else ("k_band_bp_vacf" if self.mode == "direct" else "k_band_bp_helf")
@@ -438,7 +447,7 @@ def roofline_of(case, kernel_ms, helfand_fft=False, float32=False):
                         "reference_flops_tflops": tf, "reference_flops_frac": tf / mpeak})
         return out
     return {"bound": "valu", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-            "traffic": None, "kernel": "k_direct", "kernel_ms": kernel_ms,
+            "traffic": None, "kernel": case.kernel_name(), "kernel_ms": kernel_ms,
             "algorithmic_flops_per_launch": fl, "hbm_GBps_for_reference": gbps}
 
 

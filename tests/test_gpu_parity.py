@@ -1525,23 +1525,25 @@ def test_kernel_timeline_sums_to_the_call(ctx):
 
 def test_direct_forms_by_trajectory_length(ctx):
     """"direct_mfma" 1 (the default) picks the form by n_frames: the matrix-core kernels pay a ring fill and an epilogue
-    per particle and lag group, and the vector kernel packs 2 - 8 particles into a wave under ~640 frames ("direct_subwave"),
-    so the vector kernel runs the windowed VACF up to 512 frames, Einstein-Helfand float64 up to 351 and its float32 option up
-    to 447 — thresholds from profiles/r06_direct_mid_sweep.txt (up to 64 frames: k_short, test_short_trajectory_kernels).
+    per particle and lag group, and the vector kernels pack several particles into a wave under ~640 frames ("direct_subwave";
+    k_mid, test_mid_length_kernel), so vector kernels run the windowed VACF up to 512 frames (k_mid from 97), Einstein-Helfand
+    float64 up to 351 (k_mid from 97 to 128) and its float32 option up to 447 — thresholds from
+    profiles/r06_direct_mid_sweep.txt (up to 64 frames: k_short, test_short_trajectory_kernels).
     Whatever is picked agrees with the forced forms, whole-wave column groups ("direct_subwave" 0) agree with the packed
     ones, and "direct_mfma" 2 is rejected."""
     from oracle import numpy_oracle as orc
     from transport_analysis_amd import _lib
 
     def names():
-        return [n for n, _ in ctx.kernel_timeline() if n.startswith(("k_band", "k_direct"))]
+        return [n for n, _ in ctx.kernel_timeline() if n.startswith(("k_band", "k_direct", "k_mid"))]
 
     with pytest.raises(_lib.TAError, match="tools/band"):
         ctx.set_option("direct_mfma", 2)
     ctx.set_option("timeline", 1)
     try:
-        for T, vacf, helf, helf32 in ((100, "k_direct", "k_direct", "k_direct"), (351, "k_direct", "k_direct", "k_direct"), (352, "k_direct", "k_band_bp_helf", "k_direct"),
-                                      (512, "k_direct", "k_band_bp_helf", "k_band32_tp"),
+        for T, vacf, helf, helf32 in ((80, "k_direct", "k_direct", "k_direct"), (100, "k_mid", "k_mid", "k_direct"),
+                                      (351, "k_mid", "k_direct", "k_direct"), (352, "k_mid", "k_band_bp_helf", "k_direct"),
+                                      (512, "k_mid", "k_band_bp_helf", "k_band32_tp"),
                                       (513, "k_band_bp_vacf", "k_band_bp_helf", "k_band32_tp"),
                                       (1600, "k_band_bp_vacf", "k_band_bp_helf", "k_band32_tp")):
             v, x, m, vol = orc.synthetic_helfand(T, 37, 3, seed=41 + T)
@@ -1859,4 +1861,65 @@ def test_short_trajectory_kernels(ctx, T, D):
     finally:
         ctx.set_option("short_max", 64)
         ctx.set_option("short_lags_max", 48)
+        ctx.set_option("timeline", 0)
+
+
+@pytest.mark.parametrize("D", [1, 2, 3])
+@pytest.mark.parametrize("T", [65, 80, 96, 127, 128, 129, 200, 255, 256, 257, 300, 400, 511, 512])
+def test_mid_length_kernel(ctx, T, D):
+    """65 ... 512 frames: k_mid (mid_kernels.hpp: a lane per column and pair of 16-lag blocks, a sliding window in registers)
+    for the windowed VACF and the Einstein-Helfand sums, with and without the by-particle array, wherever it can run
+    ("mid_all" 1; by default: the windowed VACF from 97 frames, Helfand from 97 to 128) — against the oracle
+    (velocityautocorr.py:217-238, viscosity.py:201-233), against the kernels it replaces ("mid_max" 0), particle by
+    particle and lag by lag; frame counts on both sides of the 16-lag blocks and of the three launch shapes (64 / 32 / 16
+    columns per tile), particle counts on both sides of a tile; same bits every launch; 513 frames take the old kernels."""
+    from oracle import numpy_oracle as orc
+
+    def names():
+        return [n for n, _ in ctx.kernel_timeline() if not n.startswith(("k_sum", "end", "memset", "k_bp_transpose", "k_helfand_product"))]
+
+    ctx.set_option("timeline", 1)
+    try:
+        for A in (1, 5, 6, 10, 11, 21, 22, 64, 150):
+            v, x, m, vol = orc.synthetic_helfand(T, A, D, seed=9000 + 13 * T + A)
+            x = x + 50.0
+            scale = 1.0 / (2 * orc.BOLTZMANN_KJ_PER_MOL_K * np.average(vol) * 300.0)
+            want_bp, want_ts = orc.vacf_windowed(v)
+            want_hb, want_hs = orc.helfand(v, x, m, vol, 300.0)
+            got = {}
+            for mid in (512, 0):
+                ctx.set_option("mid_max", mid)
+                ctx.set_option("mid_all", 1)
+                hs, hb = run_helfand(ctx, v, x, m, scale, True)
+                if mid:
+                    assert names() == ["k_mid"], names()
+                    again = ctx.helfand_msd(m, scale, by_particle=True)
+                    assert np.array_equal(again[0], hs) and np.array_equal(again[1], hb)
+                else:
+                    assert "k_mid" not in names()
+                hs_l, _ = ctx.helfand_msd(m, scale, by_particle=False)
+                ts_d, bp_d = ctx.vacf_direct(by_particle=True)
+                ts_dl, _ = ctx.vacf_direct(by_particle=False)
+                assert ("k_mid" in names()) == bool(mid)
+                got[mid] = (hs, hb, hs_l, ts_d, bp_d, ts_dl)
+                assert hb.shape == (T, A) and not hb[0].any()
+                for a, w in ((hb, want_hb), (hs, want_hs), (hs_l, want_hs), (bp_d, want_bp), (ts_d, want_ts), (ts_dl, want_ts)):
+                    assert scale_rel_err(a, w) < TOL, (T, A, D, mid)
+            for a, b in zip(got[512], got[0]):
+                assert scale_rel_err(a, b) < 1e-12, (T, A, D)
+            rel = np.abs(got[512][1][1:] - got[0][1][1:]) / np.abs(got[0][1][1:])  # Helfand, lag by lag, particle by particle
+            assert rel.max() < 1e-9, (T, A, D, rel.max())
+        # the default choice
+        ctx.set_option("mid_max", 512)
+        ctx.set_option("mid_all", 0)
+        ctx.vacf_direct(by_particle=True)
+        assert ("k_mid" in names()) == (T >= 97), names()
+        ctx.helfand_msd(m, scale, by_particle=True)
+        assert ("k_mid" in names()) == (97 <= T <= 128), names()
+        v = orc.synthetic_velocities(513, 30, D, seed=65)
+        run_vacf(ctx, v, False, True)
+        assert "k_mid" not in names()
+    finally:
+        ctx.set_option("mid_max", 512)
+        ctx.set_option("mid_all", 0)
         ctx.set_option("timeline", 0)

@@ -12,7 +12,7 @@ def short(name):
     for key in ("k_wsplit_accum", "k_winverse", "k_w1_accum", "k_w1_bp", "k_wf_sum", "k_wf_fold", "k_wf_lags", "k_relayout",
                 "k_synth", "k_unlayout", "k_bp_transpose", "k_row_sums", "k_direct", "k_sum_partials",
                 "k_helfand_product32", "k_helfand_product", "k_helfand_combine", "k_band32_tp", "k_band32_lags", "k_band32_bp", "k_widen_f32", "k_helfand",
-                "k_band_bp_vacf", "k_band_bp_helf", "k_bandbp_gather", "k_band_lags", "k_band_gather", "k_short"):
+                "k_band_bp_vacf", "k_band_bp_helf", "k_bandbp_gather", "k_band_lags", "k_band_gather", "k_short", "k_mid"):
         if key in name:
             return key
     return name[:60]

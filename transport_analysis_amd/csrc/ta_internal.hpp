@@ -91,6 +91,19 @@ int short_grid(int n_cu, int mode, int T, long n_atoms, int D, bool by_particle)
 hipError_t launch_short(int mode, int nwg, const double* vel, const double* pos, const double* masses, long pitch, int T,
                         long n_atoms, int D, double factor, double* bp, long ld_bp, double* partial, hipStream_t st);
 
+// mid.hip: 65 ... mid_max_frames() frames, a lane per (column, pair of 16-lag blocks) walking a sliding window (mid_kernels.hpp);
+// bp (n_frames, ld_bp) or NULL; partial [nwg][T]; factor 1 (VACF) or scale / D (Helfand)
+struct MidShape {
+    int ncl_log2, nc, ts, threads;
+    size_t lds;
+};
+int mid_max_frames();
+MidShape mid_shape(int T, int D);
+void mid_set_ncl(int v);
+int mid_grid(int n_cu, int mode, int T, long n_atoms, int D);
+hipError_t launch_mid(int mode, int nwg, const double* vel, const double* pos, const double* masses, long pitch, int T,
+                      long n_atoms, int D, double factor, double* bp, long ld_bp, double* partial, hipStream_t st);
+
 hipError_t launch_row_sums(const double* bp, long n_rows, long n_cols, long ld, double* out,
                            hipStream_t st);
 // bandbp.hip: the windowed VACF with its by-particle array on the FP64 matrix cores (atom-major scratch, zeroed inside)
