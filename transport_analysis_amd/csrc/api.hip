@@ -98,7 +98,7 @@ struct ta_ctx {
     // path's lag sums alone as well, up to this many frames (per 12 GB: 2.1 against 3.9 ms at 32 frames, 3.8 against 4.6 at
     // 48, 4.1 against 3.8 at 64: profiles/r06_short.txt)
     int64_t opt_short_max = 64, opt_short_lags_max = 48;
-    int64_t opt_mid_max = 512, opt_mid_all = 0;  // k_mid (mid_kernels.hpp) under "direct_mfma" 1: see direct_impl
+    int64_t opt_mid_max = 512, opt_mid_all = 0, opt_mid_ncl = 0;  // k_mid (mid_kernels.hpp) under "direct_mfma" 1: see direct_impl
     int64_t opt_direct_subwave = 1;  // "direct_subwave": k_direct's column groups may be 16 or 32 lanes (under ~640 frames)
     int64_t opt_stage_device_f32 = 0;
     int64_t opt_fail_alloc_after = 0, opt_fail_throw_after = 0;  // test hooks of ensure()
@@ -243,13 +243,13 @@ int short_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos, 
 // 65 ... 512 frames (mid_kernels.hpp): a lane per (column, pair of 16-lag blocks), sliding window in registers
 int mid_impl(ta_ctx* ctx, int mode, const double* d_vel, const double* d_pos, const double* d_masses, int64_t T, int64_t A, int D,
              int64_t pitch, double scale, double* d_lagsum, double* d_bp, int64_t ld_bp, hipStream_t st) {
-    const int nwg = mid_grid(ctx->n_cu, mode, (int)T, A, D);
+    const int nwg = mid_grid(ctx->n_cu, mode, (int)T, A, D, (int)ctx->opt_mid_ncl);
     int rc = ensure(ctx, ctx->ts_partial, sizeof(double) * (size_t)nwg * T);
     if (rc) return rc;
     tl_mark(ctx, "k_mid", st);
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[1], st));
     TA_HIP_TRY(ctx, launch_mid(mode, nwg, d_vel, d_pos, d_masses, pitch, (int)T, A, D, mode == MODE_HELFAND ? scale / (double)D : 1.0,
-                               d_bp, ld_bp, (double*)ctx->ts_partial.p, st));
+                               d_bp, ld_bp, (double*)ctx->ts_partial.p, (int)ctx->opt_mid_ncl, st));
     TA_HIP_TRY(ctx, hipEventRecord(ctx->ev[2], st));
     tl_mark(ctx, "k_sum_partials", st);
     TA_HIP_TRY(ctx, launch_sum_partials((const double*)ctx->ts_partial.p, nwg, T, d_lagsum, st));
@@ -927,7 +927,7 @@ int ta_set_option(ta_ctx* ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "direct_subwave")) ctx->opt_direct_subwave = value;
     else if (!strcmp(key, "mid_max")) ctx->opt_mid_max = value;
     else if (!strcmp(key, "mid_all")) ctx->opt_mid_all = value;
-    else if (!strcmp(key, "mid_ncl")) mid_set_ncl((int)value);
+    else if (!strcmp(key, "mid_ncl")) ctx->opt_mid_ncl = value;
     else if (!strcmp(key, "short_lags_max")) ctx->opt_short_lags_max = value;
     else if (!strcmp(key, "stage_device_f32")) ctx->opt_stage_device_f32 = value;
     else if (!strcmp(key, "timeline")) ctx->opt_timeline = value;

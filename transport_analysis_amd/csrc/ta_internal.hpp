@@ -98,11 +98,10 @@ struct MidShape {
     size_t lds;
 };
 int mid_max_frames();
-MidShape mid_shape(int T, int D);
-void mid_set_ncl(int v);
-int mid_grid(int n_cu, int mode, int T, long n_atoms, int D);
+MidShape mid_shape(int T, int D, int ncl_log2 = 0);  // ncl_log2 3..6: lanes per pair of blocks forced (0: by n_frames)
+int mid_grid(int n_cu, int mode, int T, long n_atoms, int D, int ncl_log2);
 hipError_t launch_mid(int mode, int nwg, const double* vel, const double* pos, const double* masses, long pitch, int T,
-                      long n_atoms, int D, double factor, double* bp, long ld_bp, double* partial, hipStream_t st);
+                      long n_atoms, int D, double factor, double* bp, long ld_bp, double* partial, int ncl_log2, hipStream_t st);
 
 hipError_t launch_row_sums(const double* bp, long n_rows, long n_cols, long ld, double* out,
                            hipStream_t st);
