@@ -339,7 +339,8 @@ int ta_fft_plan_info(int64_t n_frames, int64_t *m_out, int *n_threads, int *n_st
  *   "mid_max" n      : trajectories of 97 ... n frames (default and maximum 512; 0 = never) take k_mid (mid_kernels.hpp: a
  *                      lane per column and pair of 16-lag blocks, a sliding window in registers) for the windowed VACF, and
  *                      for the Einstein-Helfand sums up to 128 frames, under "direct_mfma" 1 and float64 arithmetic;
- *                      "mid_all" 1: wherever the kernel can run (65 ... 512 frames, both quantities);
+ *                      "mid_all" 1: wherever the kernel can run (65 ... 512 frames, both quantities); "mid_ncl" 3..6:
+ *                      log2 of the lanes per pair of lag blocks, i.e. the columns per tile (tools/mid_shapes.py; 0: by length);
  *   "direct_subwave" 1|0 : the vector kernel's column groups may be 8, 16 or 32 lanes where a column has that few
  *                      pairs of lag chunks (under ~640 frames): several particles per wave, 3x at 65 ... 256 frames
  *                      (0: a whole wave per column, as before round 6);
